@@ -1,0 +1,216 @@
+"""ctypes binding of libbnf_hip.so (C ABI: include/bnf.h).
+
+There is deliberately no fallback: if the shared library (or a gfx950 device)
+is missing every compute call raises.  torch-ROCm tensors are used only as
+device-memory containers; the library receives raw pointers.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import spec as _spec
+
+_LIB_NAME = 'libbnf_hip.so'
+_lib = None
+
+ABI_VERSION = 1
+MAX_INPUTS, MAX_GROUPS, MAX_LAYERS, MAX_FREQS, MAX_INTERACT = 8, 12, 8, 96, 16
+DTYPE = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
+OBS = {'NORMAL': 0, 'NB': 1, 'ZINB': 2}
+MODE_MAP, MODE_VI = 0, 1
+
+EXPORTS = (
+    'bnf_abi_version', 'bnf_last_error', 'bnf_create', 'bnf_destroy',
+    'bnf_workspace_bytes', 'bnf_state_bytes', 'bnf_param_bytes', 'bnf_bind',
+    'bnf_init_params', 'bnf_train', 'bnf_vi_posterior_draws', 'bnf_forward',
+    'bnf_normal_mixture_quantiles', 'bnf_debug_loss_and_grad',
+    'bnf_debug_row_index', 'bnf_debug_vi_eps', 'bnf_debug_activation',
+    'bnf_debug_gemm_nt', 'bnf_profile_enable', 'bnf_profile_read',
+    'bnf_kernel_flops')
+
+
+class BnfConfig(C.Structure):
+  """Mirror of `struct bnf_config` (include/bnf.h); field order matters."""
+  _fields_ = [
+      ('abi_version', C.c_int32), ('device', C.c_int32), ('dtype', C.c_int32),
+      ('obs_model', C.c_int32), ('mode', C.c_int32),
+      ('n_inputs', C.c_int32), ('width', C.c_int32), ('depth', C.c_int32),
+      ('n_features', C.c_int32), ('n_params', C.c_int32),
+      ('n_groups', C.c_int32),
+      ('group_kind', C.c_int32 * MAX_GROUPS),
+      ('group_arg', C.c_int32 * MAX_GROUPS),
+      ('group_ncols', C.c_int32 * MAX_GROUPS),
+      ('group_col0', C.c_int32 * MAX_GROUPS),
+      ('group_scale_off', C.c_int32 * MAX_GROUPS),
+      ('fourier_degree', C.c_int32 * MAX_INPUTS),
+      ('input_scale', C.c_float * MAX_INPUTS),
+      ('n_freqs', C.c_int32),
+      ('freq', C.c_float * MAX_FREQS),
+      ('harmonic', C.c_float * MAX_FREQS),
+      ('n_interact', C.c_int32),
+      ('interact', (C.c_int32 * 2) * MAX_INTERACT),
+      ('off_log_noise_scale', C.c_int32), ('off_shape', C.c_int32),
+      ('off_inflated', C.c_int32),
+      ('off_bias', C.c_int32 * (MAX_LAYERS + 1)),
+      ('off_kernel', C.c_int32 * (MAX_LAYERS + 1)),
+      ('off_layer_scale', C.c_int32 * MAX_LAYERS),
+      ('off_output_scale', C.c_int32), ('off_lsa', C.c_int32),
+      ('off_act_weight', C.c_int32),
+      ('n_rows', C.c_int64), ('batch', C.c_int64),
+      ('members', C.c_int32), ('member_offset', C.c_int64),
+      ('vi_samples', C.c_int32), ('forward_only', C.c_int32),
+      ('learning_rate', C.c_float), ('prior_weight', C.c_float),
+      ('kl_weight', C.c_float),
+      ('seed', C.c_uint64),
+  ]
+
+
+def library_path() -> str:
+  return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def load():
+  """dlopen the engine (once) and declare prototypes.  Raises RuntimeError
+  with build instructions when the shared object is missing."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  path = library_path()
+  if not os.path.exists(path):
+    raise RuntimeError(
+        f'{path} not found. Build it with `python -c "import __graft_entry__ '
+        'as g; g.build()"` or `make -C bayesnf_amd/csrc`. bayesnf_amd has no '
+        'CPU fallback.')
+  lib = C.CDLL(path)
+  vp, i32, i64, f32p = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
+  lib.bnf_abi_version.restype = C.c_int
+  lib.bnf_last_error.restype = C.c_char_p
+  lib.bnf_create.argtypes = [C.POINTER(BnfConfig), C.POINTER(vp)]
+  lib.bnf_destroy.argtypes = [vp]
+  lib.bnf_destroy.restype = None
+  for name in ('bnf_workspace_bytes', 'bnf_state_bytes', 'bnf_param_bytes'):
+    getattr(lib, name).argtypes = [vp]
+    getattr(lib, name).restype = C.c_size_t
+  lib.bnf_bind.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+  lib.bnf_init_params.argtypes = [vp, C.c_float]
+  lib.bnf_train.argtypes = [vp, i64, i64, f32p]
+  lib.bnf_vi_posterior_draws.argtypes = [vp, i32, f32p]
+  lib.bnf_forward.argtypes = [vp, vp, i64, vp, i64, vp, vp]
+  lib.bnf_normal_mixture_quantiles.argtypes = [
+      vp, vp, vp, i64, i64, C.POINTER(C.c_float), i32, i32, vp]
+  lib.bnf_debug_loss_and_grad.argtypes = [vp, i64, i64, vp, vp]
+  lib.bnf_debug_row_index.argtypes = [vp, i64, i64, vp]
+  lib.bnf_debug_vi_eps.argtypes = [vp, i64, vp]
+  lib.bnf_debug_activation.argtypes = [vp, i32, vp]
+  lib.bnf_debug_gemm_nt.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+  lib.bnf_profile_enable.argtypes = [vp, i32]
+  lib.bnf_profile_read.argtypes = [
+      vp, C.POINTER(i32), C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+      C.POINTER(i64)]
+  lib.bnf_kernel_flops.argtypes = [vp, C.c_char_p]
+  lib.bnf_kernel_flops.restype = C.c_double
+  for name in EXPORTS:
+    getattr(lib, name)  # AttributeError here = stale .so missing an ABI symbol
+  if lib.bnf_abi_version() != ABI_VERSION:
+    raise RuntimeError('libbnf_hip.so ABI version mismatch')
+  _lib = lib
+  return lib
+
+
+def last_error() -> str:
+  return load().bnf_last_error().decode('utf-8', 'replace')
+
+
+def check(rc: int, what: str):
+  if rc == 0:
+    return
+  msg = f'{what}: {last_error()} (code {rc})'
+  if rc == -1:
+    raise ValueError(msg)
+  raise RuntimeError(msg)
+
+
+def seed_to_u64(seed) -> int:
+  """int, or anything shaped like a jax PRNGKey (2 x uint32) -> 64-bit seed."""
+  if isinstance(seed, (int, np.integer)):
+    return int(seed) & 0xFFFFFFFFFFFFFFFF
+  arr = np.asarray(seed).astype(np.uint64).reshape(-1)
+  if arr.size == 1:
+    return int(arr[0])
+  if arr.size != 2:
+    raise ValueError('seed must be an int or a length-2 uint32 array')
+  return (int(arr[0]) << 32) | (int(arr[1]) & 0xFFFFFFFF)
+
+
+def fold_in(seed_u64: int, data: int) -> int:
+  """Derive an independent 64-bit seed (stand-in for jax.random.fold_in used by
+  fit_map's num_splits loop, inference.py:434): splitmix64 of seed ^ golden*data."""
+  z = (seed_u64 ^ (0x9E3779B97F4A7C15 * (data + 1))) & 0xFFFFFFFFFFFFFFFF
+  z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+  z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+  return z ^ (z >> 31)
+
+
+def make_config(net: _spec.NetSpec, *, device, dtype, mode, n_rows, batch,
+                members, member_offset, seed, learning_rate=0.005,
+                prior_weight=1.0, kl_weight=1.0, vi_samples=1, forward_only=False) -> BnfConfig:
+  """Serialise a NetSpec + run arguments into the C struct."""
+  if net.D > MAX_INPUTS:
+    raise ValueError(f'at most {MAX_INPUTS} input columns are supported')
+  if len(net.groups) > MAX_GROUPS:
+    raise ValueError('too many feature groups')
+  if net.depth > MAX_LAYERS:
+    raise ValueError(f'depth > {MAX_LAYERS} not supported')
+  if net.freqs.size > MAX_FREQS:
+    raise ValueError(f'more than {MAX_FREQS} seasonal frequencies')
+  if net.interactions.shape[0] > MAX_INTERACT:
+    raise ValueError(f'more than {MAX_INTERACT} interactions')
+  if net.width % 64 or net.width < 64:
+    raise ValueError('width must be a positive multiple of 64 on this backend')
+  c = BnfConfig()
+  c.abi_version = ABI_VERSION
+  c.device = int(device)
+  c.dtype = DTYPE[dtype]
+  c.obs_model = OBS[net.observation_model]
+  c.mode = mode
+  c.n_inputs, c.width, c.depth = net.D, net.width, net.depth
+  c.n_features, c.n_params, c.n_groups = net.F, net.P, len(net.groups)
+  for i, g in enumerate(net.groups):
+    c.group_kind[i], c.group_arg[i] = g.kind, g.arg
+    c.group_ncols[i], c.group_col0[i] = g.ncols, g.col0
+    c.group_scale_off[i] = g.scale_offset
+  for d in range(net.D):
+    c.fourier_degree[d] = int(net.fourier_degrees[d])
+    c.input_scale[d] = float(np.float32(net.input_scales[d]))
+  c.n_freqs = int(net.freqs.size)
+  for j in range(net.freqs.size):
+    c.freq[j] = float(net.freqs[j])
+    c.harmonic[j] = float(net.harmonics[j])
+  c.n_interact = int(net.interactions.shape[0])
+  for k in range(c.n_interact):
+    c.interact[k][0] = int(net.interactions[k, 0])
+    c.interact[k][1] = int(net.interactions[k, 1])
+  c.off_log_noise_scale = net.offset('log_noise_scale')
+  c.off_shape = net.offset('shape')
+  c.off_inflated = net.offset('inflated_loc_probs')
+  for l in range(net.depth + 1):
+    c.off_bias[l] = net.offset(f'Dense_{l}/bias')
+    c.off_kernel[l] = net.offset(f'Dense_{l}/kernel')
+  for l in range(net.depth):
+    c.off_layer_scale[l] = net.offset(f'inv_sp_layer_scale{l}')
+  c.off_output_scale = net.offset('inv_sp_output_scale')
+  c.off_lsa = net.offset('log_scale_adjustment')
+  c.off_act_weight = net.offset('logit_activation_weight')
+  c.n_rows, c.batch = int(n_rows), int(batch)
+  c.members, c.member_offset = int(members), int(member_offset)
+  c.vi_samples = int(vi_samples)
+  c.forward_only = 1 if forward_only else 0
+  c.learning_rate = float(learning_rate)
+  c.prior_weight = float(prior_weight)
+  c.kl_weight = float(kl_weight)
+  c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+  return c

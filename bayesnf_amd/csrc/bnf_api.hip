@@ -1,0 +1,877 @@
+// bnf_api.hip -- host engine + C ABI (include/bnf.h) of libbnf_hip.so.
+//
+// The reference runs a whole fit() as ONE XLA program (inference.py:621 is the
+// single host->device dispatch).  Here the C side enqueues every kernel of every
+// step on the caller's HIP stream without ever synchronising, so Python is not
+// in the loop either.  One train step of all local members (MAP, depth L):
+//
+//   memset grad | pack weights | featurise | L x forward contraction |
+//   output+likelihood+last-layer backward | (L-1) x dgrad | dgrad0 | featurise bwd |
+//   L x wgrad | prior + Adam
+//
+// VI runs the same pipeline on members x S "virtual members" whose parameters
+// are the reparameterised samples, bracketed by k_vi_sample / k_vi_adam.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bnf.h"
+#include "bnf_gemm.h"
+#include "bnf_kernels.h"
+
+using namespace bnf;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess)                                                              \
+      return fail(BNF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                  __FILE__, __LINE__);                                                 \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// kernel ids for the event timer
+// ---------------------------------------------------------------------------
+enum KernelId {
+  KID_PACK = 0, KID_FEAT, KID_FWD0, KID_FWD, KID_OUT, KID_DGRAD, KID_DGRAD0, KID_FEATBWD,
+  KID_WGRAD0, KID_WGRAD, KID_ADAM, KID_VISAMPLE, KID_VIADAM, KID_COUNT
+};
+static const char* kKernelNames[KID_COUNT] = {
+    "pack_weights", "featurize", "gemm_fwd_l0", "gemm_fwd", "out_loss", "gemm_dgrad",
+    "gemm_dgrad0", "feat_bwd", "gemm_wgrad_l0", "gemm_wgrad", "adam_map", "vi_sample", "vi_adam"};
+
+struct TimedLaunch {
+  int kid;
+  hipEvent_t t0, t1;
+};
+
+struct bnf_handle {
+  bnf_config cfg;
+  NetDev nd;
+  FreqTab ft;
+  bool bf16 = false;
+  int es = 4;          // element size of T
+  int Ev = 0;          // virtual members = members * S
+  int S = 1;
+  int L = 0, W = 0, F = 0, Fp = 0, P = 0;
+  int64_t N = 0, B = 0, Bp = 0;
+  hipStream_t stream = nullptr;
+  bool bound = false;
+  int64_t adam_t = 0;  // optimiser step count
+  // caller buffers
+  float* params = nullptr;   // MAP theta (E,P) | VI mu (E,P) then rho (E,P)
+  float* state = nullptr;
+  char* ws = nullptr;
+  const float* X = nullptr;
+  const float* y = nullptr;
+  // carved from the workspace
+  float* theta_c = nullptr;  // VI: z samples (Ev,P); MAP: == params
+  float* grad = nullptr;
+  float* stab = nullptr;
+  float* stab_pred = nullptr;
+  void* H0 = nullptr; void* H0t = nullptr;
+  void* A[BNF_MAX_LAYERS]; void* H[BNF_MAX_LAYERS]; void* Ht[BNF_MAX_LAYERS];
+  void* dZ[BNF_MAX_LAYERS]; void* dZt[BNF_MAX_LAYERS];
+  void* Kn[BNF_MAX_LAYERS]; void* Kt[BNF_MAX_LAYERS];
+  int64_t pack_batch[BNF_MAX_LAYERS];
+  float* dH0 = nullptr; float* out = nullptr; float* ybat = nullptr; float* loss_raw = nullptr;
+  float* qscratch = nullptr;  // quantile partials: 2*1024*2 + 2 floats
+  float* dbg_a = nullptr; float* dbg_b = nullptr;  // small debug staging (gmu/grho)
+  uint8_t* is_matrix = nullptr;
+  size_t ws_bytes = 0;
+  // profiling
+  bool prof = false;
+  std::vector<TimedLaunch> timed;
+  std::vector<hipEvent_t> event_pool;
+  size_t pool_used = 0;
+  double acc_ms[KID_COUNT];
+  int64_t acc_calls[KID_COUNT];
+};
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// carve or just measure (base == nullptr) the workspace layout
+static size_t carve(bnf_handle* h, char* base) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) -> char* {
+    char* p = base ? base + off : nullptr;
+    off += (size_t)align_up((int64_t)bytes, 256);
+    return p;
+  };
+  const int64_t Ev = h->Ev, Bp = h->Bp, W = h->W, Fp = h->Fp, P = h->P, es = h->es;
+  const int nf2 = 2 * h->ft.n;
+  const bool fo = h->cfg.forward_only != 0;
+  h->grad = fo ? nullptr : (float*)take((size_t)Ev * P * 4);
+  if (h->cfg.mode == BNF_MODE_VI) h->theta_c = (float*)take((size_t)Ev * P * 4);
+  h->stab = (float*)take((size_t)std::max<int64_t>(1, h->N * nf2) * 4);
+  h->stab_pred = (float*)take((size_t)std::max<int64_t>(1, Bp * nf2) * 4);
+  h->H0 = take((size_t)Ev * Bp * Fp * es);
+  h->H0t = fo ? nullptr : take((size_t)Ev * Fp * Bp * es);
+  for (int l = 0; l < h->L; ++l) {
+    h->A[l] = take((size_t)Ev * Bp * W * es);
+    h->H[l] = take((size_t)Ev * Bp * W * es);
+    h->Ht[l] = (!fo && l < h->L - 1) ? take((size_t)Ev * W * Bp * es) : nullptr;
+    h->dZ[l] = fo ? nullptr : take((size_t)Ev * Bp * W * es);
+    h->dZt[l] = fo ? nullptr : take((size_t)Ev * W * Bp * es);
+    const int64_t npad = (l == 0) ? Fp : W;
+    h->pack_batch[l] = npad * W;
+    h->Kn[l] = take((size_t)Ev * npad * W * es);
+    h->Kt[l] = take((size_t)Ev * npad * W * es);
+  }
+  h->dH0 = fo ? nullptr : (float*)take((size_t)Ev * Bp * Fp * 4);
+  h->out = (float*)take((size_t)Ev * Bp * 4);
+  h->ybat = fo ? nullptr : (float*)take((size_t)Ev * Bp * 4);
+  h->loss_raw = (float*)take((size_t)Ev * 4);
+  h->qscratch = (float*)take((size_t)(4 * 1024 + 16) * 4);
+  h->dbg_a = (float*)take(256);
+  h->is_matrix = (uint8_t*)take((size_t)P);
+  return off;
+}
+
+// ---------------------------------------------------------------------------
+// timed launch helper
+// ---------------------------------------------------------------------------
+struct LaunchScope {
+  bnf_handle* h;
+  int kid;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  LaunchScope(bnf_handle* h_, int kid_) : h(h_), kid(kid_) {
+    if (!h->prof) return;
+    auto get = [&]() {
+      if (h->pool_used == h->event_pool.size()) {
+        hipEvent_t ev;
+        hipEventCreate(&ev);
+        h->event_pool.push_back(ev);
+      }
+      return h->event_pool[h->pool_used++];
+    };
+    t0 = get();
+    t1 = get();
+    hipEventRecord(t0, h->stream);
+  }
+  ~LaunchScope() {
+    if (!h->prof) return;
+    hipEventRecord(t1, h->stream);
+    h->timed.push_back({kid, t0, t1});
+  }
+};
+
+static void drain_timers(bnf_handle* h) {
+  for (auto& t : h->timed) {
+    hipEventSynchronize(t.t1);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.t0, t.t1) == hipSuccess) {
+      h->acc_ms[t.kid] += ms;
+      h->acc_calls[t.kid] += 1;
+    }
+  }
+  h->timed.clear();
+  h->pool_used = 0;
+}
+
+// ---------------------------------------------------------------------------
+// contraction launcher
+// ---------------------------------------------------------------------------
+template <typename T, int EPI, int TAG>
+static void launch_gemm(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep) {
+  g.tiles_m = (g.M + kBM - 1) / kBM;
+  g.tiles_n = (g.N + kBN - 1) / kBN;
+  if (g.splitk < 1) g.splitk = 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt<T, EPI, TAG>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
+    attr_set = true;
+  }
+  const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
+  LaunchScope ls(h, kid);
+  hipLaunchKernelGGL((gemm_nt<T, EPI, TAG>), dim3(blocks), dim3(kThreads), kGemmLds, h->stream, g, ep);
+}
+
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// pipeline pieces, templated on the storage type
+// ---------------------------------------------------------------------------
+template <typename T>
+static void run_pack(bnf_handle* h, const float* theta, int nmem) {
+  LaunchScope ls(h, KID_PACK);
+  for (int l = 0; l < h->L; ++l) {
+    const int n_in = (l == 0) ? h->F : h->W, n_pad = (l == 0) ? h->Fp : h->W;
+    dim3 grid((unsigned)((n_pad / 32) * (h->W / 32)), (unsigned)nmem);
+    hipLaunchKernelGGL((k_pack_weights<T>), grid, dim3(256), 0, h->stream, theta, (int64_t)h->P,
+                       h->nd.off_kernel[l], n_in, n_pad, h->W, (T*)h->Kn[l], (T*)h->Kt[l],
+                       h->pack_batch[l]);
+  }
+}
+
+// featurise + forward contractions for `rows` batch rows of `nmem` (virtual) members
+template <typename T>
+static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs,
+                        const float* X, const float* stab, const float* y, int64_t rows,
+                        bool train) {
+  const int64_t Bp = h->Bp;
+  {
+    LaunchScope ls(h, KID_FEAT);
+    dim3 grid(cdiv(rows, 256), (unsigned)nmem);
+    hipLaunchKernelGGL((k_featurize<T>), grid, dim3(256), 0, h->stream, h->nd, rs, X, stab, y,
+                       theta, (int64_t)h->P, rows, (T*)h->H0, Bp * h->Fp,
+                       train ? (T*)h->H0t : (T*)nullptr, (int64_t)h->Fp * Bp, (int32_t)Bp,
+                       train ? h->ybat : (float*)nullptr, Bp);
+  }
+  for (int l = 0; l < h->L; ++l) {
+    GemmArgs g{};
+    g.A = (l == 0) ? h->H0 : h->H[l - 1];
+    g.a_ld = (l == 0) ? h->Fp : h->W;
+    g.a_batch = Bp * g.a_ld;
+    g.B = h->Kt[l];
+    g.b_ld = (l == 0) ? h->Fp : h->W;
+    g.b_batch = h->pack_batch[l];
+    g.M = (int)rows;
+    g.N = h->W;
+    g.K = (l == 0) ? h->Fp : h->W;
+    g.splitk = 1;
+    g.members = nmem;
+    EpiArgs ep{};
+    ep.theta = theta;
+    ep.theta_stride = h->P;
+    ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->W));
+    ep.off_bias = h->nd.off_bias[l];
+    ep.off_layer_scale = h->nd.off_ls[l];
+    ep.off_act_weight = h->nd.off_law;
+    ep.out_a = h->A[l];
+    ep.out_h = h->H[l];
+    ep.out_t = (train && l < h->L - 1) ? h->Ht[l] : nullptr;
+    ep.act_batch = Bp * h->W;
+    ep.actt_batch = (int64_t)h->W * Bp;
+    ep.ld = h->W;
+    ep.ldt = (int32_t)Bp;
+    if (l == 0) launch_gemm<T, EPI_FWD, 0>(h, KID_FWD0, g, ep);
+    else launch_gemm<T, EPI_FWD, 1>(h, KID_FWD, g, ep);
+  }
+}
+
+struct LossSink {
+  float* loss; int64_t stride; float scale;   // loss[(e/S)*stride] += scale * step_loss
+  float* raw;                                  // optional per-virtual-member raw loss
+};
+
+// backward of one step: fills h->grad (likelihood part)
+template <typename T>
+static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs,
+                         int64_t rows, float c, const LossSink& sink) {
+  const int64_t Bp = h->Bp;
+  const int L = h->L;
+  {
+    OutArgs a{};
+    a.theta = theta; a.theta_stride = h->P; a.B = rows;
+    a.H = h->H[L - 1]; a.A = h->A[L - 1]; a.act_batch = Bp * h->W;
+    a.dZ = h->dZ[L - 1]; a.dZt = h->dZt[L - 1]; a.actt_batch = (int64_t)h->W * Bp; a.ldt = (int32_t)Bp;
+    a.ybat = h->ybat; a.ybat_batch = Bp; a.out = h->out; a.out_batch = Bp;
+    a.grad = h->grad; a.grad_stride = h->P;
+    a.loss = sink.loss; a.loss_stride = sink.stride; a.S = h->S; a.loss_scale = sink.scale;
+    a.c = c; a.loss_raw = sink.raw;
+    LaunchScope ls(h, KID_OUT);
+    dim3 grid(cdiv(rows, 32), (unsigned)nmem);
+    hipLaunchKernelGGL((k_out_loss<T, true>), grid, dim3(256), 0, h->stream, h->nd, a);
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    // dH_l = dZ_l . K_l^T / sqrt(fan_in_l)
+    GemmArgs g{};
+    g.A = h->dZ[l]; g.a_ld = h->W; g.a_batch = Bp * h->W;
+    g.B = h->Kn[l]; g.b_ld = h->W; g.b_batch = h->pack_batch[l];
+    g.M = (int)rows; g.K = h->W; g.splitk = 1; g.members = nmem;
+    EpiArgs ep{};
+    ep.theta = theta; ep.theta_stride = h->P;
+    ep.grad = h->grad; ep.grad_stride = h->P;
+    if (l > 0) {
+      g.N = h->W;
+      ep.scale = 1.0f / sqrtf((float)h->W);
+      ep.off_bias = h->nd.off_bias[l - 1];
+      ep.off_layer_scale = h->nd.off_ls[l - 1];
+      ep.off_act_weight = h->nd.off_law;
+      ep.in_a = h->A[l - 1];
+      ep.out_h = h->dZ[l - 1];
+      ep.out_t = h->dZt[l - 1];
+      ep.act_batch = Bp * h->W; ep.actt_batch = (int64_t)h->W * Bp;
+      ep.ld = h->W; ep.ldt = (int32_t)Bp;
+      launch_gemm<T, EPI_DGRAD, 1>(h, KID_DGRAD, g, ep);
+    } else {
+      g.N = h->Fp;
+      ep.scale = 1.0f / sqrtf((float)h->F);
+      ep.out_f32 = h->dH0; ep.f32_batch = Bp * h->Fp; ep.ld_f32 = h->Fp;
+      launch_gemm<T, EPI_DGRAD0, 0>(h, KID_DGRAD0, g, ep);
+    }
+  }
+  {
+    LaunchScope ls(h, KID_FEATBWD);
+    dim3 grid(cdiv(rows, 256), (unsigned)nmem);
+    const float* X = h->X;
+    hipLaunchKernelGGL(k_feat_bwd, grid, dim3(256), 0, h->stream, h->nd, rs, X, h->stab, theta,
+                       (int64_t)h->P, rows, h->dH0, Bp * h->Fp, h->grad, (int64_t)h->P);
+  }
+  for (int l = 0; l < L; ++l) {
+    // dK_l = H_l^T . dZ_l / sqrt(fan_in_l)   (contraction over the batch rows)
+    GemmArgs g{};
+    g.A = (l == 0) ? h->H0t : h->Ht[l - 1];
+    g.a_ld = (int32_t)Bp; g.a_batch = (int64_t)((l == 0) ? h->Fp : h->W) * Bp;
+    g.B = h->dZt[l]; g.b_ld = (int32_t)Bp; g.b_batch = (int64_t)h->W * Bp;
+    g.M = (l == 0) ? h->F : h->W; g.N = h->W; g.K = (int)Bp; g.members = nmem;
+    const int tiles = ((g.M + kBM - 1) / kBM) * ((g.N + kBN - 1) / kBN);
+    const int nk = (int)(Bp / (h->bf16 ? 64 : 32));
+    int sk = (1024 + nmem * tiles - 1) / (nmem * tiles);
+    sk = std::max(1, std::min(sk, std::max(1, nk / 4)));
+    g.splitk = sk;
+    EpiArgs ep{};
+    ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->W));
+    ep.grad = h->grad; ep.grad_stride = h->P; ep.off_out = h->nd.off_kernel[l]; ep.ld_f32 = h->W;
+    if (l == 0) launch_gemm<T, EPI_WGRAD, 0>(h, KID_WGRAD0, g, ep);
+    else launch_gemm<T, EPI_WGRAD, 1>(h, KID_WGRAD, g, ep);
+  }
+}
+
+static RowSrc make_rowsrc(const bnf_handle* h, int64_t epoch, int64_t step) {
+  RowSrc rs{};
+  rs.S = h->S;
+  rs.seed = h->cfg.seed;
+  rs.n_rows = h->N;
+  rs.member_offset = h->cfg.member_offset;
+  if (h->B >= h->N) {
+    rs.mode = 0;
+  } else if (h->cfg.mode == BNF_MODE_VI) {
+    rs.mode = 2;
+    rs.epoch = (uint64_t)step;  // VI: one shared random batch per optimisation step
+  } else {
+    rs.mode = 1;
+    rs.epoch = (uint64_t)epoch;
+    rs.pos0 = step * h->B;
+  }
+  return rs;
+}
+
+// One MAP/MLE step.  apply=false: leave params untouched, grad holds the full
+// gradient (likelihood + prior), loss_raw the step loss.
+template <typename T>
+static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& sink, bool apply) {
+  const RowSrc rs = make_rowsrc(h, epoch, step);
+  const int E = h->cfg.members;
+  HIPCHK(hipMemsetAsync(h->grad, 0, (size_t)h->Ev * h->P * 4, h->stream));
+  run_pack<T>(h, h->params, E);
+  run_forward<T>(h, h->params, E, rs, h->X, h->stab, h->y, h->B, true);
+  const float c = (float)((double)h->N / (double)h->B);
+  run_backward<T>(h, h->params, E, rs, h->B, c, sink);
+  AdamArgs a{};
+  a.theta = h->params; a.m = h->state; a.v = h->state + (int64_t)E * h->P; a.grad = h->grad;
+  a.stride = h->P; a.P = h->P; a.off_shape = h->nd.off_shape;
+  const int64_t t = h->adam_t + 1;
+  a.lr = h->cfg.learning_rate;
+  a.bc1 = (float)(1.0 - std::pow(0.9, (double)t));
+  a.bc2 = (float)(1.0 - std::pow(0.999, (double)t));
+  a.prior_weight = h->cfg.prior_weight;
+  a.loss = sink.loss; a.loss_stride = sink.stride; a.loss_scale = sink.scale;
+  a.apply = apply ? 1 : 0; a.loss_raw = sink.raw;
+  {
+    LaunchScope ls(h, KID_ADAM);
+    dim3 grid(cdiv(h->P, 256), (unsigned)E);
+    hipLaunchKernelGGL(k_adam_map, grid, dim3(256), 0, h->stream, a);
+  }
+  if (apply) h->adam_t = t;
+  return BNF_OK;
+}
+
+template <typename T>
+static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride, bool apply,
+                   float* gmu_out, float* grho_out) {
+  const RowSrc rs = make_rowsrc(h, 0, step);
+  const int E = h->cfg.members, S = h->S;
+  float* mu = h->params;
+  float* rho = h->params + (int64_t)E * h->P;
+  HIPCHK(hipMemsetAsync(h->grad, 0, (size_t)h->Ev * h->P * 4, h->stream));
+  {
+    LaunchScope ls(h, KID_VISAMPLE);
+    dim3 grid(cdiv(h->P, 256), (unsigned)E, (unsigned)S);
+    hipLaunchKernelGGL(k_vi_sample, grid, dim3(256), 0, h->stream, mu, rho, h->P, S, h->cfg.seed,
+                       h->cfg.member_offset, (uint64_t)step, (uint32_t)STREAM_VI_EPS, h->theta_c,
+                       (int64_t)S * h->P, (int64_t)h->P);
+  }
+  run_pack<T>(h, h->theta_c, h->Ev);
+  run_forward<T>(h, h->theta_c, h->Ev, rs, h->X, h->stab, h->y, h->B, true);
+  const float kl = h->cfg.kl_weight;
+  const float c = (float)((double)h->N / (double)h->B / (double)kl);
+  LossSink sink{loss, loss_stride, kl / (float)S, nullptr};
+  run_backward<T>(h, h->theta_c, h->Ev, rs, h->B, c, sink);
+  ViAdamArgs a{};
+  const int64_t EP = (int64_t)E * h->P;
+  a.mu = mu; a.rho = rho;
+  a.m_mu = h->state; a.v_mu = h->state + EP; a.m_rho = h->state + 2 * EP; a.v_rho = h->state + 3 * EP;
+  a.grad = h->grad; a.P = h->P; a.S = S; a.off_shape = h->nd.off_shape;
+  a.seed = h->cfg.seed; a.member_offset = h->cfg.member_offset; a.step = (uint64_t)step;
+  const int64_t t = h->adam_t + 1;
+  a.lr = h->cfg.learning_rate;
+  a.bc1 = (float)(1.0 - std::pow(0.9, (double)t));
+  a.bc2 = (float)(1.0 - std::pow(0.999, (double)t));
+  a.kl_weight = kl; a.loss = loss; a.loss_stride = loss_stride; a.apply = apply ? 1 : 0;
+  a.gmu_out = gmu_out; a.grho_out = grho_out;
+  {
+    LaunchScope ls(h, KID_VIADAM);
+    dim3 grid(cdiv(h->P, 256), (unsigned)E);
+    hipLaunchKernelGGL(k_vi_adam, grid, dim3(256), 0, h->stream, a);
+  }
+  if (apply) h->adam_t = t;
+  return BNF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int bnf_abi_version(void) { return BNF_ABI_VERSION; }
+const char* bnf_last_error(void) { return g_err; }
+
+int bnf_create(const bnf_config* cfg, bnf_handle** out) {
+  if (!cfg || !out) return fail(BNF_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != BNF_ABI_VERSION)
+    return fail(BNF_ERR_INVALID, "abi_version %d != %d", cfg->abi_version, BNF_ABI_VERSION);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(BNF_ERR_NO_DEVICE,
+                "no HIP device visible: the BayesNF engine has no CPU fallback (needs gfx950)");
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(BNF_ERR_INVALID, "device %d out of range (0..%d)", cfg->device, ndev - 1);
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(BNF_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                cfg->device, prop.gcnArchName);
+  if (cfg->dtype != BNF_DTYPE_F32 && cfg->dtype != BNF_DTYPE_BF16)
+    return fail(BNF_ERR_INVALID, "dtype %d", cfg->dtype);
+  if (cfg->obs_model != BNF_OBS_NORMAL)
+    return fail(BNF_ERR_INVALID, "observation model %d not supported by this build (NORMAL only)",
+                cfg->obs_model);
+  if (cfg->mode != BNF_MODE_MAP && cfg->mode != BNF_MODE_VI) return fail(BNF_ERR_INVALID, "mode");
+  if (cfg->n_inputs < 1 || cfg->n_inputs > BNF_MAX_INPUTS) return fail(BNF_ERR_INVALID, "n_inputs");
+  if (cfg->depth < 1 || cfg->depth > BNF_MAX_LAYERS) return fail(BNF_ERR_INVALID, "depth");
+  if (cfg->width < 64 || cfg->width % 64 != 0)
+    return fail(BNF_ERR_INVALID, "width %d must be a positive multiple of 64", cfg->width);
+  if (cfg->n_groups < 1 || cfg->n_groups > BNF_MAX_GROUPS) return fail(BNF_ERR_INVALID, "n_groups");
+  if (cfg->n_freqs < 0 || cfg->n_freqs > BNF_MAX_FREQS) return fail(BNF_ERR_INVALID, "n_freqs");
+  if (cfg->n_interact < 0 || cfg->n_interact > BNF_MAX_INTERACT)
+    return fail(BNF_ERR_INVALID, "n_interact");
+  if (cfg->n_features < 1 || cfg->n_params < 1) return fail(BNF_ERR_INVALID, "n_features/n_params");
+  if (cfg->members < 1) return fail(BNF_ERR_INVALID, "members");
+  if (cfg->n_rows < 1 || cfg->batch < 1 || cfg->batch > cfg->n_rows)
+    return fail(BNF_ERR_INVALID, "batch %lld / n_rows %lld", (long long)cfg->batch,
+                (long long)cfg->n_rows);
+  if (cfg->n_rows > 0x7fffffffLL) return fail(BNF_ERR_INVALID, "n_rows too large");
+  const int S = (cfg->mode == BNF_MODE_VI) ? cfg->vi_samples : 1;
+  if (S < 1 || S > 64) return fail(BNF_ERR_INVALID, "vi_samples");
+  if (cfg->mode == BNF_MODE_VI && !(cfg->kl_weight > 0.f)) return fail(BNF_ERR_INVALID, "kl_weight");
+  if ((int64_t)cfg->members * S > 65535) return fail(BNF_ERR_INVALID, "members * vi_samples > 65535");
+
+  bnf_handle* h = new bnf_handle();
+  h->cfg = *cfg;
+  h->bf16 = cfg->dtype == BNF_DTYPE_BF16;
+  h->es = h->bf16 ? 2 : 4;
+  h->S = S;
+  h->Ev = cfg->members * S;
+  h->L = cfg->depth; h->W = cfg->width; h->F = cfg->n_features; h->P = cfg->n_params;
+  h->Fp = (int)align_up(h->F, 64);
+  h->N = cfg->n_rows; h->B = cfg->batch; h->Bp = align_up(h->B, 128);
+  NetDev& nd = h->nd;
+  memset(&nd, 0, sizeof(nd));
+  nd.D = cfg->n_inputs; nd.F = h->F; nd.Fp = h->Fp; nd.W = h->W; nd.depth = h->L; nd.P = h->P;
+  nd.n_groups = cfg->n_groups; nd.n_freqs = cfg->n_freqs; nd.n_interact = cfg->n_interact;
+  nd.obs = cfg->obs_model;
+  for (int g = 0; g < cfg->n_groups; ++g) {
+    nd.group_kind[g] = cfg->group_kind[g]; nd.group_arg[g] = cfg->group_arg[g];
+    nd.group_ncols[g] = cfg->group_ncols[g]; nd.group_col0[g] = cfg->group_col0[g];
+    nd.group_scale_off[g] = cfg->group_scale_off[g];
+    if (cfg->group_col0[g] < 0 || cfg->group_col0[g] + cfg->group_ncols[g] > h->F ||
+        cfg->group_scale_off[g] < 0 || cfg->group_scale_off[g] >= h->P) {
+      delete h;
+      return fail(BNF_ERR_INVALID, "feature group %d out of range", g);
+    }
+  }
+  for (int d = 0; d < cfg->n_inputs; ++d) {
+    nd.fdeg[d] = cfg->fourier_degree[d];
+    nd.in_scale[d] = cfg->input_scale[d];
+    if (cfg->fourier_degree[d] < 0 || cfg->fourier_degree[d] > 24) {
+      delete h;
+      return fail(BNF_ERR_INVALID, "fourier_degree[%d]", d);
+    }
+  }
+  for (int k = 0; k < cfg->n_interact; ++k) {
+    nd.interact[k][0] = cfg->interact[k][0];
+    nd.interact[k][1] = cfg->interact[k][1];
+  }
+  nd.off_lns = cfg->off_log_noise_scale; nd.off_shape = cfg->off_shape; nd.off_infl = cfg->off_inflated;
+  for (int l = 0; l <= h->L; ++l) {
+    nd.off_bias[l] = cfg->off_bias[l];
+    nd.off_kernel[l] = cfg->off_kernel[l];
+  }
+  for (int l = 0; l < h->L; ++l) nd.off_ls[l] = cfg->off_layer_scale[l];
+  nd.off_os = cfg->off_output_scale; nd.off_lsa = cfg->off_lsa; nd.off_law = cfg->off_act_weight;
+  h->ft.n = cfg->n_freqs;
+  for (int j = 0; j < cfg->n_freqs; ++j) {
+    h->ft.f[j] = cfg->freq[j];
+    h->ft.h[j] = cfg->harmonic[j];
+  }
+  for (int k = 0; k < KID_COUNT; ++k) { h->acc_ms[k] = 0; h->acc_calls[k] = 0; }
+  h->ws_bytes = carve(h, nullptr);
+  *out = h;
+  return BNF_OK;
+}
+
+void bnf_destroy(bnf_handle* h) {
+  if (!h) return;
+  for (auto ev : h->event_pool) hipEventDestroy(ev);
+  delete h;
+}
+
+size_t bnf_workspace_bytes(const bnf_handle* h) { return h ? h->ws_bytes : 0; }
+size_t bnf_param_bytes(const bnf_handle* h) {
+  if (!h) return 0;
+  return (size_t)h->cfg.members * h->P * 4 * (h->cfg.mode == BNF_MODE_VI ? 2 : 1);
+}
+size_t bnf_state_bytes(const bnf_handle* h) {
+  if (!h) return 0;
+  return (size_t)h->cfg.members * h->P * 4 * (h->cfg.mode == BNF_MODE_VI ? 4 : 2);
+}
+
+int bnf_bind(bnf_handle* h, void* params, void* opt_state, void* workspace, const float* X,
+             const float* y, void* stream) {
+  if (!h || !workspace) return fail(BNF_ERR_INVALID, "null argument");
+  if (!h->cfg.forward_only && (!params || !opt_state || !X))
+    return fail(BNF_ERR_INVALID, "params / opt_state / X are required for a training handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  h->stream = (hipStream_t)stream;
+  h->params = (float*)params;
+  h->state = (float*)opt_state;
+  h->ws = (char*)workspace;
+  h->X = X;
+  h->y = y;
+  carve(h, h->ws);
+  if (h->cfg.mode != BNF_MODE_VI) h->theta_c = h->params;
+  HIPCHK(hipMemsetAsync(h->ws, 0, h->ws_bytes, h->stream));
+  if (h->state) HIPCHK(hipMemsetAsync(h->state, 0, bnf_state_bytes(h), h->stream));
+  // which entries are Dense kernels (rank-2 leaves)
+  std::vector<uint8_t> mm((size_t)h->P, 0);
+  for (int l = 0; l <= h->L; ++l) {
+    const int64_t n_in = (l == 0) ? h->F : h->W, n_out = (l == h->L) ? 1 : h->W;
+    for (int64_t i = 0; i < n_in * n_out; ++i) mm[(size_t)h->nd.off_kernel[l] + i] = 1;
+  }
+  HIPCHK(hipMemcpyAsync(h->is_matrix, mm.data(), (size_t)h->P, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));  // mm is a stack-owned host buffer
+  if (h->ft.n > 0 && X) {
+    hipLaunchKernelGGL(k_seasonal_table, dim3(cdiv(h->N, 256)), dim3(256), 0, h->stream, X, h->N,
+                       h->nd.D, h->ft, h->stab);
+  }
+  HIPCHK(hipGetLastError());
+  h->bound = true;
+  h->adam_t = 0;
+  return BNF_OK;
+}
+
+int bnf_init_params(bnf_handle* h, float log_noise_init) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "bnf_init_params before bnf_bind");
+  if (h->cfg.forward_only || !h->params) return fail(BNF_ERR_STATE, "forward_only handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int E = h->cfg.members;
+  dim3 grid(cdiv(h->P, 256), (unsigned)E);
+  hipLaunchKernelGGL(k_init_params, grid, dim3(256), 0, h->stream, h->params, h->P, h->is_matrix,
+                     h->nd.off_lns, log_noise_init, h->cfg.seed, h->cfg.member_offset);
+  if (h->cfg.mode == BNF_MODE_VI) {
+    const int64_t n = (int64_t)E * h->P;
+    // softplus^-1(0.3) = log(expm1(0.3)) = -1.0502256128148466
+    hipLaunchKernelGGL(k_fill, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, h->params + n, n,
+                       -1.0502256128148466f);
+  }
+  HIPCHK(hipMemsetAsync(h->state, 0, bnf_state_bytes(h), h->stream));
+  HIPCHK(hipGetLastError());
+  h->adam_t = 0;
+  return BNF_OK;
+}
+
+int bnf_train(bnf_handle* h, int64_t epoch0, int64_t num_epochs, float* losses) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "bnf_train before bnf_bind");
+  if (!losses || num_epochs < 0) return fail(BNF_ERR_INVALID, "losses / num_epochs");
+  if (!h->y) return fail(BNF_ERR_STATE, "bnf_train needs a target bound");
+  if (h->cfg.forward_only) return fail(BNF_ERR_STATE, "handle was created forward_only");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int E = h->cfg.members;
+  HIPCHK(hipMemsetAsync(losses, 0, (size_t)E * num_epochs * 4, h->stream));
+  int rc = BNF_OK;
+  if (h->cfg.mode == BNF_MODE_MAP) {
+    const int64_t steps = h->N / h->B;  // ragged tail dropped (inference.py:583-589)
+    for (int64_t ep = 0; ep < num_epochs && rc == BNF_OK; ++ep) {
+      for (int64_t s = 0; s < steps && rc == BNF_OK; ++s) {
+        LossSink sink{losses + ep, num_epochs, 1.0f / (float)steps, nullptr};
+        rc = h->bf16 ? step_map<bf16_t>(h, epoch0 + ep, s, sink, true)
+                     : step_map<float>(h, epoch0 + ep, s, sink, true);
+      }
+    }
+  } else {
+    for (int64_t st = 0; st < num_epochs && rc == BNF_OK; ++st) {
+      rc = h->bf16 ? step_vi<bf16_t>(h, epoch0 + st, losses + st, num_epochs, true, nullptr, nullptr)
+                   : step_vi<float>(h, epoch0 + st, losses + st, num_epochs, true, nullptr, nullptr);
+    }
+  }
+  if (rc != BNF_OK) return rc;
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
+int bnf_vi_posterior_draws(bnf_handle* h, int32_t n_draws, float* out) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "not bound");
+  if (h->cfg.mode != BNF_MODE_VI) return fail(BNF_ERR_STATE, "not a VI handle");
+  if (n_draws < 1 || n_draws > 65535 || !out) return fail(BNF_ERR_INVALID, "n_draws/out");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int E = h->cfg.members;
+  dim3 grid(cdiv(h->P, 256), (unsigned)E, (unsigned)n_draws);
+  // out[d][e][p]: member stride P, sample stride E*P
+  hipLaunchKernelGGL(k_vi_sample, grid, dim3(256), 0, h->stream, h->params,
+                     h->params + (int64_t)E * h->P, h->P, n_draws, h->cfg.seed,
+                     h->cfg.member_offset, (uint64_t)0, (uint32_t)STREAM_VI_DRAW, out, (int64_t)h->P,
+                     (int64_t)E * h->P);
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
+int bnf_forward(bnf_handle* h, const float* theta, int64_t n_members, const float* Xnew,
+                int64_t n_rows, float* loc, float* aux) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "bnf_forward before bnf_bind");
+  if (!theta || !Xnew || !loc || n_members < 1 || n_rows < 1) return fail(BNF_ERR_INVALID, "argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int64_t row_chunk = h->Bp, mem_chunk = h->Ev;
+  RowSrc rs{};
+  rs.mode = 0; rs.S = 1;
+  for (int64_t m0 = 0; m0 < n_members; m0 += mem_chunk) {
+    const int nm = (int)std::min<int64_t>(mem_chunk, n_members - m0);
+    const float* th = theta + m0 * h->P;
+    if (h->bf16) run_pack<bf16_t>(h, th, nm); else run_pack<float>(h, th, nm);
+    for (int64_t r0 = 0; r0 < n_rows; r0 += row_chunk) {
+      const int64_t rows = std::min<int64_t>(row_chunk, n_rows - r0);
+      const float* Xc = Xnew + r0 * h->nd.D;
+      if (h->ft.n > 0)
+        hipLaunchKernelGGL(k_seasonal_table, dim3(cdiv(rows, 256)), dim3(256), 0, h->stream, Xc, rows,
+                           h->nd.D, h->ft, h->stab_pred);
+      OutArgs a{};
+      a.theta = th; a.theta_stride = h->P; a.B = rows;
+      a.H = h->H[h->L - 1]; a.A = h->A[h->L - 1]; a.act_batch = h->Bp * h->W;
+      a.out = loc + m0 * n_rows + r0; a.out_batch = n_rows;
+      a.S = 1;
+      if (h->bf16) {
+        run_forward<bf16_t>(h, th, nm, rs, Xc, h->stab_pred, nullptr, rows, false);
+        hipLaunchKernelGGL((k_out_loss<bf16_t, false>), dim3(cdiv(rows, 32), (unsigned)nm), dim3(256),
+                           0, h->stream, h->nd, a);
+      } else {
+        run_forward<float>(h, th, nm, rs, Xc, h->stab_pred, nullptr, rows, false);
+        hipLaunchKernelGGL((k_out_loss<float, false>), dim3(cdiv(rows, 32), (unsigned)nm), dim3(256), 0,
+                           h->stream, h->nd, a);
+      }
+    }
+  }
+  if (aux)
+    hipLaunchKernelGGL(k_forecast_aux, dim3(cdiv(n_members, 256)), dim3(256), 0, h->stream, theta,
+                       (int64_t)h->P, (int32_t)n_members, h->nd.off_lns, h->nd.off_shape,
+                       h->nd.off_infl, aux);
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
+int bnf_normal_mixture_quantiles(bnf_handle* h, const float* means, const float* scales,
+                                 int64_t n_members, int64_t n_rows, const float* q, int32_t n_q,
+                                 int32_t approximate, float* out) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "not bound");
+  if (!means || !scales || !q || !out || n_members < 1 || n_rows < 1 || n_q < 0)
+    return fail(BNF_ERR_INVALID, "argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  float* mpart = h->qscratch;
+  float* spart = h->qscratch + 2048;
+  float* bracket = h->qscratch + 4096;
+  if (!approximate) {
+    const int nb_m = (int)std::min<int64_t>(1024, cdiv(n_members * n_rows, 256));
+    const int nb_s = (int)std::min<int64_t>(1024, cdiv(n_members, 256));
+    hipLaunchKernelGGL(k_minmax_partial, dim3(nb_m), dim3(256), 0, h->stream, means,
+                       n_members * n_rows, mpart);
+    hipLaunchKernelGGL(k_minmax_partial, dim3(nb_s), dim3(256), 0, h->stream, scales, n_members, spart);
+    hipLaunchKernelGGL(k_bracket, dim3(1), dim3(64), 0, h->stream, mpart, nb_m, spart, nb_s, bracket);
+  }
+  for (int i = 0; i < n_q; ++i) {
+    if (approximate)
+      hipLaunchKernelGGL(k_quantile_approx, dim3(cdiv(n_rows, 256)), dim3(256), 0, h->stream, means,
+                         scales, n_members, n_rows, q[i], out + (int64_t)i * n_rows);
+    else
+      hipLaunchKernelGGL(k_quantile_root, dim3(cdiv(n_rows, 256)), dim3(256), 0, h->stream, means,
+                         scales, n_members, n_rows, bracket, q[i], out + (int64_t)i * n_rows);
+  }
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
+// ---- debug / introspection ---------------------------------------------------
+int bnf_debug_loss_and_grad(bnf_handle* h, int64_t epoch, int64_t step, float* grads, float* loss) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "not bound");
+  if (h->cfg.forward_only) return fail(BNF_ERR_STATE, "forward_only handle");
+  if (!grads || !loss) return fail(BNF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int E = h->cfg.members;
+  int rc;
+  if (h->cfg.mode == BNF_MODE_MAP) {
+    HIPCHK(hipMemsetAsync(h->loss_raw, 0, (size_t)h->Ev * 4, h->stream));
+    HIPCHK(hipMemsetAsync(loss, 0, (size_t)E * 4, h->stream));
+    LossSink sink{loss, 1, 1.0f, nullptr};
+    rc = h->bf16 ? step_map<bf16_t>(h, epoch, step, sink, false) : step_map<float>(h, epoch, step, sink, false);
+    if (rc != BNF_OK) return rc;
+    HIPCHK(hipMemcpyAsync(grads, h->grad, (size_t)E * h->P * 4, hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    HIPCHK(hipMemsetAsync(loss, 0, (size_t)E * 4, h->stream));
+    float* gmu = grads;
+    float* grho = grads + (int64_t)E * h->P;
+    rc = h->bf16 ? step_vi<bf16_t>(h, step, loss, 1, false, gmu, grho)
+                 : step_vi<float>(h, step, loss, 1, false, gmu, grho);
+    if (rc != BNF_OK) return rc;
+  }
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
+int bnf_debug_row_index(bnf_handle* h, int64_t epoch, int64_t step, int32_t* out) {
+  if (!h || !h->bound || !out) return fail(BNF_ERR_STATE, "not bound / null");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RowSrc rs = make_rowsrc(h, epoch, step);
+  rs.S = 1;  // indexed by real member
+  dim3 grid(cdiv(h->B, 256), (unsigned)h->cfg.members);
+  hipLaunchKernelGGL(k_row_index, grid, dim3(256), 0, h->stream, rs, h->B, out);
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
+int bnf_debug_vi_eps(bnf_handle* h, int64_t step, float* out) {
+  if (!h || !h->bound || !out) return fail(BNF_ERR_STATE, "not bound / null");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  dim3 grid(cdiv(h->P, 256), (unsigned)h->cfg.members, (unsigned)h->S);
+  hipLaunchKernelGGL(k_vi_eps_dump, grid, dim3(256), 0, h->stream, h->P, h->cfg.seed,
+                     h->cfg.member_offset, (uint64_t)step, out);
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
+int bnf_debug_activation(bnf_handle* h, int32_t what, float* out) {
+  if (!h || !h->bound || !out) return fail(BNF_ERR_STATE, "not bound / null");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int64_t B = h->B, Bp = h->Bp;
+  const void* src = nullptr;
+  int64_t batch = 0; int ld = 0, cols = 0;
+  if (what == 0) { src = h->H0; batch = Bp * h->Fp; ld = h->Fp; cols = h->F; }
+  else if (what >= 1 && what <= h->L) { src = h->H[what - 1]; batch = Bp * h->W; ld = h->W; cols = h->W; }
+  else if (what >= 100 && what < 100 + h->L) { src = h->A[what - 100]; batch = Bp * h->W; ld = h->W; cols = h->W; }
+  else if (what >= 300 && what < 300 + h->L) { src = h->dZ[what - 300]; batch = Bp * h->W; ld = h->W; cols = h->W; }
+  else if (what == 200) {
+    for (int e = 0; e < h->Ev; ++e)
+      HIPCHK(hipMemcpyAsync(out + (int64_t)e * B, h->out + (int64_t)e * Bp, (size_t)B * 4,
+                            hipMemcpyDeviceToDevice, h->stream));
+    return BNF_OK;
+  } else if (what == 400) {  // dH0 (Ev, B, F) f32
+    dim3 grid(cdiv(B * h->F, 256), (unsigned)h->Ev);
+    hipLaunchKernelGGL((k_to_f32<float>), grid, dim3(256), 0, h->stream, (const float*)h->dH0,
+                       Bp * h->Fp, h->Fp, B, h->F, out);
+    HIPCHK(hipGetLastError());
+    return BNF_OK;
+  } else {
+    return fail(BNF_ERR_INVALID, "what=%d", what);
+  }
+  dim3 grid(cdiv(B * cols, 256), (unsigned)h->Ev);
+  if (h->bf16)
+    hipLaunchKernelGGL((k_to_f32<bf16_t>), grid, dim3(256), 0, h->stream, (const bf16_t*)src, batch, ld, B, cols, out);
+  else
+    hipLaunchKernelGGL((k_to_f32<float>), grid, dim3(256), 0, h->stream, (const float*)src, batch, ld, B, cols, out);
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
+int bnf_debug_gemm_nt(bnf_handle* h, const float* A, const float* Bt, int32_t M, int32_t N, int32_t K,
+                      float* C) {
+  if (!h || !A || !Bt || !C) return fail(BNF_ERR_INVALID, "null");
+  if (M < 1 || N < 1 || K < 64 || K % 64 != 0) return fail(BNF_ERR_INVALID, "K must be a multiple of 64");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  hipStream_t st = h->stream;
+  void *dA = nullptr, *dB = nullptr;
+  HIPCHK(hipMalloc(&dA, (size_t)M * K * h->es));
+  HIPCHK(hipMalloc(&dB, (size_t)N * K * h->es));
+  GemmArgs g{};
+  g.A = dA; g.B = dB; g.a_ld = K; g.b_ld = K; g.a_batch = 0; g.b_batch = 0;
+  g.M = M; g.N = N; g.K = K; g.splitk = 1; g.members = 1;
+  EpiArgs ep{};
+  ep.scale = 1.f; ep.out_f32 = C; ep.f32_batch = 0; ep.ld_f32 = N;
+  if (h->bf16) {
+    hipLaunchKernelGGL((k_from_f32<bf16_t>), dim3(cdiv((int64_t)M * K, 256)), dim3(256), 0, st, A, (int64_t)M, K, (bf16_t*)dA, K);
+    hipLaunchKernelGGL((k_from_f32<bf16_t>), dim3(cdiv((int64_t)N * K, 256)), dim3(256), 0, st, Bt, (int64_t)N, K, (bf16_t*)dB, K);
+    launch_gemm<bf16_t, EPI_PLAIN, 2>(h, KID_FWD, g, ep);
+  } else {
+    hipLaunchKernelGGL((k_from_f32<float>), dim3(cdiv((int64_t)M * K, 256)), dim3(256), 0, st, A, (int64_t)M, K, (float*)dA, K);
+    hipLaunchKernelGGL((k_from_f32<float>), dim3(cdiv((int64_t)N * K, 256)), dim3(256), 0, st, Bt, (int64_t)N, K, (float*)dB, K);
+    launch_gemm<float, EPI_PLAIN, 2>(h, KID_FWD, g, ep);
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipFree(dA));
+  HIPCHK(hipFree(dB));
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
+int bnf_profile_enable(bnf_handle* h, int32_t on) {
+  if (!h) return fail(BNF_ERR_INVALID, "null");
+  if (on) {
+    for (int k = 0; k < KID_COUNT; ++k) { h->acc_ms[k] = 0; h->acc_calls[k] = 0; }
+  } else if (h->prof) {
+    drain_timers(h);
+  }
+  h->prof = on != 0;
+  return BNF_OK;
+}
+
+int bnf_profile_read(bnf_handle* h, int32_t* n, const char** names, double* avg_ms, int64_t* calls) {
+  if (!h || !n) return fail(BNF_ERR_INVALID, "null");
+  drain_timers(h);
+  int used = 0;
+  for (int k = 0; k < KID_COUNT && used < *n; ++k) {
+    if (h->acc_calls[k] == 0) continue;
+    names[used] = kKernelNames[k];
+    avg_ms[used] = h->acc_ms[k] / (double)h->acc_calls[k];
+    calls[used] = h->acc_calls[k];
+    ++used;
+  }
+  *n = used;
+  return BNF_OK;
+}
+
+double bnf_kernel_flops(const bnf_handle* h, const char* name) {
+  if (!h || !name) return 0.0;
+  const double Ev = h->Ev, B = (double)h->B, W = h->W, F = h->F;
+  if (!strcmp(name, "gemm_fwd_l0") || !strcmp(name, "gemm_dgrad0") || !strcmp(name, "gemm_wgrad_l0"))
+    return 2.0 * Ev * B * F * W;
+  if (!strcmp(name, "gemm_fwd") || !strcmp(name, "gemm_dgrad") || !strcmp(name, "gemm_wgrad"))
+    return 2.0 * Ev * B * W * W;
+  return 0.0;
+}
+
+}  // extern "C"

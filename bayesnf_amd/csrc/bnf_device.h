@@ -1,0 +1,259 @@
+// bnf_device.h -- device-side building blocks (gfx950 / CDNA4 only).
+//
+//   * storage-type traits for the two arithmetic modes (f32 / bf16 operands,
+//     f32 accumulation in both)
+//   * the BayesNF scalar math: softplus, sigmoid, the mixed elu/tanh activation
+//     (reference models.py:258-262) in an accurate and a fast formulation
+//   * counter-based random numbers: Philox4x32-10, truncated normal, Box-Muller
+//   * the keyed Feistel bijection used as a memory-free row shuffle
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bnf {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+// ---------------------------------------------------------------------------
+// storage types
+// ---------------------------------------------------------------------------
+struct bf16_t {
+  uint16_t bits;
+};
+
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (no NaN inputs here)
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
+  return __builtin_bit_cast(float, ((uint32_t)b) << 16);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int kBytes = 4;
+  static constexpr bool kFast = false;  // accurate transcendental path
+  __device__ static __forceinline__ float load(const float* p) { return *p; }
+  __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ float round(float v) { return v; }
+};
+template <>
+struct Elem<bf16_t> {
+  static constexpr int kBytes = 2;
+  static constexpr bool kFast = true;
+  __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_bits_to_f32(p->bits); }
+  __device__ static __forceinline__ void store(bf16_t* p, float v) { p->bits = f32_to_bf16_bits(v); }
+  __device__ static __forceinline__ float round(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+};
+
+// store 4 consecutive elements (used for the transposed copies: 4 consecutive
+// rows of one column).  p must be aligned to 4 elements.
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+  f32x4 v = {a, b, c, d};
+  *reinterpret_cast<f32x4*>(p) = v;
+}
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+  uint2 v;
+  v.x = (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
+  v.y = (uint32_t)f32_to_bf16_bits(c) | ((uint32_t)f32_to_bf16_bits(d) << 16);
+  *reinterpret_cast<uint2*>(p) = v;
+}
+
+// ---------------------------------------------------------------------------
+// scalar math
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float softplusf(float x) {  // jax.nn.softplus = logaddexp(x, 0)
+  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoidf(float x) {
+  return x >= 0.f ? 1.f / (1.f + expf(-x)) : expf(x) / (1.f + expf(x));
+}
+
+// act(a) = alpha * elu(a) + (1 - alpha) * tanh(a)            models.py:258-262
+// Everything the backward needs in one evaluation:
+//   h     = act(a)
+//   dact  = alpha * (a > 0 ? 1 : exp(a)) + (1 - alpha) * (1 - tanh(a)^2)
+//   ediff = elu(a) - tanh(a)            (d act / d alpha)
+struct ActOut {
+  float h, dact, ediff;
+};
+
+template <bool FAST>
+__device__ __forceinline__ ActOut act_eval(float a, float alpha) {
+  ActOut o;
+  float th, el, dexp;
+  if constexpr (FAST) {
+    // one v_exp_f32 + one v_rcp_f32:  e1 = exp(-|a|), e2 = e1^2
+    const float e1 = __builtin_amdgcn_exp2f(fabsf(a) * -1.44269504088896340736f);
+    const float e2 = e1 * e1;
+    const float r = __builtin_amdgcn_rcpf(1.f + e2);
+    th = copysignf((1.f - e2) * r, a);
+    el = a > 0.f ? a : e1 - 1.f;
+    dexp = a > 0.f ? 1.f : e1;
+  } else {
+    th = tanhf(a);
+    el = a > 0.f ? a : expm1f(a);
+    dexp = a > 0.f ? 1.f : expf(a);
+  }
+  o.h = th + alpha * (el - th);
+  o.dact = alpha * dexp + (1.f - alpha) * (1.f - th * th);
+  o.ediff = el - th;
+  return o;
+}
+
+template <bool FAST>
+__device__ __forceinline__ float act_fwd(float a, float alpha) {
+  float th, el;
+  if constexpr (FAST) {
+    const float e1 = __builtin_amdgcn_exp2f(fabsf(a) * -1.44269504088896340736f);
+    const float e2 = e1 * e1;
+    const float r = __builtin_amdgcn_rcpf(1.f + e2);
+    th = copysignf((1.f - e2) * r, a);
+    el = a > 0.f ? a : e1 - 1.f;
+  } else {
+    th = tanhf(a);
+    el = a > 0.f ? a : expm1f(a);
+  }
+  return th + alpha * (el - th);
+}
+
+// ---------------------------------------------------------------------------
+// wave / block reductions (wave = 64 lanes)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11), counter-based: no state, any element
+// of any stream is computable independently -> results do not depend on how
+// members are sharded over GPUs.
+// ---------------------------------------------------------------------------
+struct Philox {
+  uint32_t v[4];
+};
+__host__ __device__ __forceinline__ Philox philox4x32(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                      uint32_t c3, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  Philox o;
+  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+
+// random streams (counter word 3, low byte)
+enum : uint32_t {
+  STREAM_INIT = 1,     // TruncatedNormal initial kernels
+  STREAM_SHUFFLE = 2,  // per-member per-epoch row shuffle (MAP)
+  STREAM_VI_EPS = 3,   // reparameterisation noise
+  STREAM_VI_BATCH = 4, // shared random batch of a VI step
+  STREAM_VI_DRAW = 5   // posterior draws after fitting
+};
+
+__device__ __forceinline__ float u01_open(uint32_t x) {  // (0,1), 24 bits
+  return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// TruncatedNormal(0, 1, low=-2, high=2) by inverse CDF.
+__device__ __forceinline__ float trunc_normal_m2p2(uint32_t bits) {
+  const float lo = 0.02275013194817921f;            // Phi(-2)
+  const float span = 0.9544997361036416f;           // Phi(2) - Phi(-2)
+  float x = normcdfinvf(lo + span * u01_open(bits));
+  return fminf(2.f, fmaxf(-2.f, x));
+}
+
+// standard normal from two 32-bit words (Box-Muller, cosine branch)
+__device__ __forceinline__ float std_normal(uint32_t a, uint32_t b) {
+  const float u1 = u01_open(a), u2 = u01_open(b);
+  return sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
+}
+
+// reparameterisation noise eps[member_global][sample][p] of VI step `step`
+__device__ __forceinline__ float vi_eps(uint64_t seed, uint32_t member_global, uint32_t sample,
+                                        uint32_t p, uint64_t step, uint32_t stream) {
+  Philox r = philox4x32(p, member_global, (uint32_t)step,
+                        (stream & 0xffu) | (sample << 8) | ((uint32_t)(step >> 32) << 20),
+                        (uint32_t)seed, (uint32_t)(seed >> 32));
+  return std_normal(r.v[0], r.v[1]);
+}
+
+// ---------------------------------------------------------------------------
+// Keyed Feistel bijection on [0, n): a pseudo-random permutation evaluated
+// per element (no index array in HBM).  Replaces jax.random.permutation in
+// permute_dataset (inference.py:35-39) and in ensemble_vi (inference.py:706).
+// ---------------------------------------------------------------------------
+struct FeistelKey {
+  uint32_t k[6];
+  uint32_t half_bits;  // domain = 2^(2*half_bits) >= n
+  uint64_t n;
+};
+
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // murmur3 finaliser
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+
+__host__ __device__ __forceinline__ FeistelKey feistel_key(uint64_t seed, uint32_t a, uint64_t b,
+                                                           uint32_t stream, uint64_t n) {
+  FeistelKey fk;
+  Philox r0 = philox4x32(0u, a, (uint32_t)b, (stream & 0xffu) | ((uint32_t)(b >> 32) << 8),
+                         (uint32_t)seed, (uint32_t)(seed >> 32));
+  Philox r1 = philox4x32(1u, a, (uint32_t)b, (stream & 0xffu) | ((uint32_t)(b >> 32) << 8),
+                         (uint32_t)seed, (uint32_t)(seed >> 32));
+  fk.k[0] = r0.v[0]; fk.k[1] = r0.v[1]; fk.k[2] = r0.v[2]; fk.k[3] = r0.v[3];
+  fk.k[4] = r1.v[0]; fk.k[5] = r1.v[1];
+  uint32_t bits = 2;
+  while ((1ull << bits) < n) ++bits;
+  fk.half_bits = (bits + 1) >> 1;
+  fk.n = n;
+  return fk;
+}
+
+__host__ __device__ __forceinline__ uint64_t feistel_perm(const FeistelKey& fk, uint64_t i) {
+  const uint32_t hb = fk.half_bits;
+  const uint32_t mask = (hb >= 32) ? 0xffffffffu : ((1u << hb) - 1u);
+  uint64_t x = i;
+  do {
+    uint32_t L = (uint32_t)(x >> hb) & mask, R = (uint32_t)x & mask;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const uint32_t f = mix32(R ^ fk.k[r]) & mask;
+      const uint32_t nl = R;
+      R = L ^ f;
+      L = nl;
+    }
+    x = ((uint64_t)L << hb) | R;
+  } while (x >= fk.n);
+  return x;
+}
+
+}  // namespace bnf

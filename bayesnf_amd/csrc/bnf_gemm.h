@@ -1,0 +1,376 @@
+// bnf_gemm.h -- the dense-contraction core:  C[m][n] = sum_k A[m][k] * Bt[n][k]
+//
+// One MFMA kernel serves the three contractions of a BayesNF layer (reference
+// models.py:263-268 forward and its autodiff, inference.py:602), batched over
+// ensemble members:
+//
+//   forward   Z   = H_l      (rows x n_l) . K_l^T  stored (W x n_l)   -> EPI_FWD
+//   dgrad     dH  = dZ_{l+1} (rows x W)   . K_{l+1} stored (n x W)    -> EPI_DGRAD / EPI_DGRAD0
+//   wgrad     dK  = H_l^T    (n_l x rows) . dZ_l^T stored (W x rows)  -> EPI_WGRAD
+//
+// Both operands are K-contiguous ("NT"), which is why every activation is kept
+// in HBM twice (row-major and transposed) and the weights in both layouts.
+//
+// Tiling (gfx950): 128x128 block tile, 256 threads = 4 waves (2x2), each wave a
+// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 f32 VGPRs).  K advances in
+// 128-byte rows (64 bf16 / 32 f32) through a double-buffered, XOR-swizzled LDS
+// image (row pitch 128 B, 16-byte chunk index ^= (row >> 1) & 7, which makes
+// every 16-lane ds_read_b128 group hit 16 distinct 16-byte slots).  bf16 uses
+// v_mfma_f32_32x32x16_bf16, f32 uses the exact v_mfma_f32_32x32x2_f32.
+// Workgroup ids are remapped so each XCD (private 4 MiB L2) owns a contiguous
+// range of (member, tile) work: a member's weights and activation panels stay
+// in one L2.
+#pragma once
+
+#include "bnf_device.h"
+
+namespace bnf {
+
+enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_DGRAD0 = 2, EPI_WGRAD = 3, EPI_PLAIN = 4 };
+
+constexpr int kBM = 128, kBN = 128, kRowBytes = 128, kThreads = 256;
+constexpr int kStageBytes = (kBM + kBN) * kRowBytes;  // 32 KiB
+constexpr int kGemmLds = 2 * kStageBytes;             // 64 KiB
+
+struct GemmArgs {
+  const void* A;  // (M, K) elements of T, leading dim a_ld, member stride a_batch
+  const void* B;  // (N, K)
+  int64_t a_batch, b_batch;
+  int32_t a_ld, b_ld;
+  int32_t M, N, K;  // K: multiple of the tile depth, zero padded
+  int32_t tiles_m, tiles_n, splitk, members;
+};
+
+struct EpiArgs {
+  const float* theta;  // (members, P) f32 compute parameters
+  int64_t theta_stride;
+  float scale;  // 1/sqrt(fan_in) folded into the accumulator
+  int32_t off_bias, off_layer_scale, off_act_weight;
+  // activations: row-major (rows, ld) and transposed (ld, ldt) copies
+  void* out_a;         // FWD: pre-activation A_l
+  void* out_h;         // FWD: H_{l+1} ; DGRAD: dZ_l
+  void* out_t;         // FWD: H_{l+1}^T ; DGRAD: dZ_l^T (may be null)
+  const void* in_a;    // DGRAD: A_l
+  int64_t act_batch;   // elements between members, row-major buffers
+  int64_t actt_batch;  // elements between members, transposed buffers
+  int32_t ld, ldt;
+  // f32 outputs
+  float* grad;         // (members, P): bias / scale grads (DGRAD), kernel grads (WGRAD)
+  int64_t grad_stride;
+  int32_t off_out;     // WGRAD: offset of Dense_l/kernel ; PLAIN/DGRAD0: unused
+  float* out_f32;      // DGRAD0 / PLAIN: (members, M, ld_f32)
+  int64_t f32_batch;
+  int32_t ld_f32;
+};
+
+template <typename T>
+struct Mma;
+
+template <>
+struct Mma<bf16_t> {
+  static constexpr int kTileK = 64;  // elements per 128-byte row
+  static constexpr int kSteps = 4;   // MFMA k-steps (16 elements) per tile
+  struct Frag {
+    bf16x8 v;
+  };
+  // lane (row, kg = lane >> 5) takes 8 consecutive k at chunk 2*ks + kg
+  __device__ static __forceinline__ Frag load(const char* row, int swz, int ks, int kg) {
+    Frag f;
+    f.v = *reinterpret_cast<const bf16x8*>(row + (((ks * 2 + kg) ^ swz) << 4));
+    return f;
+  }
+  __device__ static __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+  }
+};
+
+template <>
+struct Mma<float> {
+  static constexpr int kTileK = 32;
+  static constexpr int kSteps = 2;  // k-groups of 16 floats (64 bytes)
+  struct Frag {
+    f32x4 lo, hi;
+  };
+  // lane (row, kg) takes 8 consecutive k at chunks 4*ks + 2*kg, +1.  MFMA j then
+  // contracts k = base + j (lanes 0-31) and base + 8 + j (lanes 32-63): a
+  // permutation of k shared by both operands, so the sum is unchanged.
+  __device__ static __forceinline__ Frag load(const char* row, int swz, int ks, int kg) {
+    Frag f;
+    const int c = ks * 4 + kg * 2;
+    f.lo = *reinterpret_cast<const f32x4*>(row + (((c) ^ swz) << 4));
+    f.hi = *reinterpret_cast<const f32x4*>(row + (((c + 1) ^ swz) << 4));
+    return f;
+  }
+  __device__ static __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[j], b.lo[j], acc, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[j], b.hi[j], acc, 0, 0, 0);
+  }
+};
+
+// XCD-aware bijective remap of the linear workgroup id (8 XCDs, block b runs on
+// XCD b % 8): XCD x gets the contiguous logical range starting at first(x).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total) {
+  const uint32_t q = total >> 3, r = total & 7u, x = b & 7u, slot = b >> 3;
+  const uint32_t first = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return first + slot;
+}
+
+template <typename T, int EPI, int TAG>
+__global__ __launch_bounds__(kThreads) void gemm_nt(const GemmArgs g, const EpiArgs ep) {
+  using M_ = Mma<T>;
+  constexpr bool FAST = Elem<T>::kFast;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // ---- which (member, k-split, tile) ----------------------------------------
+  const uint32_t per_member = (uint32_t)(g.tiles_m * g.tiles_n * g.splitk);
+  uint32_t w = xcd_remap(blockIdx.x, gridDim.x);
+  const int e = (int)(w / per_member);
+  w -= (uint32_t)e * per_member;
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int split = (int)(w / (uint32_t)tiles);
+  w -= (uint32_t)split * tiles;
+  const int tm = (int)(w / (uint32_t)g.tiles_n), tn = (int)(w % (uint32_t)g.tiles_n);
+  const int m0 = tm * kBM, n0 = tn * kBN;
+
+  const int nk_total = g.K / M_::kTileK;
+  const int nk_per = (nk_total + g.splitk - 1) / g.splitk;
+  const int kt0 = split * nk_per;
+  const int kt1 = min(nk_total, kt0 + nk_per);
+
+  const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)e * g.a_batch * Elem<T>::kBytes;
+  const char* Bb = reinterpret_cast<const char*>(g.B) + (int64_t)e * g.b_batch * Elem<T>::kBytes;
+
+  // ---- staging map: 4 A chunks + 4 B chunks of 16 B per thread per tile ------
+  const char* a_src[4];
+  const char* b_src[4];
+  int lds_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + i * kThreads;
+    const int row = q >> 3, c = q & 7;
+    const int am = min(m0 + row, g.M - 1), bn = min(n0 + row, g.N - 1);
+    a_src[i] = Ab + ((int64_t)am * g.a_ld) * Elem<T>::kBytes + c * 16;
+    b_src[i] = Bb + ((int64_t)bn * g.b_ld) * Elem<T>::kBytes + c * 16;
+    lds_off[i] = row * kRowBytes + ((c ^ ((row >> 1) & 7)) << 4);
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+    const int64_t koff = (int64_t)kt * kRowBytes;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + koff);
+      rb[i] = *reinterpret_cast<const u32x4*>(b_src[i] + koff);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* sA = smem + buf * kStageBytes;
+    char* sB = sA + kBM * kRowBytes;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(sA + lds_off[i]) = ra[i];
+      *reinterpret_cast<u32x4*>(sB + lds_off[i]) = rb[i];
+    }
+  };
+
+  // fragment rows of this lane
+  const int frow = lane & 31, kg = lane >> 5;
+  int a_row[2], b_row[2], a_swz[2], b_swz[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    a_row[i] = wr * 64 + i * 32 + frow;
+    b_row[i] = wc * 64 + i * 32 + frow;
+    a_swz[i] = (a_row[i] >> 1) & 7;
+    b_swz[i] = (b_row[i] >> 1) & 7;
+  }
+
+  if (kt0 < kt1) {
+    gload(kt0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      if (kt + 1 < kt1) gload(kt + 1);
+      const char* sA = smem + buf * kStageBytes;
+      const char* sB = sA + kBM * kRowBytes;
+#pragma unroll
+      for (int ks = 0; ks < M_::kSteps; ++ks) {
+        typename M_::Frag fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[i] = M_::load(sA + a_row[i] * kRowBytes, a_swz[i], ks, kg);
+          fb[i] = M_::load(sB + b_row[i] * kRowBytes, b_swz[i], ks, kg);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) M_::mma(acc[i][j], fa[i], fb[j]);
+      }
+      if (kt + 1 < kt1) lstore(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogues --------------------------------------------------------------
+  // accumulator element (i, j, r): row m = m0 + wr*64 + i*32 + 8*(r>>2) + 4*kg + (r&3)
+  //                                col n = n0 + wc*64 + j*32 + frow
+  const int mw = m0 + wr * 64 + 4 * kg;
+  const int nw = n0 + wc * 64 + frow;
+
+  if constexpr (EPI == EPI_PLAIN || EPI == EPI_DGRAD0) {
+    float* out = ep.out_f32 + (int64_t)e * ep.f32_batch;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = nw + j * 32;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + i * 32 + 8 * (r >> 2) + (r & 3);
+          if (m < g.M) out[(int64_t)m * ep.ld_f32 + n] = acc[i][j][r] * ep.scale;
+        }
+    }
+  } else if constexpr (EPI == EPI_WGRAD) {
+    float* out = ep.grad + (int64_t)e * ep.grad_stride + ep.off_out;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = nw + j * 32;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + i * 32 + 8 * (r >> 2) + (r & 3);
+          if (m < g.M) {
+            const float v = acc[i][j][r] * ep.scale;
+            if (g.splitk > 1) atomicAdd(&out[(int64_t)m * ep.ld_f32 + n], v);
+            else out[(int64_t)m * ep.ld_f32 + n] = v;
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_FWD) {
+    const float* th = ep.theta + (int64_t)e * ep.theta_stride;
+    const float gamma = softplusf(th[ep.off_layer_scale]);
+    const float alpha = sigmoidf(th[ep.off_act_weight]);
+    T* oa = reinterpret_cast<T*>(ep.out_a) + (int64_t)e * ep.act_batch;
+    T* oh = reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch;
+    T* ot = ep.out_t ? reinterpret_cast<T*>(ep.out_t) + (int64_t)e * ep.actt_batch : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = nw + j * 32;
+      if (n >= g.N) continue;
+      const float bias = th[ep.off_bias + n];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int mb = mw + i * 32 + 8 * rg;
+          float hv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float a = gamma * (acc[i][j][rg * 4 + q] * ep.scale + bias);
+            const float h = act_fwd<FAST>(a, alpha);
+            hv[q] = h;
+            const int m = mb + q;
+            if (m < g.M) {
+              Elem<T>::store(oa + (int64_t)m * ep.ld + n, a);
+              Elem<T>::store(oh + (int64_t)m * ep.ld + n, h);
+            }
+          }
+          if (ot) {
+            T* p = ot + (int64_t)n * ep.ldt + mb;
+            if (mb + 3 < g.M) store4(p, hv[0], hv[1], hv[2], hv[3]);
+            else
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (mb + q < g.M) Elem<T>::store(p + q, hv[q]);
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_DGRAD) {
+    const float* th = ep.theta + (int64_t)e * ep.theta_stride;
+    const float gamma = softplusf(th[ep.off_layer_scale]);
+    const float alpha = sigmoidf(th[ep.off_act_weight]);
+    const T* ia = reinterpret_cast<const T*>(ep.in_a) + (int64_t)e * ep.act_batch;
+    T* oz = reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch;
+    T* ot = ep.out_t ? reinterpret_cast<T*>(ep.out_t) + (int64_t)e * ep.actt_batch : nullptr;
+    float s_alpha = 0.f, s_gamma = 0.f, colsum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = nw + j * 32;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int mb = mw + i * 32 + 8 * rg;
+          float zv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int m = mb + q;
+            zv[q] = 0.f;
+            if (m < g.M) {
+              const float a = Elem<T>::load(ia + (int64_t)m * ep.ld + n);
+              const float dh = acc[i][j][rg * 4 + q] * ep.scale;
+              const ActOut o = act_eval<FAST>(a, alpha);
+              s_alpha += dh * o.ediff;
+              const float da = dh * o.dact;
+              s_gamma += da * a;
+              const float dz = gamma * da;
+              colsum[j] += dz;
+              zv[q] = dz;
+              Elem<T>::store(oz + (int64_t)m * ep.ld + n, dz);
+            }
+          }
+          if (ot) {
+            T* p = ot + (int64_t)n * ep.ldt + mb;
+            if (mb + 3 < g.M) store4(p, zv[0], zv[1], zv[2], zv[3]);
+            else
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (mb + q < g.M) Elem<T>::store(p + q, zv[q]);
+          }
+        }
+    }
+    // block reduction through LDS (free after the last barrier of the K loop)
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float c = colsum[j] + __shfl_xor(colsum[j], 32, 64);
+      if (lane < 32) red[wr * 128 + wc * 64 + j * 32 + lane] = c;
+    }
+    const float sa = wave_sum(s_alpha), sg = wave_sum(s_gamma);
+    if (lane == 0) {
+      red[256 + wave * 2] = sa;
+      red[257 + wave * 2] = sg;
+    }
+    __syncthreads();
+    float* gr = ep.grad + (int64_t)e * ep.grad_stride;
+    if (tid < 128) {
+      const int n = n0 + tid;
+      if (n < g.N) atomicAdd(&gr[ep.off_bias + n], red[tid] + red[128 + tid]);
+    }
+    if (tid == 0) {
+      const float ta = red[256] + red[258] + red[260] + red[262];
+      const float tg = red[257] + red[259] + red[261] + red[263];
+      atomicAdd(&gr[ep.off_act_weight], alpha * (1.f - alpha) * ta);
+      atomicAdd(&gr[ep.off_layer_scale], sigmoidf(th[ep.off_layer_scale]) * tg / gamma);
+    }
+  }
+}
+
+}  // namespace bnf

@@ -1,0 +1,823 @@
+// bnf_kernels.h -- everything of a BayesNF train / predict step that is not a
+// dense contraction: featurisation (fwd + bwd), output layer + likelihood +
+// last-layer activation backward, prior + Adam, weight packing, VI sampling,
+// mixture quantiles.  All kernels are batched over (virtual) ensemble members
+// with blockIdx.y = member.
+#pragma once
+
+#include "bnf_device.h"
+#include "../../include/bnf.h"
+
+namespace bnf {
+
+// Device copy of the static network description (passed by value, ~700 B).
+struct NetDev {
+  int32_t D, F, Fp, W, depth, P, n_groups, n_freqs, n_interact, obs;
+  int32_t group_kind[BNF_MAX_GROUPS], group_arg[BNF_MAX_GROUPS], group_ncols[BNF_MAX_GROUPS],
+      group_col0[BNF_MAX_GROUPS], group_scale_off[BNF_MAX_GROUPS];
+  int32_t fdeg[BNF_MAX_INPUTS];
+  float in_scale[BNF_MAX_INPUTS];
+  int32_t interact[BNF_MAX_INTERACT][2];
+  int32_t off_lns, off_shape, off_infl;
+  int32_t off_bias[BNF_MAX_LAYERS + 1], off_kernel[BNF_MAX_LAYERS + 1], off_ls[BNF_MAX_LAYERS];
+  int32_t off_os, off_lsa, off_law;
+};
+
+// Which data row does batch position r of (virtual) member e read?
+struct RowSrc {
+  int32_t mode;          // 0 identity, 1 per-member epoch shuffle, 2 shared random batch
+  int32_t S;             // virtual members per member (VI samples), >= 1
+  uint64_t seed;
+  uint64_t epoch;        // mode 1: epoch ; mode 2: step
+  int64_t pos0;          // mode 1: step * B
+  int64_t n_rows;        // N
+  int64_t member_offset; // global id of local member 0
+};
+
+__device__ __forceinline__ int64_t row_of(const RowSrc& rs, int e, int64_t r) {
+  if (rs.mode == 0) return r;
+  if (rs.mode == 1) {
+    const FeistelKey fk = feistel_key(rs.seed, (uint32_t)(rs.member_offset + e / rs.S), rs.epoch,
+                                      STREAM_SHUFFLE, (uint64_t)rs.n_rows);
+    return (int64_t)feistel_perm(fk, (uint64_t)(rs.pos0 + r));
+  }
+  const FeistelKey fk = feistel_key(rs.seed, 0u, rs.epoch, STREAM_VI_BATCH, (uint64_t)rs.n_rows);
+  return (int64_t)feistel_perm(fk, (uint64_t)r);
+}
+
+constexpr float kTwoPiF = 6.2831854820251465f;  // float32(2*pi), as jnp evaluates 2*jnp.pi in f32
+
+// ---------------------------------------------------------------------------
+// seasonal feature table (data-constant):  S[n][j]      = cos(y)/h_j
+//                                          S[n][nf + j] = sin(y)/h_j
+// y = fl32(fl32(fl32(2 pi) f_j) t_n), exactly the float32 argument of the
+// reference (models.py:73-74); cos/sin of that float are taken in double and
+// rounded once.  Time is column 0 of X.
+// ---------------------------------------------------------------------------
+struct FreqTab {
+  int32_t n;
+  float f[BNF_MAX_FREQS], h[BNF_MAX_FREQS];
+};
+
+__global__ void k_seasonal_table(const float* __restrict__ X, int64_t n_rows, int D, FreqTab ft,
+                                 float* __restrict__ S) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const float t = X[r * D];
+  for (int j = 0; j < ft.n; ++j) {
+    const float cf = kTwoPiF * ft.f[j];
+    const float y = cf * t;
+    double s, c;
+    sincos((double)y, &s, &c);
+    S[r * (2 * ft.n) + j] = (float)c / ft.h[j];
+    S[r * (2 * ft.n) + ft.n + j] = (float)s / ft.h[j];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// featurise forward (models.py:218-252): one thread per batch row.
+//   writes H0 (rows, Fp) and H0^T (Fp, ldt) in T, plus the gathered target.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_featurize(
+    NetDev nd, RowSrc rs, const float* __restrict__ X, const float* __restrict__ Stab,
+    const float* __restrict__ y, const float* __restrict__ theta, int64_t theta_stride, int64_t B,
+    T* __restrict__ H0, int64_t h0_batch, T* __restrict__ H0t, int64_t h0t_batch, int32_t ldt,
+    float* __restrict__ ybat, int64_t ybat_batch) {
+  const int e = blockIdx.y;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  const float* th = theta + (int64_t)e * theta_stride;
+  const int64_t row = row_of(rs, e, r);
+  const float* x = X + row * nd.D;
+  float u[BNF_MAX_INPUTS];
+#pragma unroll
+  for (int d = 0; d < BNF_MAX_INPUTS; ++d)
+    if (d < nd.D) u[d] = x[d] / (nd.in_scale[d] * expf(th[nd.off_lsa + d]));
+  T* hrow = H0 + (int64_t)e * h0_batch + r * nd.Fp;
+  T* hcol = H0t ? H0t + (int64_t)e * h0t_batch + r : nullptr;
+  auto put = [&](int col, float v) {
+    Elem<T>::store(hrow + col, v);
+    if (hcol) Elem<T>::store(hcol + (int64_t)col * ldt, v);
+  };
+  for (int g = 0; g < nd.n_groups; ++g) {
+    const float sp = softplusf(th[nd.group_scale_off[g]]);
+    const int c0 = nd.group_col0[g], nc = nd.group_ncols[g];
+    const int kind = nd.group_kind[g];
+    if (kind == BNF_GROUP_INPUT) {
+      for (int d = 0; d < nd.D; ++d) put(c0 + d, u[d] * sp);
+    } else if (kind == BNF_GROUP_FOURIER) {
+      const int deg = nc >> 1;
+      float ud = 0.f;
+#pragma unroll
+      for (int d = 0; d < BNF_MAX_INPUTS; ++d)
+        if (d == nd.group_arg[g]) ud = u[d];
+      const float y0 = kTwoPiF * ud;
+      for (int k = 0; k < deg; ++k) {
+        float s, c;
+        sincosf(y0 * (float)(1u << k), &s, &c);
+        const float den = (float)(k + 1);
+        put(c0 + k, (c / den) * sp);
+        put(c0 + deg + k, (s / den) * sp);
+      }
+    } else if (kind == BNF_GROUP_SEASONAL) {
+      const float* srow = Stab + row * nc;
+      for (int j = 0; j < nc; ++j) put(c0 + j, srow[j] * sp);
+    } else {
+      for (int k = 0; k < nc; ++k) {
+        float up = 0.f, uq = 0.f;
+#pragma unroll
+        for (int d = 0; d < BNF_MAX_INPUTS; ++d) {
+          if (d == nd.interact[k][0]) up = u[d];
+          if (d == nd.interact[k][1]) uq = u[d];
+        }
+        put(c0 + k, (up * uq) * sp);
+      }
+    }
+  }
+  if (ybat) ybat[(int64_t)e * ybat_batch + r] = y ? y[row] : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// featurise backward: d feature scales, d log_scale_adjustment.
+// dH0 (rows, Fp) f32 comes from the layer-0 dgrad contraction.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_feat_bwd(
+    NetDev nd, RowSrc rs, const float* __restrict__ X, const float* __restrict__ Stab,
+    const float* __restrict__ theta, int64_t theta_stride, int64_t B,
+    const float* __restrict__ dH0, int64_t dh0_batch, float* __restrict__ grad,
+    int64_t grad_stride) {
+  __shared__ float red[4][BNF_MAX_GROUPS + BNF_MAX_INPUTS];
+  const int e = blockIdx.y;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float* th = theta + (int64_t)e * theta_stride;
+  float dfs[BNF_MAX_GROUPS], dlsa[BNF_MAX_INPUTS];
+#pragma unroll
+  for (int g = 0; g < BNF_MAX_GROUPS; ++g) dfs[g] = 0.f;
+#pragma unroll
+  for (int d = 0; d < BNF_MAX_INPUTS; ++d) dlsa[d] = 0.f;
+  if (r < B) {
+    const int64_t row = row_of(rs, e, r);
+    const float* x = X + row * nd.D;
+    float u[BNF_MAX_INPUTS], du[BNF_MAX_INPUTS];
+#pragma unroll
+    for (int d = 0; d < BNF_MAX_INPUTS; ++d) {
+      du[d] = 0.f;
+      u[d] = 0.f;
+      if (d < nd.D) u[d] = x[d] / (nd.in_scale[d] * expf(th[nd.off_lsa + d]));
+    }
+    const float* dh = dH0 + (int64_t)e * dh0_batch + r * nd.Fp;
+#pragma unroll
+    for (int g = 0; g < BNF_MAX_GROUPS; ++g) {
+      if (g >= nd.n_groups) continue;
+      const float sp = softplusf(th[nd.group_scale_off[g]]);
+      const int c0 = nd.group_col0[g], nc = nd.group_ncols[g];
+      const int kind = nd.group_kind[g];
+      float acc = 0.f;
+      if (kind == BNF_GROUP_INPUT) {
+#pragma unroll
+        for (int d = 0; d < BNF_MAX_INPUTS; ++d)
+          if (d < nd.D) {
+            const float dhv = dh[c0 + d];
+            acc += dhv * u[d];
+            du[d] += sp * dhv;
+          }
+      } else if (kind == BNF_GROUP_FOURIER) {
+        const int deg = nc >> 1;
+        float ud = 0.f;
+#pragma unroll
+        for (int d = 0; d < BNF_MAX_INPUTS; ++d)
+          if (d == nd.group_arg[g]) ud = u[d];
+        const float y0 = kTwoPiF * ud;
+        float dud = 0.f;
+        for (int k = 0; k < deg; ++k) {
+          float s, c;
+          const float sc = (float)(1u << k);
+          sincosf(y0 * sc, &s, &c);
+          const float den = (float)(k + 1);
+          const float dc = dh[c0 + k], ds = dh[c0 + deg + k];
+          acc += dc * (c / den) + ds * (s / den);
+          dud += (kTwoPiF * sc) * (-s * dc + c * ds) / den;
+        }
+#pragma unroll
+        for (int d = 0; d < BNF_MAX_INPUTS; ++d)
+          if (d == nd.group_arg[g]) du[d] += sp * dud;
+      } else if (kind == BNF_GROUP_SEASONAL) {
+        const float* srow = Stab + row * nc;
+        for (int j = 0; j < nc; ++j) acc += dh[c0 + j] * srow[j];
+      } else {
+        for (int k = 0; k < nc; ++k) {
+          const int p = nd.interact[k][0], q = nd.interact[k][1];
+          float up = 0.f, uq = 0.f;
+#pragma unroll
+          for (int d = 0; d < BNF_MAX_INPUTS; ++d) {
+            if (d == p) up = u[d];
+            if (d == q) uq = u[d];
+          }
+          const float dhv = dh[c0 + k];
+          acc += dhv * up * uq;
+#pragma unroll
+          for (int d = 0; d < BNF_MAX_INPUTS; ++d) {
+            if (d == p) du[d] += sp * dhv * uq;
+            if (d == q) du[d] += sp * dhv * up;
+          }
+        }
+      }
+      dfs[g] = acc;
+    }
+#pragma unroll
+    for (int d = 0; d < BNF_MAX_INPUTS; ++d) dlsa[d] = -du[d] * u[d];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int g = 0; g < BNF_MAX_GROUPS; ++g) {
+    const float s = wave_sum(dfs[g]);
+    if (lane == 0) red[wave][g] = s;
+  }
+#pragma unroll
+  for (int d = 0; d < BNF_MAX_INPUTS; ++d) {
+    const float s = wave_sum(dlsa[d]);
+    if (lane == 0) red[wave][BNF_MAX_GROUPS + d] = s;
+  }
+  __syncthreads();
+  float* gr = grad + (int64_t)e * grad_stride;
+  const int t = threadIdx.x;
+  if (t < nd.n_groups) {
+    const float s = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    atomicAdd(&gr[nd.group_scale_off[t]], sigmoidf(th[nd.group_scale_off[t]]) * s);
+  } else if (t >= BNF_MAX_GROUPS && t < BNF_MAX_GROUPS + nd.D) {
+    const float s = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    atomicAdd(&gr[nd.off_lsa + (t - BNF_MAX_GROUPS)], s);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// output layer + likelihood (+ backward of the last hidden activation).
+//   block = 4 waves; wave w owns rows r0 + 8w .. +7; lane owns 8 consecutive
+//   columns per 512-column pass.
+//   forward  (models.py:269-273, 157-164): v = (H_L/sqrt W) k_o + b_o, out = gamma_o v
+//   loss     (inference.py:558-569):       -(N/B) * lik_scale * loglik
+//   backward: d out, d log_noise_scale, d output scale/bias/kernel,
+//            dZ_{L-1} = gamma (dv k_o^T/sqrt W) . act'(A_{L-1}) (+ bias/scale/alpha grads)
+// TRAIN=false: forward only (predict path).
+// ---------------------------------------------------------------------------
+struct OutArgs {
+  const float* theta;
+  int64_t theta_stride;
+  int64_t B;             // rows in this launch
+  const void* H;         // (rows, W) last hidden output, T
+  const void* A;         // (rows, W) last pre-activation, T
+  int64_t act_batch;
+  void* dZ;              // (rows, W)
+  void* dZt;             // (W, ldt)
+  int64_t actt_batch;
+  int32_t ldt;
+  const float* ybat;     // (members, ybat_batch)
+  int64_t ybat_batch;
+  float* out;            // (members, out_batch) network output
+  int64_t out_batch;
+  float* grad;
+  int64_t grad_stride;
+  float* loss;           // loss[(e / S) * loss_stride] += loss_scale * step loss
+  int64_t loss_stride;
+  int32_t S;
+  float loss_scale;
+  float c;               // (N/B) * lik_scale
+  float* loss_raw;       // optional (members,) un-scaled per-virtual-member loss (debug)
+};
+
+template <typename T, bool TRAIN>
+__global__ __launch_bounds__(256) void k_out_loss(NetDev nd, OutArgs a) {
+  constexpr bool FAST = Elem<T>::kFast;
+  __shared__ float s_dv[32];
+  __shared__ float s_red[4][8];
+  __shared__ float s_col[4][2][512];
+  const int e = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * 32 + wave * 8;
+  const float* th = a.theta + (int64_t)e * a.theta_stride;
+  const int W = nd.W, L = nd.depth;
+  const float inv_sw = 1.0f / sqrtf((float)W);
+  const float* ko = th + nd.off_kernel[L];
+  const float bo = th[nd.off_bias[L]];
+  const float gam_o = softplusf(th[nd.off_os]);
+  const T* H = reinterpret_cast<const T*>(a.H) + (int64_t)e * a.act_batch;
+
+  // ---- phase 1: row dots -----------------------------------------------------
+  float p[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = 0.f;
+  for (int cb = 0; cb < W; cb += 512) {
+    const int j0 = cb + lane * 8;
+    if (j0 < W) {
+      float kv[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) kv[c] = ko[j0 + c];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t r = r0 + i;
+        if (r < a.B) {
+          const T* hp = H + r * W + j0;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) p[i] += Elem<T>::load(hp + c) * kv[c];
+        }
+      }
+    }
+  }
+  float v_mine = 0.f;  // lane i (< 8) of the wave keeps row i
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float s = wave_sum(p[i]);
+    if (lane == i) v_mine = s;
+  }
+  float ll = 0.f, s_doutv = 0.f, s_dvsum = 0.f, s_lns = 0.f;
+  if (lane < 8) {
+    const int64_t r = r0 + lane;
+    float dv = 0.f;
+    if (r < a.B) {
+      const float v = v_mine * inv_sw + bo;
+      const float out = gam_o * v;
+      a.out[(int64_t)e * a.out_batch + r] = out;
+      if constexpr (TRAIN) {
+        const float yv = a.ybat[(int64_t)e * a.ybat_batch + r];
+        // NORMAL (models.py:157-164): sigma = 0.01 + exp(lns)
+        const float lns = th[nd.off_lns];
+        const float sigma = 0.01f + expf(lns);
+        const float res = yv - out;
+        const float z = res / sigma;
+        ll = -0.5f * z * z - logf(sigma) - 0.918938533204672742f;
+        const float dout = -a.c * res / (sigma * sigma);
+        s_doutv = dout * v;
+        dv = gam_o * dout;
+        s_dvsum = dv;
+        s_lns = -a.c * (res * res / (sigma * sigma * sigma) - 1.0f / sigma) * expf(lns);
+      }
+    }
+    if constexpr (TRAIN) s_dv[wave * 8 + lane] = dv;
+  }
+  if constexpr (!TRAIN) return;
+
+  // block sums of the 4 row scalars
+  {
+    const float t0 = wave_sum(ll), t1 = wave_sum(s_doutv), t2 = wave_sum(s_dvsum),
+                t3 = wave_sum(s_lns);
+    if (lane == 0) {
+      s_red[wave][0] = t0; s_red[wave][1] = t1; s_red[wave][2] = t2; s_red[wave][3] = t3;
+    }
+  }
+  __syncthreads();
+  float* gr = a.grad + (int64_t)e * a.grad_stride;
+  if (threadIdx.x == 0) {
+    const float t0 = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+    const float t1 = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
+    const float t2 = s_red[0][2] + s_red[1][2] + s_red[2][2] + s_red[3][2];
+    const float t3 = s_red[0][3] + s_red[1][3] + s_red[2][3] + s_red[3][3];
+    const float step_loss = -a.c * t0;
+    atomicAdd(&a.loss[(int64_t)(e / a.S) * a.loss_stride], a.loss_scale * step_loss);
+    if (a.loss_raw) atomicAdd(&a.loss_raw[e], step_loss);
+    atomicAdd(&gr[nd.off_os], sigmoidf(th[nd.off_os]) * t1);
+    atomicAdd(&gr[nd.off_bias[L]], t2);
+    atomicAdd(&gr[nd.off_lns], t3);
+  }
+
+  // ---- phase 2: last hidden layer backward -------------------------------------
+  const int l = L - 1;
+  const float gamma = softplusf(th[nd.off_ls[l]]);
+  const float alpha = sigmoidf(th[nd.off_law]);
+  const T* Ap = reinterpret_cast<const T*>(a.A) + (int64_t)e * a.act_batch;
+  T* dZ = reinterpret_cast<T*>(a.dZ) + (int64_t)e * a.act_batch;
+  T* dZt = reinterpret_cast<T*>(a.dZt) + (int64_t)e * a.actt_batch;
+  float dvr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dvr[i] = s_dv[wave * 8 + i];
+  float s_alpha = 0.f, s_gamma = 0.f;
+  for (int cb = 0; cb < W; cb += 512) {
+    const int j0 = cb + lane * 8;
+    float cs_b[8], cs_k[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cs_b[c] = cs_k[c] = 0.f;
+    if (j0 < W) {
+      float kv[8], dz[8][8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) kv[c] = ko[j0 + c] * inv_sw;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t r = r0 + i;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dz[i][c] = 0.f;
+        if (r < a.B) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const float av = Elem<T>::load(Ap + r * W + j0 + c);
+            const float hv = Elem<T>::load(H + r * W + j0 + c);
+            const float dh = dvr[i] * kv[c];
+            const ActOut o = act_eval<FAST>(av, alpha);
+            s_alpha += dh * o.ediff;
+            const float da = dh * o.dact;
+            s_gamma += da * av;
+            const float z = gamma * da;
+            dz[i][c] = z;
+            cs_b[c] += z;
+            cs_k[c] += hv * dvr[i];
+            Elem<T>::store(dZ + r * W + j0 + c, z);
+          }
+        }
+      }
+      // transposed copy: 8 consecutive rows of each column
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        T* tp = dZt + (int64_t)(j0 + c) * a.ldt + r0;
+        if (r0 + 7 < a.B) {
+          store4(tp, dz[0][c], dz[1][c], dz[2][c], dz[3][c]);
+          store4(tp + 4, dz[4][c], dz[5][c], dz[6][c], dz[7][c]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (r0 + i < a.B) Elem<T>::store(tp + i, dz[i][c]);
+        }
+      }
+    }
+    // column sums over the 4 waves (32 rows), then one atomic per column
+    if (j0 < W) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        s_col[wave][0][lane * 8 + c] = cs_b[c];
+        s_col[wave][1][lane * 8 + c] = cs_k[c];
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 1024; t += 256) {
+      const int which = t >> 9, col = t & 511;
+      if (cb + col < W) {
+        const float s = s_col[0][which][col] + s_col[1][which][col] + s_col[2][which][col] +
+                        s_col[3][which][col];
+        if (which == 0) atomicAdd(&gr[nd.off_bias[l] + cb + col], s);
+        else atomicAdd(&gr[nd.off_kernel[L] + cb + col], s * inv_sw);
+      }
+    }
+    __syncthreads();
+  }
+  {
+    const float t0 = wave_sum(s_alpha), t1 = wave_sum(s_gamma);
+    if (lane == 0) {
+      s_red[wave][4] = t0; s_red[wave][5] = t1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float ta = s_red[0][4] + s_red[1][4] + s_red[2][4] + s_red[3][4];
+    const float tg = s_red[0][5] + s_red[1][5] + s_red[2][5] + s_red[3][5];
+    atomicAdd(&gr[nd.off_law], alpha * (1.f - alpha) * ta);
+    atomicAdd(&gr[nd.off_ls[l]], sigmoidf(th[nd.off_ls[l]]) * tg / gamma);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// packed operand copies of the Dense kernels (both layouts, type T):
+//   Kn (n_pad, W)  = K            -> Bt of the dgrad contraction
+//   Kt (W, n_pad)  = K^T          -> Bt of the forward contraction
+// 32x32 tiles through LDS so both writes are coalesced.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ theta,
+                                                      int64_t theta_stride, int32_t off_kernel,
+                                                      int32_t n_in, int32_t n_pad, int32_t W,
+                                                      T* __restrict__ Kn, T* __restrict__ Kt,
+                                                      int64_t pack_batch) {
+  __shared__ float tile[32][33];
+  const int e = blockIdx.y;
+  const int tiles_j = W / 32;
+  const int ti = blockIdx.x / tiles_j, tj = blockIdx.x % tiles_j;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* K = theta + (int64_t)e * theta_stride + off_kernel;
+  T* kn = Kn + (int64_t)e * pack_batch;
+  T* kt = Kt + (int64_t)e * pack_batch;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int i = ti * 32 + ty + s * 8, j = tj * 32 + tx;
+    const float v = (i < n_in) ? K[(int64_t)i * W + j] : 0.f;
+    tile[ty + s * 8][tx] = v;
+    if (i < n_pad) Elem<T>::store(kn + (int64_t)i * W + j, v);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int j = tj * 32 + ty + s * 8, i = ti * 32 + tx;
+    if (i < n_pad) Elem<T>::store(kt + (int64_t)j * n_pad + i, tile[tx][ty + s * 8]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Logistic prior + Adam (models.py:94-103, inference.py:569,580,605-606).
+//   g_total = g_lik + prior_weight * tanh((theta - loc)/2)
+//   loss   += loss_scale * (-prior_weight * sum log Logistic(theta; loc, 1))
+// Also clears the gradient buffer for the next step's atomics.
+// ---------------------------------------------------------------------------
+struct AdamArgs {
+  float* theta; float* m; float* v; float* grad;
+  int64_t stride;         // P
+  int32_t P;
+  int32_t off_shape;      // the one leaf with prior loc -1.5
+  float lr, bc1, bc2;     // bias corrections 1 - b1^t, 1 - b2^t
+  float prior_weight;
+  float* loss; int64_t loss_stride; float loss_scale;
+  int32_t apply;          // 0: only add the prior gradient into grad (debug path)
+  float* loss_raw;
+};
+
+__global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
+  __shared__ float red[4];
+  const int e = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  float lp = 0.f;
+  if (p < a.P) {
+    const int64_t i = (int64_t)e * a.stride + p;
+    const float th = a.theta[i];
+    float g = a.grad[i];
+    if (a.prior_weight != 0.f) {
+      const float z = th - (p == a.off_shape ? -1.5f : 0.f);
+      g += a.prior_weight * tanhf(0.5f * z);
+      lp = -z - 2.f * softplusf(-z);
+    }
+    if (a.apply) {
+      const float m = 0.9f * a.m[i] + 0.1f * g;
+      const float v = 0.999f * a.v[i] + 0.001f * g * g;
+      a.m[i] = m;
+      a.v[i] = v;
+      a.theta[i] = th - a.lr * (m / a.bc1) / (sqrtf(v / a.bc2) + 1e-8f);
+      a.grad[i] = 0.f;
+    } else {
+      a.grad[i] = g;
+    }
+  }
+  const float s = wave_sum(lp);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0 && a.prior_weight != 0.f) {
+    const float t = -(a.prior_weight) * (red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(&a.loss[(int64_t)e * a.loss_stride], a.loss_scale * t);
+    if (a.loss_raw) atomicAdd(&a.loss_raw[e], t);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// mean-field VI (inference.py:687-720): sample, then combine S sample gradients.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float vi_sigma(float rho) { return 1e-4f + softplusf(rho); }
+
+__global__ __launch_bounds__(256) void k_vi_sample(const float* __restrict__ mu,
+                                                   const float* __restrict__ rho, int32_t P,
+                                                   int32_t S, uint64_t seed, int64_t member_offset,
+                                                   uint64_t step, uint32_t stream,
+                                                   float* __restrict__ z, int64_t z_member_stride,
+                                                   int64_t z_sample_stride) {
+  // grid: (ceil(P/256), members, S)
+  const int e = blockIdx.y, s = blockIdx.z;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int64_t i = (int64_t)e * P + p;
+  const float eps = vi_eps(seed, (uint32_t)(member_offset + e), (uint32_t)s, (uint32_t)p, step, stream);
+  z[(int64_t)e * z_member_stride + (int64_t)s * z_sample_stride + p] = mu[i] + vi_sigma(rho[i]) * eps;
+}
+
+struct ViAdamArgs {
+  float* mu; float* rho; float* m_mu; float* v_mu; float* m_rho; float* v_rho;
+  float* grad;            // (members*S, P) likelihood gradients wrt z (scaled by 1/kl)
+  int32_t P, S, off_shape;
+  uint64_t seed; int64_t member_offset; uint64_t step;
+  float lr, bc1, bc2, kl_weight;
+  float* loss; int64_t loss_stride;
+  int32_t apply;
+  float* gmu_out; float* grho_out;  // debug: (members, P) each
+};
+
+__global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
+  __shared__ float red[4];
+  const int e = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  float lterm = 0.f;
+  if (p < a.P) {
+    const int64_t i = (int64_t)e * a.P + p;
+    const float mu = a.mu[i], rho = a.rho[i];
+    const float sig = vi_sigma(rho);
+    const float loc = (p == a.off_shape) ? -1.5f : 0.f;
+    float gmu = 0.f, grho = 0.f, e2 = 0.f, lpr = 0.f;
+    for (int s = 0; s < a.S; ++s) {
+      const float eps = vi_eps(a.seed, (uint32_t)(a.member_offset + e), (uint32_t)s, (uint32_t)p,
+                               a.step, STREAM_VI_EPS);
+      const float z = mu + sig * eps - loc;
+      const int64_t gi = ((int64_t)e * a.S + s) * a.P + p;
+      const float g = a.grad[gi] + tanhf(0.5f * z);
+      if (a.apply) a.grad[gi] = 0.f;
+      gmu += g;
+      grho += g * eps;
+      e2 += eps * eps;
+      lpr += -z - 2.f * softplusf(-z);
+    }
+    const float invS = 1.f / (float)a.S;
+    gmu *= invS;
+    grho = sigmoidf(rho) * (grho * invS - 1.f / sig);
+    // mean_s [ log q(z_s) - log p(z_s) ] for this coordinate
+    lterm = (-0.5f * e2 * invS - logf(sig) - 0.918938533204672742f) - lpr * invS;
+    if (a.apply) {
+      float m = 0.9f * a.m_mu[i] + 0.1f * gmu, v = 0.999f * a.v_mu[i] + 0.001f * gmu * gmu;
+      a.m_mu[i] = m; a.v_mu[i] = v;
+      a.mu[i] = mu - a.lr * (m / a.bc1) / (sqrtf(v / a.bc2) + 1e-8f);
+      m = 0.9f * a.m_rho[i] + 0.1f * grho; v = 0.999f * a.v_rho[i] + 0.001f * grho * grho;
+      a.m_rho[i] = m; a.v_rho[i] = v;
+      a.rho[i] = rho - a.lr * (m / a.bc1) / (sqrtf(v / a.bc2) + 1e-8f);
+    } else {
+      a.gmu_out[i] = gmu;
+      a.grho_out[i] = grho;
+    }
+  }
+  const float s = wave_sum(lterm);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicAdd(&a.loss[(int64_t)e * a.loss_stride], a.kl_weight * (red[0] + red[1] + red[2] + red[3]));
+}
+
+// ---------------------------------------------------------------------------
+// initial values (inference.py:399-427, 203-231)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_params(float* __restrict__ theta, int32_t P,
+                                                     const uint8_t* __restrict__ is_matrix,
+                                                     int32_t off_lns, float lns_init, uint64_t seed,
+                                                     int64_t member_offset) {
+  const int e = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float v = 0.f;
+  if (is_matrix[p]) {
+    const Philox r = philox4x32((uint32_t)p, (uint32_t)(member_offset + e), 0u, STREAM_INIT,
+                                (uint32_t)seed, (uint32_t)(seed >> 32));
+    v = trunc_normal_m2p2(r.v[0]);
+  } else if (p == off_lns) {
+    v = lns_init;
+  }
+  theta[(int64_t)e * P + p] = v;
+}
+
+__global__ void k_fill(float* p, int64_t n, float v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ void k_row_index(RowSrc rs, int64_t B, int32_t* out) {
+  const int e = blockIdx.y;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < B) out[(int64_t)e * B + r] = (int32_t)row_of(rs, e, r);
+}
+
+__global__ void k_vi_eps_dump(int32_t P, uint64_t seed, int64_t member_offset, uint64_t step,
+                              float* out) {
+  const int e = blockIdx.y, s = blockIdx.z, S = gridDim.z;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < P)
+    out[((int64_t)e * S + s) * P + p] =
+        vi_eps(seed, (uint32_t)(member_offset + e), (uint32_t)s, (uint32_t)p, step, STREAM_VI_EPS);
+}
+
+// predict: aux[e] = {0.01 + exp(lns), softplus(shape), sigmoid(infl)}
+__global__ void k_forecast_aux(const float* theta, int64_t stride, int32_t n, int32_t off_lns,
+                               int32_t off_shape, int32_t off_infl, float* aux) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const float* th = theta + (int64_t)e * stride;
+  aux[e * 3 + 0] = 0.01f + expf(th[off_lns]);
+  aux[e * 3 + 1] = softplusf(th[off_shape]);
+  aux[e * 3 + 2] = sigmoidf(th[off_infl]);
+}
+
+// ---------------------------------------------------------------------------
+// conversions / copies used by the debug entry points
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_to_f32(const T* __restrict__ src, int64_t src_batch, int32_t src_ld,
+                         int64_t rows, int32_t cols, float* __restrict__ dst) {
+  const int e = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int64_t r = i / cols;
+  const int c = (int)(i % cols);
+  dst[(int64_t)e * rows * cols + i] = Elem<T>::load(src + (int64_t)e * src_batch + r * src_ld + c);
+}
+
+template <typename T>
+__global__ void k_from_f32(const float* __restrict__ src, int64_t rows, int32_t cols,
+                           T* __restrict__ dst, int32_t dst_ld) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int64_t r = i / cols;
+  const int c = (int)(i % cols);
+  Elem<T>::store(dst + r * dst_ld + c, src[i]);
+}
+
+// ---------------------------------------------------------------------------
+// mixture-of-Normals quantiles (inference.py:42-84)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_minmax_partial(const float* __restrict__ x, int64_t n,
+                                                        float* __restrict__ part) {
+  __shared__ float smin[4], smax[4];
+  float lo = INFINITY, hi = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  if ((threadIdx.x & 63) == 0) {
+    smin[threadIdx.x >> 6] = lo;
+    smax[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+    part[blockIdx.x * 2 + 1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+  }
+}
+
+// bracket[0..1] = [min mu - 5 max sigma, max mu + 5 max sigma]
+__global__ void k_bracket(const float* mean_part, int n_mean_part, const float* scale_part,
+                          int n_scale_part, float* bracket) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float lo = INFINITY, hi = -INFINITY, smax = -INFINITY;
+  for (int i = 0; i < n_mean_part; ++i) {
+    lo = fminf(lo, mean_part[2 * i]);
+    hi = fmaxf(hi, mean_part[2 * i + 1]);
+  }
+  for (int i = 0; i < n_scale_part; ++i) smax = fmaxf(smax, scale_part[2 * i + 1]);
+  bracket[0] = lo - 5.f * smax;
+  bracket[1] = hi + 5.f * smax;
+}
+
+__device__ __forceinline__ float ndtrf(float z) { return 0.5f * erfcf(-z * 0.70710678118654752440f); }
+
+__device__ __forceinline__ float mix_cdf(const float* __restrict__ means,
+                                         const float* __restrict__ scales, int64_t n_members,
+                                         int64_t n_rows, int64_t r, float x) {
+  float acc = 0.f;
+  for (int64_t m = 0; m < n_members; ++m) acc += ndtrf((x - means[m * n_rows + r]) / scales[m]);
+  return acc / (float)n_members;
+}
+
+// Chandrupatla's bracketing root finder (the algorithm behind
+// tfp.math.find_root_chandrupatla), one thread per row.
+__global__ __launch_bounds__(256) void k_quantile_root(const float* __restrict__ means,
+                                                       const float* __restrict__ scales,
+                                                       int64_t n_members, int64_t n_rows,
+                                                       const float* __restrict__ bracket, float q,
+                                                       float* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const float vtol = 1e-5f, ptol = 1e-8f;
+  float a = bracket[0], b = bracket[1];
+  float fa = mix_cdf(means, scales, n_members, n_rows, r, a) - q;
+  float fb = mix_cdf(means, scales, n_members, n_rows, r, b) - q;
+  float c = a, fc = fa, t = 0.5f;
+  float best = fabsf(fa) < fabsf(fb) ? a : b;
+  float fbest = fabsf(fa) < fabsf(fb) ? fa : fb;
+  for (int it = 0; it < 60 && fabsf(fbest) > vtol; ++it) {
+    const float xn = a + t * (b - a);
+    const float fn = mix_cdf(means, scales, n_members, n_rows, r, xn) - q;
+    const bool same = (fn > 0.f) == (fa > 0.f) && (fn < 0.f) == (fa < 0.f);
+    if (same) { c = a; fc = fa; }
+    else { c = b; fc = fb; b = a; fb = fa; }
+    a = xn; fa = fn;
+    if (fabsf(fa) < fabsf(fb)) { best = a; fbest = fa; } else { best = b; fbest = fb; }
+    const float tol = ptol / fabsf(b - c);
+    if (tol > 0.5f || fbest == 0.f) break;
+    const float xi = (a - b) / (c - b), phi = (fa - fb) / (fc - fb);
+    if (phi * phi < xi && (1.f - phi) * (1.f - phi) < 1.f - xi) {
+      t = (fa / (fb - fa)) * (fc / (fb - fc)) + ((c - a) / (b - a)) * (fa / (fc - fa)) * (fb / (fc - fb));
+    } else {
+      t = 0.5f;
+    }
+    t = fminf(fmaxf(t, tol), 1.f - tol);
+    if (!(t == t)) t = 0.5f;
+  }
+  out[r] = best;
+}
+
+// moment-matched Normal quantile (inference.py:55-84)
+__global__ __launch_bounds__(256) void k_quantile_approx(const float* __restrict__ means,
+                                                         const float* __restrict__ scales,
+                                                         int64_t n_members, int64_t n_rows, float q,
+                                                         float* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t m = 0; m < n_members; ++m) {
+    const float mu = means[m * n_rows + r], sd = scales[m];
+    s1 += mu;
+    s2 += sd * sd + mu * mu;
+  }
+  const float mm = s1 / (float)n_members;
+  const float var = s2 / (float)n_members - mm * mm;
+  out[r] = mm + sqrtf(fmaxf(var, 0.f)) * normcdfinvf(q);
+}
+
+}  // namespace bnf

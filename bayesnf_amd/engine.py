@@ -1,0 +1,235 @@
+"""Thin Python owner of one `bnf_handle` and of the device buffers it uses.
+
+torch-ROCm supplies device memory and the HIP stream; every computation is a
+call into libbnf_hip.so through ctypes (`_native`).  No computation here.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _native
+from . import distributed
+from .spec import NetSpec
+
+
+def default_dtype(compute_dtype=None) -> str:
+  dt = compute_dtype or os.environ.get('BNF_DTYPE', 'fp32')
+  if dt not in _native.DTYPE:
+    raise ValueError(f'compute_dtype must be one of {sorted(_native.DTYPE)}')
+  return 'bf16' if _native.DTYPE[dt] == 1 else 'fp32'
+
+
+def _ptr(t):
+  return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+  """One GPU's share of an ensemble: `members` networks trained side by side.
+
+  mode 'map' (MAP / MLE via prior_weight) or 'vi'.  X (N, D) and y (N,) are
+  copied to the device once, as float32 (what `jnp.array` does with x64 off,
+  reference inference.py:553-554).
+  """
+
+  def __init__(self, net: NetSpec, *, mode='map', X=None, y=None, batch=None,
+               members=1, member_offset=0, seed=0, learning_rate=0.005,
+               prior_weight=1.0, kl_weight=1.0, vi_samples=1,
+               compute_dtype=None, forward_only=False, row_capacity=None,
+               device_index=None):
+    self.lib = _native.load()
+    if not torch.cuda.is_available():
+      raise RuntimeError(
+          'bayesnf_amd: no GPU visible (torch.cuda.is_available() is False). '
+          'The engine is HIP-only; there is no CPU fallback.')
+    self.net = net
+    self.mode = mode
+    self.dtype = default_dtype(compute_dtype)
+    self.dev_index = (distributed.local_device_index()
+                      if device_index is None else int(device_index))
+    self.device = torch.device(f'cuda:{self.dev_index}')
+    torch.cuda.set_device(self.device)
+    self.members = int(members)
+    self.member_offset = int(member_offset)
+    self.forward_only = bool(forward_only)
+    if forward_only:
+      n_rows = batch = int(row_capacity)
+      self.X = self.y = None
+    else:
+      X = np.ascontiguousarray(np.asarray(X, dtype=np.float64), dtype=np.float32)
+      y = np.ascontiguousarray(np.asarray(y, dtype=np.float64), dtype=np.float32)
+      n_rows = X.shape[0]
+      batch = n_rows if batch is None else int(batch)
+      self.X = torch.from_numpy(X).to(self.device)
+      self.y = torch.from_numpy(y).to(self.device)
+    self.n_rows, self.batch = n_rows, batch
+    self.S = int(vi_samples) if mode == 'vi' else 1
+    cfg = _native.make_config(
+        net, device=self.dev_index, dtype=self.dtype,
+        mode=_native.MODE_VI if mode == 'vi' else _native.MODE_MAP,
+        n_rows=n_rows, batch=batch, members=members,
+        member_offset=member_offset, seed=_native.seed_to_u64(seed),
+        learning_rate=learning_rate, prior_weight=prior_weight,
+        kl_weight=kl_weight, vi_samples=self.S, forward_only=forward_only)
+    self.cfg = cfg
+    handle = C.c_void_p()
+    _native.check(self.lib.bnf_create(C.byref(cfg), C.byref(handle)), 'bnf_create')
+    self.handle = handle
+    ws_bytes = self.lib.bnf_workspace_bytes(handle)
+    self.workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+    if forward_only:
+      self.params = self.state = None
+    else:
+      self.params = torch.empty(self.lib.bnf_param_bytes(handle) // 4,
+                                dtype=torch.float32, device=self.device)
+      self.state = torch.empty(self.lib.bnf_state_bytes(handle) // 4,
+                               dtype=torch.float32, device=self.device)
+    self.stream = torch.cuda.current_stream(self.device)
+    _native.check(
+        self.lib.bnf_bind(handle, _ptr(self.params), _ptr(self.state),
+                          _ptr(self.workspace), _ptr(self.X), _ptr(self.y),
+                          C.c_void_p(self.stream.cuda_stream)), 'bnf_bind')
+
+  # -- lifecycle ---------------------------------------------------------------
+  def close(self):
+    if getattr(self, 'handle', None) is not None:
+      torch.cuda.synchronize(self.device)
+      self.lib.bnf_destroy(self.handle)
+      self.handle = None
+      self.workspace = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  # -- training ----------------------------------------------------------------
+  def init_params(self, log_noise_init: float):
+    _native.check(self.lib.bnf_init_params(self.handle, C.c_float(log_noise_init)),
+                  'bnf_init_params')
+
+  def set_params(self, theta):
+    """theta: array (members, P) [MAP] or (2, members, P) = (mu, rho) [VI]."""
+    t = torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float32))
+    self.params.copy_(t.reshape(-1).to(self.device))
+
+  def get_params(self) -> np.ndarray:
+    p = self.params.detach().cpu().numpy()
+    if self.mode == 'vi':
+      return p.reshape(2, self.members, self.net.P)
+    return p.reshape(self.members, self.net.P)
+
+  def train(self, epoch0: int, num_epochs: int) -> torch.Tensor:
+    """Enqueue the whole optimisation; returns the (members, num_epochs) loss
+    tensor on the device (valid after a stream sync)."""
+    losses = torch.zeros((self.members, num_epochs), dtype=torch.float32,
+                         device=self.device)
+    if num_epochs > 0:
+      _native.check(self.lib.bnf_train(self.handle, int(epoch0), int(num_epochs),
+                                       _ptr(losses)), 'bnf_train')
+    return losses
+
+  def vi_posterior_draws(self, n_draws: int) -> torch.Tensor:
+    out = torch.empty((n_draws, self.members, self.net.P), dtype=torch.float32,
+                      device=self.device)
+    _native.check(self.lib.bnf_vi_posterior_draws(self.handle, int(n_draws), _ptr(out)),
+                  'bnf_vi_posterior_draws')
+    return out
+
+  # -- prediction --------------------------------------------------------------
+  def forward(self, theta: torch.Tensor, Xnew: torch.Tensor):
+    """theta (M, P) f32 device, Xnew (R, D) f32 device -> loc (M, R), aux (M, 3)."""
+    theta = theta.contiguous()
+    Xnew = Xnew.contiguous()
+    M, R = theta.shape[0], Xnew.shape[0]
+    loc = torch.empty((M, R), dtype=torch.float32, device=self.device)
+    aux = torch.empty((M, 3), dtype=torch.float32, device=self.device)
+    _native.check(self.lib.bnf_forward(self.handle, _ptr(theta), M, _ptr(Xnew), R,
+                                       _ptr(loc), _ptr(aux)), 'bnf_forward')
+    return loc, aux
+
+  def normal_mixture_quantiles(self, means: torch.Tensor, scales: torch.Tensor,
+                               quantiles, approximate=False) -> torch.Tensor:
+    """means (M, R), scales (M,) -> (n_q, R)."""
+    means = means.contiguous().float()
+    scales = scales.contiguous().float()
+    q = np.asarray(list(quantiles), dtype=np.float32)
+    out = torch.empty((len(q), means.shape[1]), dtype=torch.float32, device=self.device)
+    qa = (C.c_float * len(q))(*q.tolist())
+    _native.check(self.lib.bnf_normal_mixture_quantiles(
+        self.handle, _ptr(means), _ptr(scales), means.shape[0], means.shape[1], qa,
+        len(q), 1 if approximate else 0, _ptr(out)), 'bnf_normal_mixture_quantiles')
+    return out
+
+  # -- introspection (tests, bench) -------------------------------------------
+  def debug_loss_and_grad(self, epoch=0, step=0):
+    k = 2 if self.mode == 'vi' else 1
+    grads = torch.empty((k * self.members, self.net.P), dtype=torch.float32, device=self.device)
+    loss = torch.empty((self.members,), dtype=torch.float32, device=self.device)
+    _native.check(self.lib.bnf_debug_loss_and_grad(self.handle, epoch, step, _ptr(grads),
+                                                   _ptr(loss)), 'bnf_debug_loss_and_grad')
+    torch.cuda.synchronize(self.device)
+    g = grads.cpu().numpy()
+    if self.mode == 'vi':
+      g = g.reshape(2, self.members, self.net.P)
+    return loss.cpu().numpy(), g
+
+  def debug_row_index(self, epoch=0, step=0) -> np.ndarray:
+    out = torch.empty((self.members, self.batch), dtype=torch.int32, device=self.device)
+    _native.check(self.lib.bnf_debug_row_index(self.handle, epoch, step, _ptr(out)),
+                  'bnf_debug_row_index')
+    torch.cuda.synchronize(self.device)
+    return out.cpu().numpy()
+
+  def debug_vi_eps(self, step=0) -> np.ndarray:
+    out = torch.empty((self.members, self.S, self.net.P), dtype=torch.float32, device=self.device)
+    _native.check(self.lib.bnf_debug_vi_eps(self.handle, step, _ptr(out)), 'bnf_debug_vi_eps')
+    torch.cuda.synchronize(self.device)
+    return out.cpu().numpy()
+
+  def debug_activation(self, what: int) -> np.ndarray:
+    ev = self.members * self.S
+    if what == 0 or what == 400:
+      shape = (ev, self.batch, self.net.F)
+    elif what == 200:
+      shape = (ev, self.batch)
+    else:
+      shape = (ev, self.batch, self.net.width)
+    out = torch.empty(shape, dtype=torch.float32, device=self.device)
+    _native.check(self.lib.bnf_debug_activation(self.handle, what, _ptr(out)),
+                  'bnf_debug_activation')
+    torch.cuda.synchronize(self.device)
+    return out.cpu().numpy()
+
+  def debug_gemm_nt(self, A: np.ndarray, Bt: np.ndarray) -> np.ndarray:
+    A = torch.as_tensor(np.ascontiguousarray(A, dtype=np.float32)).to(self.device)
+    Bt = torch.as_tensor(np.ascontiguousarray(Bt, dtype=np.float32)).to(self.device)
+    Cout = torch.empty((A.shape[0], Bt.shape[0]), dtype=torch.float32, device=self.device)
+    _native.check(self.lib.bnf_debug_gemm_nt(self.handle, _ptr(A), _ptr(Bt), A.shape[0],
+                                             Bt.shape[0], A.shape[1], _ptr(Cout)),
+                  'bnf_debug_gemm_nt')
+    torch.cuda.synchronize(self.device)
+    return Cout.cpu().numpy()
+
+  def profile(self, on: bool):
+    _native.check(self.lib.bnf_profile_enable(self.handle, 1 if on else 0), 'bnf_profile_enable')
+
+  def profile_read(self) -> dict:
+    cap = 32
+    n = C.c_int32(cap)
+    names = (C.c_char_p * cap)()
+    avg = (C.c_double * cap)()
+    calls = (C.c_int64 * cap)()
+    _native.check(self.lib.bnf_profile_read(self.handle, C.byref(n), names, avg, calls),
+                  'bnf_profile_read')
+    out = {}
+    for i in range(n.value):
+      name = names[i].decode()
+      out[name] = dict(avg_ms=avg[i], calls=calls[i],
+                       flops=self.lib.bnf_kernel_flops(self.handle, names[i]))
+    return out

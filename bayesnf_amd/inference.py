@@ -1,0 +1,240 @@
+"""Engine seam: same three entry points as the reference's inference module.
+
+  fit_map      /root/reference/src/bayesnf/inference.py:376-458
+  fit_vi       /root/reference/src/bayesnf/inference.py:336-373
+  predict_bnf  /root/reference/src/bayesnf/inference.py:461-507
+
+with identical argument names / meaning / return structure, so the estimator
+layer (spatiotemporal.py) reads like the reference's.  Underneath, every member
+lives on one GPU (`engine.Engine` -> libbnf_hip.so); ranks hold disjoint member
+shards and the fitted parameters / predictive means are all-gathered once at
+the end (the reference's implicit pmap output gather, inference.py:452,486-492).
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+import torch
+
+from . import _native
+from . import distributed
+from .engine import Engine
+from .spec import NetSpec
+
+
+def _net_from_args(model_args: dict[str, Any], observation_model: str) -> NetSpec:
+  args = dict(model_args)
+  args.pop('likelihood_distribution', None)
+  return NetSpec(observation_model=observation_model, **args)
+
+
+def _struct_tuple(net: NetSpec, theta: np.ndarray):
+  """(..., P) -> StructTuple(var0, var1, ...) of (..., *leaf_shape) arrays."""
+  return net.struct_tuple_type()(*net.unpack(theta))
+
+
+def _flatten_struct(net: NetSpec, params) -> np.ndarray:
+  """StructTuple with arbitrary leading dims -> (..., P) float32."""
+  return net.pack(list(params), dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------
+# MAP / MLE
+# ---------------------------------------------------------------------------
+def fit_map(features, target, seed, observation_model, model_args, num_particles,
+            learning_rate, num_epochs, prior_weight=1.0, batch_size=None,
+            num_splits=1, compute_dtype=None):
+  """Fit `num_particles` MAP (or MLE, prior_weight=0) members.
+
+  Returns (params, losses): params is a StructTuple whose leaves have shape
+  (num_devices, num_particles // num_devices, *leaf_shape); losses has shape
+  (num_devices, num_particles // num_devices, num_epochs).
+  """
+  net = _net_from_args(model_args, observation_model)
+  features = np.asarray(features, dtype=np.float64)
+  target = np.asarray(target, dtype=np.float64)
+  n_rows = target.shape[0]
+  if batch_size is None:
+    batch_size = n_rows
+  world, rank = distributed.device_count(), distributed.rank()
+  seed64 = _native.seed_to_u64(seed)
+  per_device = (num_particles // num_splits) // world
+  if per_device < 1:
+    raise ValueError('fewer than one particle per device and split')
+  log_noise_init = float(np.log(np.nanstd(target) / 2.0))
+  thetas, losses = [], []
+  for i in range(num_splits):
+    seed_i = _native.fold_in(seed64, i) if num_splits > 1 else seed64
+    eng = Engine(net, mode='map', X=features, y=target, batch=batch_size,
+                 members=per_device, member_offset=rank * per_device, seed=seed_i,
+                 learning_rate=learning_rate, prior_weight=prior_weight,
+                 compute_dtype=compute_dtype)
+    eng.init_params(log_noise_init)
+    loss_dev = eng.train(0, num_epochs)
+    theta_dev = eng.params.view(per_device, net.P)
+    thetas.append(distributed.all_gather_stack(theta_dev).cpu().numpy())
+    losses.append(distributed.all_gather_stack(loss_dev).cpu().numpy())
+    eng.close()
+  theta = np.concatenate(thetas, axis=1)          # (world, E/world, P)
+  return _struct_tuple(net, theta), np.concatenate(losses, axis=1)
+
+
+# ---------------------------------------------------------------------------
+# VI
+# ---------------------------------------------------------------------------
+class MeanFieldSurrogate:
+  """What `ensemble_vi` returns first (a JointDistribution of Normals in the
+  reference, inference.py:760-764): per-coordinate mean and scale."""
+
+  def __init__(self, net: NetSpec, mu: np.ndarray, rho: np.ndarray):
+    self.net = net
+    self.loc = _struct_tuple(net, mu)
+    self.scale = _struct_tuple(net, 1e-4 + np.logaddexp(rho, 0.0))
+    self._mu, self._rho = mu, rho
+
+  def mean(self):
+    return self.loc
+
+  def stddev(self):
+    return self.scale
+
+
+def fit_vi(features, target, seed, observation_model, model_args, ensemble_size,
+           learning_rate, num_epochs, sample_size_divergence,
+           sample_size_posterior, kl_weight, batch_size=None, compute_dtype=None):
+  """Fit mean-field surrogates.  Returns (surrogate, losses, predictions):
+  losses (num_devices, E/num_devices, num_epochs) already multiplied by
+  kl_weight; predictions = StructTuple of posterior draws with leaves
+  (num_devices, sample_size_posterior, E/num_devices, *leaf_shape)."""
+  net = _net_from_args(model_args, observation_model)
+  features = np.asarray(features, dtype=np.float64)
+  target = np.asarray(target, dtype=np.float64)
+  n_rows = target.shape[0]
+  if batch_size is not None and n_rows < batch_size:
+    raise AssertionError(f'batch_size={batch_size} exceeds target.shape[0]={n_rows}')
+  world, rank = distributed.device_count(), distributed.rank()
+  per_device = ensemble_size // world
+  if per_device < 1:
+    raise ValueError('fewer than one surrogate per device')
+  eng = Engine(net, mode='vi', X=features, y=target,
+               batch=n_rows if batch_size is None else batch_size,
+               members=per_device, member_offset=rank * per_device,
+               seed=_native.seed_to_u64(seed), learning_rate=learning_rate,
+               kl_weight=kl_weight, vi_samples=sample_size_divergence,
+               compute_dtype=compute_dtype)
+  eng.init_params(0.0)
+  loss_dev = eng.train(0, num_epochs)
+  draws = eng.vi_posterior_draws(sample_size_posterior)   # (n, E_local, P)
+  mu_rho = eng.params.view(2, per_device, net.P)
+  mu = distributed.all_gather_stack(mu_rho[0]).cpu().numpy()
+  rho = distributed.all_gather_stack(mu_rho[1]).cpu().numpy()
+  losses = distributed.all_gather_stack(loss_dev).cpu().numpy()
+  preds = distributed.all_gather_stack(draws).cpu().numpy()   # (world, n, E/world, P)
+  eng.close()
+  return MeanFieldSurrogate(net, mu, rho), losses, _struct_tuple(net, preds)
+
+
+# ---------------------------------------------------------------------------
+# predict
+# ---------------------------------------------------------------------------
+_ROW_CHUNK = 8192
+
+
+def _forward_local(net, theta_local, features, compute_dtype):
+  """theta_local (M, P) numpy: members owned by this rank -> loc (M, R), aux (M, 3)
+  as device tensors, plus the engine (kept alive for the quantile kernels)."""
+  n_rows = features.shape[0]
+  M = theta_local.shape[0]
+  # capacity: bound activation memory to ~2 GiB of (members x rows x width) cells
+  cells = max(1, (1 << 28) // max(1, net.width))
+  row_cap = int(min(n_rows, _ROW_CHUNK))
+  mem_cap = int(max(1, min(M, cells // row_cap)))
+  eng = Engine(net, mode='map', members=mem_cap, forward_only=True,
+               row_capacity=row_cap, compute_dtype=compute_dtype)
+  theta = torch.from_numpy(np.ascontiguousarray(theta_local, dtype=np.float32)).to(eng.device)
+  X = torch.from_numpy(np.ascontiguousarray(
+      np.asarray(features, dtype=np.float64), dtype=np.float32)).to(eng.device)
+  loc, aux = eng.forward(theta, X)
+  return eng, loc, aux
+
+
+def _ensemble_forecast(features, observation_model, params, model_args,
+                       ensemble_dims, compute_dtype):
+  net = _net_from_args(model_args, observation_model)
+  theta_all = _flatten_struct(net, params)            # (world, [S,] E/world, P)
+  lead = theta_all.shape[:-1]
+  if len(lead) != ensemble_dims:
+    raise ValueError(f'params have {len(lead)} ensemble dims, expected {ensemble_dims}')
+  world, rank = distributed.device_count(), distributed.rank()
+  if lead[0] != world:
+    raise ValueError(f'params were fitted on {lead[0]} devices, job has {world}')
+  theta_local = theta_all[rank].reshape(-1, net.P)
+  eng, loc, aux = _forward_local(net, theta_local, features, compute_dtype)
+  loc_all = distributed.all_gather_stack(loc)          # (world, M_local, R)
+  aux_all = distributed.all_gather_stack(aux)
+  return net, eng, lead, loc_all, aux_all
+
+
+def predict_bnf(features, observation_model, params, model_args, quantiles,
+                ensemble_dims=2, approximate_quantiles=False, compute_dtype=None):
+  """-> (means, [quantile arrays]).  means: leading ensemble dims of `params`
+  + (n_rows,); each quantile array has shape (n_rows,)."""
+  assert ensemble_dims >= 1
+  if observation_model != 'NORMAL':
+    raise NotImplementedError(
+        'predict for NB / ZINB observation models is not built yet (SURVEY row N4)')
+  features = np.asarray(features, dtype=np.float64)
+  net, eng, lead, loc_all, aux_all = _ensemble_forecast(
+      features, observation_model, params, model_args, ensemble_dims, compute_dtype)
+  n_rows = features.shape[0]
+  means = loc_all.reshape(-1, n_rows)
+  scales = aux_all.reshape(-1, 3)[:, 0]
+  q = eng.normal_mixture_quantiles(means, scales, quantiles,
+                                   approximate=approximate_quantiles)
+  torch.cuda.synchronize(eng.device)
+  means_np = means.cpu().numpy().reshape(tuple(lead) + (n_rows,))
+  q_np = q.cpu().numpy()
+  eng.close()
+  return means_np, [q_np[i] for i in range(q_np.shape[0])]
+
+
+class EnsembleLikelihood:
+  """Minimal stand-in for the TFP distribution returned by the reference's
+  `likelihood_model` (spatiotemporal.py:433-468): Independent Normal per
+  member with event shape (n_rows,) and batch shape = ensemble dims."""
+
+  def __init__(self, loc: np.ndarray, scale: np.ndarray):
+    self.loc = loc                       # (*ens, R)
+    self.scale = scale[..., None]        # (*ens, 1)
+
+  def mean(self):
+    return self.loc
+
+  def stddev(self):
+    return np.broadcast_to(self.scale, self.loc.shape)
+
+  def log_prob(self, y):
+    y = np.asarray(y, dtype=np.float64)
+    z = (y - self.loc) / self.scale
+    return np.sum(-0.5 * z * z - np.log(self.scale) - 0.5 * np.log(2 * np.pi), axis=-1)
+
+  def sample(self, seed=0):
+    rng = np.random.default_rng(_native.seed_to_u64(seed))
+    return self.loc + self.scale * rng.standard_normal(self.loc.shape)
+
+
+def likelihood_model(features, observation_model, params, model_args,
+                     ensemble_dims=2, compute_dtype=None):
+  if observation_model != 'NORMAL':
+    raise NotImplementedError('NB / ZINB likelihood objects are not built yet')
+  features = np.asarray(features, dtype=np.float64)
+  net, eng, lead, loc_all, aux_all = _ensemble_forecast(
+      features, observation_model, params, model_args, ensemble_dims, compute_dtype)
+  torch.cuda.synchronize(eng.device)
+  n_rows = features.shape[0]
+  loc = loc_all.cpu().numpy().reshape(tuple(lead) + (n_rows,))
+  scale = aux_all.cpu().numpy().reshape(tuple(lead) + (3,))[..., 0]
+  eng.close()
+  return EnsembleLikelihood(loc.astype(np.float64), scale.astype(np.float64))

@@ -1,0 +1,210 @@
+/* bnf.h -- C ABI of the MI355X-native BayesNF ensemble engine (libbnf_hip.so).
+ *
+ * The reference (google/bayesnf, /root/reference) has no FFI: its hot path is
+ * reached through three Python calls (src/bayesnf/spatiotemporal.py:400,529,634
+ * -> src/bayesnf/inference.py fit_map:376 / fit_vi:336 / predict_bnf:461) that
+ * trace into one XLA program (`jax.pmap(jax.vmap(...))`, inference.py:577-619,
+ * :727-745, :474-477).  This header is the boundary a maintainer would bind in
+ * place of that XLA program (ctypes stub in INTEGRATION.md); each entry point
+ * cites the reference code it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every pointer marked DEVICE is HBM memory owned by the caller (the Python
+ *     side uses torch-ROCm tensors purely as containers); the library owns only
+ *     the opaque handle and a few HIP events.
+ *   - all work is enqueued on the caller's HIP stream (`stream`, a hipStream_t
+ *     passed as void*; NULL = the default stream).  Nothing synchronises unless
+ *     stated.
+ *   - return value 0 = ok, negative = error; bnf_last_error() returns a
+ *     thread-local message.  Nothing throws across the ABI.
+ *   - one handle per GPU, used from one host thread at a time.
+ *   - there is NO CPU fallback: every compute entry point fails with
+ *     BNF_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef BNF_H_
+#define BNF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BNF_ABI_VERSION 1
+
+/* limits of the static network description */
+#define BNF_MAX_INPUTS   8    /* D  : time + spatial covariates              */
+#define BNF_MAX_GROUPS   12   /* feature groups (inputs, fourier_d, seasonal, interactions) */
+#define BNF_MAX_LAYERS   8    /* hidden layers                                */
+#define BNF_MAX_FREQS    96   /* distinct seasonal frequencies                */
+#define BNF_MAX_INTERACT 16
+
+enum {
+  BNF_OK = 0,
+  BNF_ERR_INVALID = -1,    /* bad argument / unsupported configuration */
+  BNF_ERR_NO_DEVICE = -2,  /* no usable HIP device (no CPU fallback exists) */
+  BNF_ERR_HIP = -3,        /* a HIP runtime call failed */
+  BNF_ERR_STATE = -4       /* call order violated (e.g. train before bind) */
+};
+
+enum { BNF_DTYPE_F32 = 0, BNF_DTYPE_BF16 = 1 };   /* arithmetic of the dense contractions; accumulation is always f32 */
+enum { BNF_OBS_NORMAL = 0, BNF_OBS_NB = 1, BNF_OBS_ZINB = 2 }; /* models.py:30-33 */
+enum { BNF_MODE_MAP = 0, BNF_MODE_VI = 1 };       /* MLE = MAP with prior_weight 0 (spatiotemporal.py:551) */
+
+/* feature-group kinds, order of models.py:242-247 */
+enum { BNF_GROUP_INPUT = 0, BNF_GROUP_FOURIER = 1, BNF_GROUP_SEASONAL = 2, BNF_GROUP_INTERACT = 3 };
+
+/* Static description of the network + run.  Mirrors `model_args`
+ * (spatiotemporal.py:360-370) plus the arguments of ensemble_map / ensemble_vi
+ * (inference.py:510-522, 626-639).  Offsets index the packed per-member
+ * parameter vector whose leaf order is the reference's `params_` tuple
+ * (models.py:95-103 + sorted flax leaves; bayesnf_amd/spec.py). */
+typedef struct bnf_config {
+  int32_t abi_version;      /* BNF_ABI_VERSION */
+  int32_t device;           /* HIP device ordinal */
+  int32_t dtype;            /* BNF_DTYPE_* */
+  int32_t obs_model;        /* BNF_OBS_* */
+  int32_t mode;             /* BNF_MODE_* */
+
+  /* network (models.py:197-273) */
+  int32_t n_inputs;         /* D */
+  int32_t width;            /* W, multiple of 64 */
+  int32_t depth;            /* hidden layers, 1..BNF_MAX_LAYERS */
+  int32_t n_features;       /* F */
+  int32_t n_params;         /* P */
+  int32_t n_groups;
+  int32_t group_kind[BNF_MAX_GROUPS];
+  int32_t group_arg[BNF_MAX_GROUPS];        /* input column for FOURIER */
+  int32_t group_ncols[BNF_MAX_GROUPS];
+  int32_t group_col0[BNF_MAX_GROUPS];
+  int32_t group_scale_off[BNF_MAX_GROUPS];  /* feature_inv_sp_scale{i} */
+  int32_t fourier_degree[BNF_MAX_INPUTS];
+  float   input_scale[BNF_MAX_INPUTS];      /* float32(input_scales) */
+  int32_t n_freqs;
+  float   freq[BNF_MAX_FREQS];              /* make_seasonal_frequencies, float32 */
+  float   harmonic[BNF_MAX_FREQS];
+  int32_t n_interact;
+  int32_t interact[BNF_MAX_INTERACT][2];
+  int32_t off_log_noise_scale, off_shape, off_inflated;   /* params[0..2] */
+  int32_t off_bias[BNF_MAX_LAYERS + 1];     /* Dense_l/bias ; [depth] = output layer */
+  int32_t off_kernel[BNF_MAX_LAYERS + 1];   /* Dense_l/kernel (in,out) row-major */
+  int32_t off_layer_scale[BNF_MAX_LAYERS];  /* inv_sp_layer_scale{l} */
+  int32_t off_output_scale;
+  int32_t off_lsa;                          /* log_scale_adjustment (D) */
+  int32_t off_act_weight;                   /* logit_activation_weight */
+
+  /* run (inference.py:510-522 / 626-639) */
+  int64_t n_rows;           /* N training rows held in X / y */
+  int64_t batch;            /* B rows per step (== N: full batch, no shuffling) */
+  int32_t members;          /* ensemble members on THIS device */
+  int64_t member_offset;    /* global id of local member 0: random streams are keyed
+                               by the global id, so results do not depend on sharding */
+  int32_t vi_samples;       /* S = sample_size_divergence (VI), else 1 */
+  int32_t forward_only;     /* 1: handle is used for bnf_forward / quantiles only
+                               (no backward buffers are carved, bnf_train refuses) */
+  float   learning_rate;
+  float   prior_weight;     /* 1 MAP, 0 MLE (inference.py:561-569) */
+  float   kl_weight;        /* VI (inference.py:689-702) */
+  uint64_t seed;
+} bnf_config;
+
+typedef struct bnf_handle bnf_handle;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+int bnf_abi_version(void);
+const char* bnf_last_error(void);
+
+/* Validates cfg, selects the device, precomputes launch geometry. */
+int bnf_create(const bnf_config* cfg, bnf_handle** out);
+void bnf_destroy(bnf_handle* h);
+
+/* Sizes (bytes) of the caller-provided device buffers. */
+size_t bnf_workspace_bytes(const bnf_handle* h);  /* activations, gradients, packed weights */
+size_t bnf_state_bytes(const bnf_handle* h);      /* optimiser state: MAP 2*E*P f32 (m,v); VI 4*E*P */
+size_t bnf_param_bytes(const bnf_handle* h);      /* MAP E*P f32 ; VI 2*E*P (mu then rho) */
+
+/* Attach device buffers.  X: (N, D) f32 row-major, y: (N,) f32 (replicated
+ * closed-over constants of ensemble_map, inference.py:553-554).  Zeroes the
+ * workspace and precomputes the seasonal feature table (models.py:62-76; the
+ * features of the raw time index are data-constant).  */
+int bnf_bind(bnf_handle* h, void* params /*DEVICE*/, void* opt_state /*DEVICE*/,
+             void* workspace /*DEVICE*/, const float* X /*DEVICE*/,
+             const float* y /*DEVICE*/, void* stream);
+
+/* ---- training -------------------------------------------------------------- */
+/* Initial values (inference.py:399-427 MAP/MLE ; :203-231 VI): Dense kernels ~
+ * TruncatedNormal(0,1,[-2,2]) from the counter RNG keyed by (seed, global member,
+ * index); log_noise_scale = log_noise_init (MAP: log(nanstd(y)/2), VI: 0);
+ * everything else 0; VI rho = softplus^-1(0.3).  Resets optimiser state + step. */
+int bnf_init_params(bnf_handle* h, float log_noise_init);
+
+/* ensemble_map._run / tfp.vi.fit_surrogate_posterior_stateless (inference.py:
+ * 577-619 / 727-738): `num_epochs` x (N // B) Adam steps for every local member,
+ * enqueued back to back with no host round trip.  losses: DEVICE (members,
+ * num_epochs) f32, receives the per-epoch mean of the pre-update step losses
+ * (inference.py:614); for VI one "epoch" is one step and the value is already
+ * multiplied by kl_weight (inference.py:758).  `epoch0` = index of the first
+ * epoch (continuation of an earlier call; keys the shuffles). */
+int bnf_train(bnf_handle* h, int64_t epoch0, int64_t num_epochs, float* losses /*DEVICE*/);
+
+/* VI only: draw `n_draws` parameter vectors per member from the fitted
+ * surrogate (inference.py:741-745).  out: DEVICE (n_draws, members, P) f32. */
+int bnf_vi_posterior_draws(bnf_handle* h, int32_t n_draws, float* out /*DEVICE*/);
+
+/* ---- prediction ------------------------------------------------------------ */
+/* forecast_inner over all members (inference.py:103-126,129-200): theta is
+ * DEVICE (n_members, P) f32 (any count; processed in chunks), Xnew DEVICE
+ * (n_rows, D) f32.  loc: DEVICE (n_members, n_rows) f32 = network output;
+ * aux: DEVICE (n_members, 3) f32 = {noise scale 0.01+exp(lns), softplus(shape),
+ * sigmoid(inflated_loc_probs)}.  Does not touch the training state. */
+int bnf_forward(bnf_handle* h, const float* theta, int64_t n_members,
+                const float* Xnew, int64_t n_rows, float* loc, float* aux);
+
+/* Quantiles of the equal-weight mixture of Normals over members, per row
+ * (inference.py:42-100).  means DEVICE (n_members, n_rows), scales DEVICE
+ * (n_members,), q HOST (n_q,), out DEVICE (n_q, n_rows).  approximate=0:
+ * Chandrupatla root of mean_e Phi((x-mu_e)/sigma_e) - q on
+ * [min mu - 5 max sigma, max mu + 5 max sigma], value tolerance 1e-5, <= 60
+ * iterations; approximate=1: moment-matched Normal. */
+int bnf_normal_mixture_quantiles(bnf_handle* h, const float* means, const float* scales,
+                                 int64_t n_members, int64_t n_rows, const float* q,
+                                 int32_t n_q, int32_t approximate, float* out);
+
+/* ---- introspection used by tests and bench.py ------------------------------ */
+/* One forward+backward of every local member on batch `step` of `epoch` WITHOUT
+ * the optimiser update: grads DEVICE (members*S, P) f32 receives d(step loss)/d
+ * theta of the likelihood part + prior part exactly as Adam would consume it;
+ * loss DEVICE (members*S,) f32 the step loss.  theta_eff may be NULL (use the
+ * bound params; VI: the z samples of that step). */
+int bnf_debug_loss_and_grad(bnf_handle* h, int64_t epoch, int64_t step,
+                            float* grads, float* loss);
+/* Row ids the engine uses for (epoch, step): out DEVICE (members, B) int32
+ * (MAP: per-member shuffle, inference.py:593-597; VI: one shared batch,
+ * :704-709; full batch: 0..N-1). */
+int bnf_debug_row_index(bnf_handle* h, int64_t epoch, int64_t step, int32_t* out);
+/* VI noise of a step: out DEVICE (members, S, P) f32. */
+int bnf_debug_vi_eps(bnf_handle* h, int64_t step, float* out);
+/* Copy of an internal activation buffer, as f32: what = 0 features H0 (E',B,F),
+ * 1+l hidden output H_{l+1} (E',B,W), 100+l pre-activation A_l (E',B,W),
+ * 200 network output (E',B). Valid after bnf_debug_loss_and_grad. */
+int bnf_debug_activation(bnf_handle* h, int32_t what, float* out);
+/* Raw C = A * Bt^T of the dense-contraction core (A (M,K), Bt (N,K), K a multiple
+ * of 64, dtype = handle dtype, inputs given as f32 and converted) -> C (M,N) f32. */
+int bnf_debug_gemm_nt(bnf_handle* h, const float* A, const float* Bt, int32_t M,
+                      int32_t N, int32_t K, float* C);
+
+/* Per-kernel HIP-event timing: enable, run bnf_train, synchronise, then read.
+ * names/avg_ms/calls arrays of length *n (in: capacity, out: used). */
+int bnf_profile_enable(bnf_handle* h, int32_t on);
+int bnf_profile_read(bnf_handle* h, int32_t* n, const char** names, double* avg_ms,
+                     int64_t* calls);
+/* Algorithmic FLOPs of one launch of kernel `name` for the bound configuration
+ * (DESIGN.md section 4), 0 for non-contraction kernels. */
+double bnf_kernel_flops(const bnf_handle* h, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BNF_H_ */
