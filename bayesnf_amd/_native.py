@@ -107,7 +107,7 @@ def load():
   lib.bnf_debug_vi_eps.argtypes = [vp, i64, vp]
   lib.bnf_debug_activation.argtypes = [vp, i32, vp]
   lib.bnf_debug_gemm_nt.argtypes = [vp, vp, vp, i32, i32, i32, vp]
-  lib.bnf_profile_enable.argtypes = [vp, i32]
+  lib.bnf_profile_enable.argtypes = [vp, C.c_char_p]
   lib.bnf_profile_read.argtypes = [
       vp, C.POINTER(i32), C.POINTER(C.c_char_p), C.POINTER(C.c_double),
       C.POINTER(i64)]

@@ -96,7 +96,7 @@ struct bnf_handle {
   uint8_t* is_matrix = nullptr;
   size_t ws_bytes = 0;
   // profiling
-  bool prof = false;
+  uint32_t prof = 0;   // bit k: bracket launches of kernel id k with HIP events
   std::vector<TimedLaunch> timed;
   std::vector<hipEvent_t> event_pool;
   size_t pool_used = 0;
@@ -151,8 +151,9 @@ struct LaunchScope {
   bnf_handle* h;
   int kid;
   hipEvent_t t0 = nullptr, t1 = nullptr;
-  LaunchScope(bnf_handle* h_, int kid_) : h(h_), kid(kid_) {
-    if (!h->prof) return;
+  bool on;
+  LaunchScope(bnf_handle* h_, int kid_) : h(h_), kid(kid_), on(((h_->prof >> kid_) & 1u) != 0) {
+    if (!on) return;
     auto get = [&]() {
       if (h->pool_used == h->event_pool.size()) {
         hipEvent_t ev;
@@ -166,7 +167,7 @@ struct LaunchScope {
     hipEventRecord(t0, h->stream);
   }
   ~LaunchScope() {
-    if (!h->prof) return;
+    if (!on) return;
     hipEventRecord(t1, h->stream);
     h->timed.push_back({kid, t0, t1});
   }
@@ -838,14 +839,23 @@ int bnf_debug_gemm_nt(bnf_handle* h, const float* A, const float* Bt, int32_t M,
   return BNF_OK;
 }
 
-int bnf_profile_enable(bnf_handle* h, int32_t on) {
+int bnf_profile_enable(bnf_handle* h, const char* kernel) {
   if (!h) return fail(BNF_ERR_INVALID, "null");
-  if (on) {
-    for (int k = 0; k < KID_COUNT; ++k) { h->acc_ms[k] = 0; h->acc_calls[k] = 0; }
-  } else if (h->prof) {
-    drain_timers(h);
+  if (h->prof) drain_timers(h);
+  if (!kernel) {
+    h->prof = 0;
+    return BNF_OK;
   }
-  h->prof = on != 0;
+  uint32_t mask = 0;
+  if (!strcmp(kernel, "*")) {
+    mask = (1u << KID_COUNT) - 1u;
+  } else {
+    for (int k = 0; k < KID_COUNT; ++k)
+      if (!strcmp(kernel, kKernelNames[k])) mask = 1u << k;
+    if (!mask) return fail(BNF_ERR_INVALID, "unknown kernel '%s'", kernel);
+  }
+  for (int k = 0; k < KID_COUNT; ++k) { h->acc_ms[k] = 0; h->acc_calls[k] = 0; }
+  h->prof = mask;
   return BNF_OK;
 }
 

@@ -216,8 +216,10 @@ class Engine:
     torch.cuda.synchronize(self.device)
     return Cout.cpu().numpy()
 
-  def profile(self, on: bool):
-    _native.check(self.lib.bnf_profile_enable(self.handle, 1 if on else 0), 'bnf_profile_enable')
+  def profile(self, kernel):
+    """kernel: '*' (all), a kernel name, or None (off)."""
+    arg = None if kernel is None else str(kernel).encode()
+    _native.check(self.lib.bnf_profile_enable(self.handle, arg), 'bnf_profile_enable')
 
   def profile_read(self) -> dict:
     cap = 32

@@ -195,9 +195,12 @@ int bnf_debug_activation(bnf_handle* h, int32_t what, float* out);
 int bnf_debug_gemm_nt(bnf_handle* h, const float* A, const float* Bt, int32_t M,
                       int32_t N, int32_t K, float* C);
 
-/* Per-kernel HIP-event timing: enable, run bnf_train, synchronise, then read.
- * names/avg_ms/calls arrays of length *n (in: capacity, out: used). */
-int bnf_profile_enable(bnf_handle* h, int32_t on);
+/* Per-kernel HIP-event timing on the handle's stream.  kernel = "*" brackets
+ * every launch with an event pair, a kernel name (as reported by
+ * bnf_profile_read, e.g. "gemm_fwd") only that kernel, NULL switches it off.
+ * Enable, run bnf_train, then read (read synchronises on the recorded events).
+ * names/avg_ms/calls: arrays of length *n (in: capacity, out: used). */
+int bnf_profile_enable(bnf_handle* h, const char* kernel);
 int bnf_profile_read(bnf_handle* h, int32_t* n, const char** names, double* avg_ms,
                      int64_t* calls);
 /* Algorithmic FLOPs of one launch of kernel `name` for the bound configuration

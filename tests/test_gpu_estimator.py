@@ -1,0 +1,86 @@
+"""End-to-end through the public estimator API on the GPU, including the
+reference's own fixture (KAT K1-K4 of SURVEY.md, now with the HIP engine)."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from bayesnf_amd import BayesianNeuralFieldMAP, BayesianNeuralFieldMLE, BayesianNeuralFieldVI
+from oracle import bnf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MODEL = dict(width=256, depth=2, seasonality_periods=np.asarray([4.0, 52.1775]),
+             num_seasonal_harmonics=np.asarray([2.0, 10]), observation_model='NORMAL',
+             feature_cols=['datetime', 'latitude', 'longitude'], target_col='chickenpox',
+             timetype='index', freq='W', standardize=['latitude', 'longitude'])
+
+
+def _train_frame(golden_dir):
+  return pd.read_csv(os.path.join(golden_dir, 'chickenpox.8.train.csv'), index_col=0,
+                     parse_dates=['datetime'])
+
+
+@pytest.mark.parametrize('cls,gold_name,gold_hw', [
+    (BayesianNeuralFieldMAP, 'bnf-map.chickenpox.8.mini.pred.csv', 37.9523),
+    (BayesianNeuralFieldMLE, 'bnf-mle.chickenpox.8.mini.pred.csv', 37.9533)])
+def test_chickenpox_mini_map_mle(golden_dir, cls, gold_name, gold_hw):
+  df = _train_frame(golden_dir)
+  gold = pd.read_csv(os.path.join(golden_dir, gold_name), index_col=0).iloc[:100]
+  est = cls(**MODEL).fit(df, seed=0, ensemble_size=4, num_epochs=5, learning_rate=0.005)
+  assert est.losses_.shape == (1, 4, 5) and np.all(np.diff(est.losses_, axis=-1) < 0)
+  assert len(est.params_) == 19 and est.params_.var4.shape == (1, 4, 57, 256)
+  assert est.params_[0].shape == (1, 4) and est.params_._fields[0] == 'var0'
+  means, qs = est.predict(df, quantiles=(0.5, 0.025, 0.975))
+  assert means.shape == (1, 4, 100) and len(qs) == 3 and qs[0].shape == (100,)
+  hw = ((qs[2] - qs[1]) / 2).mean()
+  np.testing.assert_allclose(hw, gold_hw, rtol=2e-4)
+  yhat = means.mean(axis=(0, 1))
+  assert 0.5 * gold.yhat.mean() < yhat.mean() < 1.6 * gold.yhat.mean()
+  # the engine's own parameters, pushed through the oracle, give the same prediction
+  from bayesnf_amd.spec import NetSpec
+  X = est.data_handler.get_test(df)
+  args = est._model_args(X.shape)
+  model = O.Model(**{k: args[k] for k in ('width', 'depth', 'input_scales', 'fourier_degrees',
+                                          'interactions', 'seasonality_periods',
+                                          'num_seasonal_harmonics')})
+  net = NetSpec(**args)
+  theta = net.pack(list(est.params_))[0]
+  mu_o, sd_o = O.predict_normal(model, theta, X.astype(np.float32).astype(np.float64))
+  np.testing.assert_allclose(means[0], mu_o, rtol=2e-3, atol=2e-4)
+  for i, q in enumerate((0.5, 0.025, 0.975)):
+    np.testing.assert_allclose(O.mixture_cdf(mu_o, sd_o, qs[i]), q, atol=1e-4)
+  m2, q2 = est.predict(df, quantiles=(0.9,), approximate_quantiles=True)
+  np.testing.assert_allclose(q2[0], O.approximate_normal_quantile(mu_o, sd_o, 0.9), rtol=1e-3)
+  lik = est.likelihood_model(df)
+  assert lik.mean().shape == (1, 4, 100) and lik.log_prob(df['chickenpox'].values).shape == (1, 4)
+
+
+def test_chickenpox_mini_vi(golden_dir):
+  df = _train_frame(golden_dir)
+  gold = pd.read_csv(os.path.join(golden_dir, 'bnf-vi.chickenpox.8.mini.pred.csv'),
+                     index_col=0).iloc[:100]
+  hw_gold = ((gold.yhat_upper - gold.yhat_lower) / 2).mean()
+  hws = []
+  for seed in range(4):
+    est = BayesianNeuralFieldVI(**MODEL).fit(
+        df, seed=seed, ensemble_size=1, num_epochs=2, learning_rate=0.01, kl_weight=0.1,
+        sample_size_divergence=5, sample_size_posterior=30)
+    assert est.losses_.shape == (1, 1, 2)
+    assert est.params_.var4.shape == (1, 30, 1, 57, 256)
+    means, qs = est.predict(df, quantiles=(0.5, 0.025, 0.975))
+    assert means.shape == (1, 30, 1, 100)
+    hws.append(((qs[2] - qs[1]) / 2).mean())
+  assert min(hws) - 0.3 < hw_gold < max(hws) + 0.3, (hws, hw_gold)
+
+
+def test_minibatch_and_splits_api(golden_dir):
+  df = _train_frame(golden_dir)
+  est = BayesianNeuralFieldMAP(**{**MODEL, 'width': 64}).fit(
+      df, seed=[0, 42], ensemble_size=4, num_epochs=3, batch_size=32, num_splits=2)
+  assert est.losses_.shape == (1, 4, 3) and est.params_.var6.shape == (1, 4, 64, 64)
+  # the two splits use different seeds -> different members
+  assert not np.allclose(est.params_.var4[0, 0], est.params_.var4[0, 2])
+  with pytest.raises(ValueError):
+    BayesianNeuralFieldMAP(**MODEL).fit(df, seed=0, ensemble_size=0, num_epochs=1)

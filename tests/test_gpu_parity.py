@@ -1,0 +1,223 @@
+"""Parity of the HIP engine (through the C ABI) against the CPU oracle.
+
+Tolerances (fp32 engine vs float64 oracle that uses the reference's float32
+trig arguments): the contraction is exact-f32 MFMA, transcendental functions are
+ocml's (<= 2 ulp), reductions use f32 atomics, and the Fourier features amplify
+a 1-ulp difference in the scaled input by up to 2 pi 2^4 -> feature errors up to
+~2e-5 absolute.  Stated bars:  features 5e-5 abs, activations / output 2e-4 rel,
+loss 2e-5 rel, gradients 5e-4 of the leaf's max, parameters after 30 full-batch
+Adam steps 2e-3 rel, quantile CDF residual 2e-5.  bf16 engine: statistical.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bnf_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(net, X, y, **kw):
+  from bayesnf_amd.engine import Engine
+  return Engine(net, X=X, y=y, **kw)
+
+
+# --------------------------------------------------------------------------- GEMM core
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(128, 128, 64), (300, 200, 128), (57, 512, 320), (1000, 64, 64)])
+def test_contraction_core(dtype, shape):
+  M, N, K = shape
+  net, model, X, y = util.make_problem(n_rows=8, width=64, depth=1)
+  eng = _engine(net, X, y, members=1, compute_dtype=dtype)
+  rng = np.random.default_rng(M + N)
+  A = rng.standard_normal((M, K)).astype(np.float32)
+  Bt = rng.standard_normal((N, K)).astype(np.float32)   # asymmetric on purpose
+  Cd = eng.debug_gemm_nt(A, Bt)
+  if dtype == 'bf16':
+    A = torch.tensor(A).bfloat16().float().numpy()
+    Bt = torch.tensor(Bt).bfloat16().float().numpy()
+  ref = A.astype(np.float64) @ Bt.astype(np.float64).T
+  assert util.rel_err(Cd, ref) < 2e-6, util.rel_err(Cd, ref)
+  eng.close()
+
+
+# --------------------------------------------------------------------------- forward / grads
+@pytest.mark.parametrize('depth,width,n_rows', [(2, 64, 300), (1, 128, 130), (3, 192, 257)])
+def test_forward_and_grad_fp32(depth, width, n_rows):
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth)
+  E = 3
+  theta = util.random_theta(model, E)
+  for pw in (1.0, 0.0):
+    eng = _engine(net, X, y, members=E, prior_weight=pw, compute_dtype='fp32')
+    eng.set_params(theta)
+    loss_d, g_d = eng.debug_loss_and_grad()
+    out_o, ch = O.forward(model, theta, X, keep=True)
+    loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows, prior_weight=pw)
+    H0 = eng.debug_activation(0)
+    assert np.max(np.abs(H0 - ch['Hs'][0])) < 5e-5
+    for l in range(depth):
+      assert util.rel_err(eng.debug_activation(100 + l), ch['As'][l]) < 2e-4, l
+      assert util.rel_err(eng.debug_activation(1 + l), ch['Hs'][l + 1]) < 2e-4, l
+    assert util.rel_err(eng.debug_activation(200), out_o) < 2e-4
+    np.testing.assert_allclose(loss_d, loss_o, rtol=2e-5)
+    errs = util.per_leaf_rel_err(model, g_d, g_o)
+    bad = {k: v for k, v in errs.items() if v > 5e-4}
+    assert not bad, bad
+    eng.close()
+
+
+def test_train_full_batch_fp32():
+  n_rows, E, steps = 200, 4, 30
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=2)
+  eng = _engine(net, X, y, members=E, seed=11, learning_rate=0.005, compute_dtype='fp32')
+  eng.init_params(float(np.log(np.nanstd(y) / 2)))
+  theta0 = eng.get_params().astype(np.float64)
+  mm = model.matrix_mask()
+  # init: kernels ~ TN(0,1,[-2,2]); everything else 0 except log_noise_scale
+  assert np.all(np.abs(theta0[:, mm]) <= 2.0) and abs(theta0[:, mm].std() - 0.8796) < 0.03
+  rest = theta0[:, ~mm].copy()
+  rest[:, model.leaf['log_noise_scale'].offset - 0] = 0  # lns sits before any matrix
+  assert np.all(rest == 0)
+  np.testing.assert_allclose(theta0[:, model.leaf['log_noise_scale'].offset],
+                             np.log(np.nanstd(y) / 2), rtol=1e-6)
+  losses = eng.train(0, steps)
+  torch.cuda.synchronize()
+  theta_d = eng.get_params()
+  theta_o, losses_o = O.train_map(model, theta0, X, y, lr=0.005, num_epochs=steps)
+  np.testing.assert_allclose(losses.cpu().numpy(), losses_o, rtol=5e-5)
+  assert util.rel_err(theta_d, theta_o) < 2e-3
+  eng.close()
+
+
+def test_minibatch_shuffle_and_training_fp32():
+  n_rows, B, E, epochs = 333, 100, 3, 2
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=2)
+  eng = _engine(net, X, y, members=E, batch=B, seed=5, member_offset=7, compute_dtype='fp32')
+  eng.init_params(0.3)
+  theta0 = eng.get_params().astype(np.float64)
+  steps = n_rows // B
+  idx = {}
+  for ep in range(epochs):
+    rows = np.concatenate([eng.debug_row_index(ep, s) for s in range(steps)], axis=1)
+    assert rows.shape == (E, steps * B)
+    for e in range(E):  # a prefix of a permutation: no repeats, all in range
+      assert len(set(rows[e].tolist())) == steps * B and rows[e].min() >= 0 and rows[e].max() < n_rows
+    assert not np.array_equal(rows[0], rows[1])            # per-member shuffles differ
+    idx[ep] = rows
+  assert not np.array_equal(idx[0], idx[1])                # and change every epoch
+  losses = eng.train(0, epochs)
+  torch.cuda.synchronize()
+  theta_o, losses_o = O.train_map(model, theta0, X, y, lr=0.005, num_epochs=epochs, batch_size=B,
+                                  row_index_fn=lambda ep: idx[ep])
+  np.testing.assert_allclose(losses.cpu().numpy(), losses_o, rtol=1e-4)
+  assert util.rel_err(eng.get_params(), theta_o) < 1e-3
+  # shard invariance: the same global members on a differently placed shard
+  eng2 = _engine(net, X, y, members=1, batch=B, seed=5, member_offset=8, compute_dtype='fp32')
+  eng2.init_params(0.3)
+  np.testing.assert_array_equal(eng2.get_params()[0], theta0[1].astype(np.float32))
+  np.testing.assert_array_equal(eng2.debug_row_index(1, 2)[0], eng.debug_row_index(1, 2)[1])
+  eng.close(); eng2.close()
+
+
+# --------------------------------------------------------------------------- VI
+def test_vi_step_and_training_fp32():
+  n_rows, E, S = 150, 2, 3
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=2)
+  eng = _engine(net, X, y, mode='vi', members=E, vi_samples=S, kl_weight=0.2, seed=3,
+                learning_rate=0.01, compute_dtype='fp32')
+  eng.init_params(0.0)
+  p0 = eng.get_params().astype(np.float64)
+  mu0, rho0 = p0[0], p0[1]
+  np.testing.assert_allclose(rho0, np.log(np.expm1(0.3)), rtol=1e-6)
+  eps0 = eng.debug_vi_eps(0)
+  assert eps0.shape == (E, S, model.P)
+  assert abs(eps0.mean()) < 0.01 and abs(eps0.std() - 1) < 0.01
+  assert abs(np.corrcoef(eps0[0, 0], eps0[0, 1])[0, 1]) < 0.02
+  loss_d, g_d = eng.debug_loss_and_grad(0, 0)
+  loss_o, gmu_o, grho_o = O.vi_loss_and_grad(model, mu0, rho0, eps0, X, y, n_rows, 0.2)
+  np.testing.assert_allclose(loss_d, loss_o * 0.2, rtol=5e-5)
+  bad = {k: v for k, v in util.per_leaf_rel_err(model, g_d[0], gmu_o).items() if v > 5e-4}
+  assert not bad, ('gmu', bad)
+  bad = {k: v for k, v in util.per_leaf_rel_err(model, g_d[1], grho_o).items() if v > 5e-4}
+  assert not bad, ('grho', bad)
+  steps = 5
+  eps = {s: eng.debug_vi_eps(s) for s in range(steps)}
+  losses = eng.train(0, steps)
+  torch.cuda.synchronize()
+  mu_o, rho_o, losses_o = O.train_vi(model, mu0, rho0, X, y, lr=0.01, num_steps=steps,
+                                     sample_size=S, kl_weight=0.2, eps_fn=lambda s: eps[s])
+  np.testing.assert_allclose(losses.cpu().numpy(), losses_o, rtol=2e-4)
+  p = eng.get_params()
+  assert util.rel_err(p[0], mu_o) < 1e-3 and util.rel_err(p[1], rho_o) < 1e-3
+  draws = eng.vi_posterior_draws(7).cpu().numpy()
+  assert draws.shape == (7, E, model.P)
+  zs = (draws - p[0][None]) / O.vi_sigma(p[1].astype(np.float64))[None]
+  assert abs(zs.mean()) < 0.01 and abs(zs.std() - 1) < 0.01
+  eng.close()
+
+
+def test_vi_minibatch_shares_one_batch():
+  n_rows, B = 200, 64
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=1)
+  eng = _engine(net, X, y, mode='vi', members=3, vi_samples=2, kl_weight=0.1, batch=B, seed=9,
+                compute_dtype='fp32')
+  eng.init_params(0.0)
+  p0 = eng.get_params().astype(np.float64)
+  r0, r1 = eng.debug_row_index(0, 0), eng.debug_row_index(0, 1)
+  assert np.array_equal(r0[0], r0[1]) and np.array_equal(r0[0], r0[2])   # inference.py:704-709
+  assert not np.array_equal(r0[0], r1[0]) and len(set(r0[0].tolist())) == B
+  eps = eng.debug_vi_eps(1)
+  loss_d, g_d = eng.debug_loss_and_grad(0, 1)
+  rows = r1[0]
+  loss_o, gmu_o, grho_o = O.vi_loss_and_grad(model, p0[0], p0[1], eps, X[rows], y[rows], n_rows, 0.1)
+  np.testing.assert_allclose(loss_d, loss_o * 0.1, rtol=5e-5)
+  assert max(util.per_leaf_rel_err(model, g_d[0], gmu_o).values()) < 5e-4
+  eng.close()
+
+
+# --------------------------------------------------------------------------- predict
+def test_forward_only_and_quantiles():
+  from bayesnf_amd.engine import Engine
+  net, model, X, y = util.make_problem(n_rows=700, width=64, depth=2)
+  M = 11
+  theta = util.random_theta(model, M, scale=0.4)
+  eng = Engine(net, members=4, forward_only=True, row_capacity=256, compute_dtype='fp32')
+  th_d = torch.tensor(theta, dtype=torch.float32, device=eng.device)
+  X_d = torch.tensor(X, dtype=torch.float32, device=eng.device)
+  loc, aux = eng.forward(th_d, X_d)          # 3 member chunks x 3 row chunks
+  torch.cuda.synchronize()
+  mu_o, sd_o = O.predict_normal(model, theta, X)
+  assert util.rel_err(loc.cpu().numpy(), mu_o) < 2e-4
+  np.testing.assert_allclose(aux[:, 0].cpu().numpy(), sd_o, rtol=1e-5)
+  qs = (0.5, 0.025, 0.975)
+  q_d = eng.normal_mixture_quantiles(loc, aux[:, 0], qs).cpu().numpy()
+  for i, q in enumerate(qs):
+    np.testing.assert_allclose(O.mixture_cdf(mu_o, sd_o, q_d[i]), q, atol=2e-5)
+    np.testing.assert_allclose(q_d[i], O.normal_quantile_via_root(mu_o, sd_o, q), atol=2e-3)
+  qa = eng.normal_mixture_quantiles(loc, aux[:, 0], qs, approximate=True).cpu().numpy()
+  for i, q in enumerate(qs):
+    np.testing.assert_allclose(qa[i], O.approximate_normal_quantile(mu_o, sd_o, q), rtol=1e-4, atol=1e-4)
+  eng.close()
+
+
+# --------------------------------------------------------------------------- bf16
+def test_bf16_tracks_fp32():
+  n_rows, E, steps = 512, 4, 40
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=128, depth=2)
+  res = {}
+  for dt in ('fp32', 'bf16'):
+    eng = _engine(net, X, y, members=E, seed=2, compute_dtype=dt)
+    eng.init_params(float(np.log(np.nanstd(y) / 2)))
+    if dt == 'fp32':
+      theta0 = eng.get_params()
+    else:
+      np.testing.assert_array_equal(eng.get_params(), theta0)   # init does not depend on dtype
+    l0, g0 = eng.debug_loss_and_grad()
+    losses = eng.train(0, steps).cpu().numpy()
+    res[dt] = (l0, g0, losses, eng.get_params())
+    eng.close()
+  np.testing.assert_allclose(res['bf16'][0], res['fp32'][0], rtol=2e-3)
+  assert util.rel_err(res['bf16'][1], res['fp32'][1]) < 0.05
+  np.testing.assert_allclose(res['bf16'][2][:, -1], res['fp32'][2][:, -1], rtol=1e-2)
+  assert np.all(res['bf16'][2][:, -1] < res['bf16'][2][:, 0])
