@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -49,11 +50,11 @@ static int fail(int code, const char* fmt, ...) {
 // kernel ids for the event timer
 // ---------------------------------------------------------------------------
 enum KernelId {
-  KID_PACK = 0, KID_FEAT, KID_FWD0, KID_FWD, KID_OUT, KID_DGRAD, KID_DGRAD0, KID_FEATBWD,
-  KID_WGRAD0, KID_WGRAD, KID_ADAM, KID_VISAMPLE, KID_VIADAM, KID_COUNT
+  KID_PACK = 0, KID_FEAT, KID_FWD0, KID_FWD, KID_ROWLOSS, KID_LASTBWD, KID_DGRAD, KID_DGRAD0,
+  KID_FEATBWD, KID_WGRAD0, KID_WGRAD, KID_ADAM, KID_VISAMPLE, KID_VIADAM, KID_COUNT
 };
 static const char* kKernelNames[KID_COUNT] = {
-    "pack_weights", "featurize", "gemm_fwd_l0", "gemm_fwd", "out_loss", "gemm_dgrad",
+    "pack_weights", "featurize", "gemm_fwd_l0", "gemm_fwd", "row_loss", "last_bwd", "gemm_dgrad",
     "gemm_dgrad0", "feat_bwd", "gemm_wgrad_l0", "gemm_wgrad", "adam_map", "vi_sample", "vi_adam"};
 
 struct TimedLaunch {
@@ -91,11 +92,13 @@ struct bnf_handle {
   void* Kn[BNF_MAX_LAYERS]; void* Kt[BNF_MAX_LAYERS];
   int64_t pack_batch[BNF_MAX_LAYERS];
   float* dH0 = nullptr; float* out = nullptr; float* ybat = nullptr; float* loss_raw = nullptr;
+  float* vacc = nullptr; float* dv = nullptr;   // output-layer dot accumulator, d loss / d v
   float* qscratch = nullptr;  // quantile partials: 2*1024*2 + 2 floats
   float* dbg_a = nullptr; float* dbg_b = nullptr;  // small debug staging (gmu/grho)
   uint8_t* is_matrix = nullptr;
   size_t ws_bytes = 0;
   // profiling
+  int ablate = 0;      // env BNF_ABLATE, perf experiments only
   uint32_t prof = 0;   // bit k: bracket launches of kernel id k with HIP events
   std::vector<TimedLaunch> timed;
   std::vector<hipEvent_t> event_pool;
@@ -124,8 +127,8 @@ static size_t carve(bnf_handle* h, char* base) {
   h->H0 = take((size_t)Ev * Bp * Fp * es);
   h->H0t = fo ? nullptr : take((size_t)Ev * Fp * Bp * es);
   for (int l = 0; l < h->L; ++l) {
-    h->A[l] = take((size_t)Ev * Bp * W * es);
-    h->H[l] = take((size_t)Ev * Bp * W * es);
+    h->A[l] = take((size_t)Ev * W * Bp * es);                                  // A_l^T (W, Bp)
+    h->H[l] = (l < h->L - 1) ? take((size_t)Ev * Bp * W * es) : nullptr;       // H_{l+1} (Bp, W)
     h->Ht[l] = (!fo && l < h->L - 1) ? take((size_t)Ev * W * Bp * es) : nullptr;
     h->dZ[l] = fo ? nullptr : take((size_t)Ev * Bp * W * es);
     h->dZt[l] = fo ? nullptr : take((size_t)Ev * W * Bp * es);
@@ -134,8 +137,10 @@ static size_t carve(bnf_handle* h, char* base) {
     h->Kn[l] = take((size_t)Ev * npad * W * es);
     h->Kt[l] = take((size_t)Ev * npad * W * es);
   }
-  h->dH0 = fo ? nullptr : (float*)take((size_t)Ev * Bp * Fp * 4);
+  h->dH0 = fo ? nullptr : (float*)take((size_t)Ev * Fp * Bp * 4);            // dH0^T (Fp, Bp)
   h->out = (float*)take((size_t)Ev * Bp * 4);
+  h->vacc = (float*)take((size_t)Ev * Bp * 4);
+  h->dv = fo ? nullptr : (float*)take((size_t)Ev * Bp * 4);
   h->ybat = fo ? nullptr : (float*)take((size_t)Ev * Bp * 4);
   h->loss_raw = (float*)take((size_t)Ev * 4);
   h->qscratch = (float*)take((size_t)(4 * 1024 + 16) * 4);
@@ -201,8 +206,10 @@ static void launch_gemm(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep) {
     attr_set = true;
   }
   const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
+  EpiArgs ep2 = ep;
+  ep2.ablate = h->ablate;
   LaunchScope ls(h, kid);
-  hipLaunchKernelGGL((gemm_nt<T, EPI, TAG>), dim3(blocks), dim3(kThreads), kGemmLds, h->stream, g, ep);
+  hipLaunchKernelGGL((gemm_nt<T, EPI, TAG>), dim3(blocks), dim3(kThreads), kGemmLds, h->stream, g, ep2);
 }
 
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
@@ -222,7 +229,8 @@ static void run_pack(bnf_handle* h, const float* theta, int nmem) {
   }
 }
 
-// featurise + forward contractions for `rows` batch rows of `nmem` (virtual) members
+// featurise + forward contractions for `rows` batch rows of `nmem` (virtual)
+// members; leaves vacc[row] = H_L[row] . k_o for the row-loss kernel.
 template <typename T>
 static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs,
                         const float* X, const float* stab, const float* y, int64_t rows,
@@ -230,13 +238,21 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
   const int64_t Bp = h->Bp;
   {
     LaunchScope ls(h, KID_FEAT);
-    dim3 grid(cdiv(rows, 256), (unsigned)nmem);
-    hipLaunchKernelGGL((k_featurize<T>), grid, dim3(256), 0, h->stream, h->nd, rs, X, stab, y,
-                       theta, (int64_t)h->P, rows, (T*)h->H0, Bp * h->Fp,
+    dim3 grid(cdiv(rows, kFeatRows), (unsigned)nmem);
+    const size_t lds = (size_t)kFeatRows * (h->Fp + 16 / h->es) * h->es;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_featurize<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((k_featurize<T>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, X, stab,
+                       y, theta, (int64_t)h->P, rows, (T*)h->H0, Bp * h->Fp,
                        train ? (T*)h->H0t : (T*)nullptr, (int64_t)h->Fp * Bp, (int32_t)Bp,
                        train ? h->ybat : (float*)nullptr, Bp);
   }
   for (int l = 0; l < h->L; ++l) {
+    const bool last = l == h->L - 1;
     GemmArgs g{};
     g.A = (l == 0) ? h->H0 : h->H[l - 1];
     g.a_ld = (l == 0) ? h->Fp : h->W;
@@ -257,8 +273,11 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
     ep.off_layer_scale = h->nd.off_ls[l];
     ep.off_act_weight = h->nd.off_law;
     ep.out_a = h->A[l];
-    ep.out_h = h->H[l];
-    ep.out_t = (train && l < h->L - 1) ? h->Ht[l] : nullptr;
+    ep.out_h = last ? nullptr : h->H[l];
+    ep.out_t = (train && !last) ? h->Ht[l] : nullptr;
+    ep.vdot = last ? h->vacc : nullptr;
+    ep.vdot_batch = Bp;
+    ep.off_ko = h->nd.off_kernel[h->L];
     ep.act_batch = Bp * h->W;
     ep.actt_batch = (int64_t)h->W * Bp;
     ep.ld = h->W;
@@ -280,17 +299,29 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
   const int64_t Bp = h->Bp;
   const int L = h->L;
   {
-    OutArgs a{};
+    RowLossArgs a{};
     a.theta = theta; a.theta_stride = h->P; a.B = rows;
-    a.H = h->H[L - 1]; a.A = h->A[L - 1]; a.act_batch = Bp * h->W;
-    a.dZ = h->dZ[L - 1]; a.dZt = h->dZt[L - 1]; a.actt_batch = (int64_t)h->W * Bp; a.ldt = (int32_t)Bp;
-    a.ybat = h->ybat; a.ybat_batch = Bp; a.out = h->out; a.out_batch = Bp;
+    a.vacc = h->vacc; a.vacc_batch = Bp; a.ybat = h->ybat;
+    a.out = h->out; a.out_batch = Bp; a.dv = h->dv;
     a.grad = h->grad; a.grad_stride = h->P;
     a.loss = sink.loss; a.loss_stride = sink.stride; a.S = h->S; a.loss_scale = sink.scale;
     a.c = c; a.loss_raw = sink.raw;
-    LaunchScope ls(h, KID_OUT);
-    dim3 grid(cdiv(rows, 32), (unsigned)nmem);
-    hipLaunchKernelGGL((k_out_loss<T, true>), grid, dim3(256), 0, h->stream, h->nd, a);
+    LaunchScope ls(h, KID_ROWLOSS);
+    hipLaunchKernelGGL((k_row_loss<true>), dim3(cdiv(rows, 256), (unsigned)nmem), dim3(256), 0,
+                       h->stream, h->nd, a);
+  }
+  {
+    LastBwdArgs a{};
+    a.theta = theta; a.theta_stride = h->P;
+    a.At = h->A[L - 1]; a.dZ = h->dZ[L - 1]; a.dZt = h->dZt[L - 1];
+    a.act_batch = Bp * h->W; a.actt_batch = (int64_t)h->W * Bp; a.ldt = (int32_t)Bp;
+    a.dv = h->dv; a.dv_batch = Bp; a.grad = h->grad; a.grad_stride = h->P;
+    a.n_row_tiles = (int32_t)((rows + 63) / 64);
+    a.tiles_per_task = 4;
+    const int tasks = (h->W / 64) * ((a.n_row_tiles + a.tiles_per_task - 1) / a.tiles_per_task);
+    LaunchScope ls(h, KID_LASTBWD);
+    hipLaunchKernelGGL((k_last_bwd<T>), dim3(cdiv(tasks, 4), (unsigned)nmem), dim3(256), 0, h->stream,
+                       h->nd, a);
   }
   for (int l = L - 1; l >= 0; --l) {
     // dH_l = dZ_l . K_l^T / sqrt(fan_in_l)
@@ -316,7 +347,7 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
     } else {
       g.N = h->Fp;
       ep.scale = 1.0f / sqrtf((float)h->F);
-      ep.out_f32 = h->dH0; ep.f32_batch = Bp * h->Fp; ep.ld_f32 = h->Fp;
+      ep.out_f32 = h->dH0; ep.f32_batch = (int64_t)h->Fp * Bp; ep.ld_f32 = (int32_t)Bp;
       launch_gemm<T, EPI_DGRAD0, 0>(h, KID_DGRAD0, g, ep);
     }
   }
@@ -325,7 +356,8 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
     dim3 grid(cdiv(rows, 256), (unsigned)nmem);
     const float* X = h->X;
     hipLaunchKernelGGL(k_feat_bwd, grid, dim3(256), 0, h->stream, h->nd, rs, X, h->stab, theta,
-                       (int64_t)h->P, rows, h->dH0, Bp * h->Fp, h->grad, (int64_t)h->P);
+                       (int64_t)h->P, rows, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->grad,
+                       (int64_t)h->P);
   }
   for (int l = 0; l < L; ++l) {
     // dK_l = H_l^T . dZ_l / sqrt(fan_in_l)   (contraction over the batch rows)
@@ -372,7 +404,6 @@ template <typename T>
 static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& sink, bool apply) {
   const RowSrc rs = make_rowsrc(h, epoch, step);
   const int E = h->cfg.members;
-  HIPCHK(hipMemsetAsync(h->grad, 0, (size_t)h->Ev * h->P * 4, h->stream));
   run_pack<T>(h, h->params, E);
   run_forward<T>(h, h->params, E, rs, h->X, h->stab, h->y, h->B, true);
   const float c = (float)((double)h->N / (double)h->B);
@@ -389,8 +420,13 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
   a.apply = apply ? 1 : 0; a.loss_raw = sink.raw;
   {
     LaunchScope ls(h, KID_ADAM);
-    dim3 grid(cdiv(h->P, 256), (unsigned)E);
-    hipLaunchKernelGGL(k_adam_map, grid, dim3(256), 0, h->stream, a);
+    if (h->P % 4 == 0) {
+      hipLaunchKernelGGL((k_adam_map<4>), dim3(cdiv(h->P / 4, 256), (unsigned)E), dim3(256), 0,
+                         h->stream, a);
+    } else {
+      hipLaunchKernelGGL((k_adam_map<1>), dim3(cdiv(h->P, 256), (unsigned)E), dim3(256), 0,
+                         h->stream, a);
+    }
   }
   if (apply) h->adam_t = t;
   return BNF_OK;
@@ -403,7 +439,6 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   const int E = h->cfg.members, S = h->S;
   float* mu = h->params;
   float* rho = h->params + (int64_t)E * h->P;
-  HIPCHK(hipMemsetAsync(h->grad, 0, (size_t)h->Ev * h->P * 4, h->stream));
   {
     LaunchScope ls(h, KID_VISAMPLE);
     dim3 grid(cdiv(h->P, 256), (unsigned)E, (unsigned)S);
@@ -536,6 +571,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
     h->ft.h[j] = cfg->harmonic[j];
   }
   for (int k = 0; k < KID_COUNT; ++k) { h->acc_ms[k] = 0; h->acc_calls[k] = 0; }
+  if (const char* ab = getenv("BNF_ABLATE")) h->ablate = atoi(ab);
   h->ws_bytes = carve(h, nullptr);
   *out = h;
   return BNF_OK;
@@ -674,20 +710,15 @@ int bnf_forward(bnf_handle* h, const float* theta, int64_t n_members, const floa
       if (h->ft.n > 0)
         hipLaunchKernelGGL(k_seasonal_table, dim3(cdiv(rows, 256)), dim3(256), 0, h->stream, Xc, rows,
                            h->nd.D, h->ft, h->stab_pred);
-      OutArgs a{};
+      RowLossArgs a{};
       a.theta = th; a.theta_stride = h->P; a.B = rows;
-      a.H = h->H[h->L - 1]; a.A = h->A[h->L - 1]; a.act_batch = h->Bp * h->W;
+      a.vacc = h->vacc; a.vacc_batch = h->Bp;
       a.out = loc + m0 * n_rows + r0; a.out_batch = n_rows;
       a.S = 1;
-      if (h->bf16) {
-        run_forward<bf16_t>(h, th, nm, rs, Xc, h->stab_pred, nullptr, rows, false);
-        hipLaunchKernelGGL((k_out_loss<bf16_t, false>), dim3(cdiv(rows, 32), (unsigned)nm), dim3(256),
-                           0, h->stream, h->nd, a);
-      } else {
-        run_forward<float>(h, th, nm, rs, Xc, h->stab_pred, nullptr, rows, false);
-        hipLaunchKernelGGL((k_out_loss<float, false>), dim3(cdiv(rows, 32), (unsigned)nm), dim3(256), 0,
-                           h->stream, h->nd, a);
-      }
+      if (h->bf16) run_forward<bf16_t>(h, th, nm, rs, Xc, h->stab_pred, nullptr, rows, false);
+      else run_forward<float>(h, th, nm, rs, Xc, h->stab_pred, nullptr, rows, false);
+      hipLaunchKernelGGL((k_row_loss<false>), dim3(cdiv(rows, 256), (unsigned)nm), dim3(256), 0,
+                         h->stream, h->nd, a);
     }
   }
   if (aux)
@@ -743,6 +774,7 @@ int bnf_debug_loss_and_grad(bnf_handle* h, int64_t epoch, int64_t step, float* g
     rc = h->bf16 ? step_map<bf16_t>(h, epoch, step, sink, false) : step_map<float>(h, epoch, step, sink, false);
     if (rc != BNF_OK) return rc;
     HIPCHK(hipMemcpyAsync(grads, h->grad, (size_t)E * h->P * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->grad, 0, (size_t)h->Ev * h->P * 4, h->stream));
   } else {
     HIPCHK(hipMemsetAsync(loss, 0, (size_t)E * 4, h->stream));
     float* gmu = grads;
@@ -750,6 +782,7 @@ int bnf_debug_loss_and_grad(bnf_handle* h, int64_t epoch, int64_t step, float* g
     rc = h->bf16 ? step_vi<bf16_t>(h, step, loss, 1, false, gmu, grho)
                  : step_vi<float>(h, step, loss, 1, false, gmu, grho);
     if (rc != BNF_OK) return rc;
+    HIPCHK(hipMemsetAsync(h->grad, 0, (size_t)h->Ev * h->P * 4, h->stream));
   }
   HIPCHK(hipGetLastError());
   return BNF_OK;
@@ -781,30 +814,32 @@ int bnf_debug_activation(bnf_handle* h, int32_t what, float* out) {
   HIPCHK(hipSetDevice(h->cfg.device));
   const int64_t B = h->B, Bp = h->Bp;
   const void* src = nullptr;
-  int64_t batch = 0; int ld = 0, cols = 0;
+  int64_t batch = 0; int ld = 0, cols = 0, transposed = 0;
   if (what == 0) { src = h->H0; batch = Bp * h->Fp; ld = h->Fp; cols = h->F; }
-  else if (what >= 1 && what <= h->L) { src = h->H[what - 1]; batch = Bp * h->W; ld = h->W; cols = h->W; }
-  else if (what >= 100 && what < 100 + h->L) { src = h->A[what - 100]; batch = Bp * h->W; ld = h->W; cols = h->W; }
-  else if (what >= 300 && what < 300 + h->L) { src = h->dZ[what - 300]; batch = Bp * h->W; ld = h->W; cols = h->W; }
+  else if (what >= 1 && what < h->L) { src = h->H[what - 1]; batch = Bp * h->W; ld = h->W; cols = h->W; }
+  else if (what >= 100 && what < 100 + h->L) {
+    src = h->A[what - 100]; batch = (int64_t)h->W * Bp; ld = (int)Bp; cols = h->W; transposed = 1;
+  } else if (what >= 300 && what < 300 + h->L) { src = h->dZ[what - 300]; batch = Bp * h->W; ld = h->W; cols = h->W; }
   else if (what == 200) {
     for (int e = 0; e < h->Ev; ++e)
       HIPCHK(hipMemcpyAsync(out + (int64_t)e * B, h->out + (int64_t)e * Bp, (size_t)B * 4,
                             hipMemcpyDeviceToDevice, h->stream));
     return BNF_OK;
-  } else if (what == 400) {  // dH0 (Ev, B, F) f32
+  } else if (what == 400) {  // dH0 (Ev, B, F) f32, stored transposed
     dim3 grid(cdiv(B * h->F, 256), (unsigned)h->Ev);
     hipLaunchKernelGGL((k_to_f32<float>), grid, dim3(256), 0, h->stream, (const float*)h->dH0,
-                       Bp * h->Fp, h->Fp, B, h->F, out);
+                       (int64_t)h->Fp * Bp, (int)Bp, B, h->F, out, 1);
     HIPCHK(hipGetLastError());
     return BNF_OK;
   } else {
-    return fail(BNF_ERR_INVALID, "what=%d", what);
+    return fail(BNF_ERR_INVALID, "what=%d (the last hidden output is never stored)", what);
   }
+  if (!src) return fail(BNF_ERR_STATE, "buffer not allocated on this handle");
   dim3 grid(cdiv(B * cols, 256), (unsigned)h->Ev);
   if (h->bf16)
-    hipLaunchKernelGGL((k_to_f32<bf16_t>), grid, dim3(256), 0, h->stream, (const bf16_t*)src, batch, ld, B, cols, out);
+    hipLaunchKernelGGL((k_to_f32<bf16_t>), grid, dim3(256), 0, h->stream, (const bf16_t*)src, batch, ld, B, cols, out, transposed);
   else
-    hipLaunchKernelGGL((k_to_f32<float>), grid, dim3(256), 0, h->stream, (const float*)src, batch, ld, B, cols, out);
+    hipLaunchKernelGGL((k_to_f32<float>), grid, dim3(256), 0, h->stream, (const float*)src, batch, ld, B, cols, out, transposed);
   HIPCHK(hipGetLastError());
   return BNF_OK;
 }

@@ -26,10 +26,15 @@ struct bf16_t {
   uint16_t bits;
 };
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// round-to-nearest-even conversions; hipcc lowers these casts to v_cvt_pk_bf16_f32
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (no NaN inputs here)
-  return (uint16_t)(u >> 16);
+  return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
   return __builtin_bit_cast(float, ((uint32_t)b) << 16);
@@ -62,9 +67,77 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
 }
 __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
   uint2 v;
-  v.x = (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
-  v.y = (uint32_t)f32_to_bf16_bits(c) | ((uint32_t)f32_to_bf16_bits(d) << 16);
+  v.x = pack_bf16x2(a, b);
+  v.y = pack_bf16x2(c, d);
   *reinterpret_cast<uint2*>(p) = v;
+}
+
+// vector loads / stores of 4 or 8 consecutive elements (p aligned to the vector)
+__device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
+  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&o)[4]) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  o[0] = __builtin_bit_cast(float, v.x << 16); o[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+  o[2] = __builtin_bit_cast(float, v.y << 16); o[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void load8(const float* p, float (&o)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+  o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&o)[8]) {
+  const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+    o[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  store4(p, v[0], v[1], v[2], v[3]);
+  store4(p + 4, v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+  u32x4 w;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+  *reinterpret_cast<u32x4*>(p) = w;
+}
+
+// raw (undecoded) vectors: issue the load early, decode at the point of use so
+// the compiler does not have to wait for the data right after the load
+struct RawF4 { f32x4 v; };
+struct RawF8 { f32x4 a, b; };
+struct RawB4 { uint2 v; };
+struct RawB8 { u32x4 v; };
+template <typename T> struct Raw;
+template <> struct Raw<float> { using R4 = RawF4; using R8 = RawF8; };
+template <> struct Raw<bf16_t> { using R4 = RawB4; using R8 = RawB8; };
+__device__ __forceinline__ RawF4 load_raw4(const float* p) { return {*reinterpret_cast<const f32x4*>(p)}; }
+__device__ __forceinline__ RawB4 load_raw4(const bf16_t* p) { return {*reinterpret_cast<const uint2*>(p)}; }
+__device__ __forceinline__ RawF8 load_raw8(const float* p) {
+  return {*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)};
+}
+__device__ __forceinline__ RawB8 load_raw8(const bf16_t* p) { return {*reinterpret_cast<const u32x4*>(p)}; }
+__device__ __forceinline__ void unpack(const RawF4& r, float (&o)[4]) {
+  o[0] = r.v[0]; o[1] = r.v[1]; o[2] = r.v[2]; o[3] = r.v[3];
+}
+__device__ __forceinline__ void unpack(const RawB4& r, float (&o)[4]) {
+  o[0] = __builtin_bit_cast(float, r.v.x << 16); o[1] = __builtin_bit_cast(float, r.v.x & 0xffff0000u);
+  o[2] = __builtin_bit_cast(float, r.v.y << 16); o[3] = __builtin_bit_cast(float, r.v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack(const RawF8& r, float (&o)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[i] = r.a[i]; o[4 + i] = r.b[i]; }
+}
+__device__ __forceinline__ void unpack(const RawB8& r, float (&o)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = __builtin_bit_cast(float, r.v[i] << 16);
+    o[2 * i + 1] = __builtin_bit_cast(float, r.v[i] & 0xffff0000u);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -131,6 +204,16 @@ __device__ __forceinline__ float act_fwd(float a, float alpha) {
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// Sum over each 32-lane half of the wave with DPP adds (no LDS traffic): the
+// result is valid in lanes 16-31 (sum of lanes 0-31) and 48-63 (lanes 32-63).
+__device__ __forceinline__ float half_wave_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1, 3
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {

@@ -30,7 +30,8 @@ enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_DGRAD0 = 2, EPI_WGRAD = 3, EPI_PLAIN = 4 
 
 constexpr int kBM = 128, kBN = 128, kRowBytes = 128, kThreads = 256;
 constexpr int kStageBytes = (kBM + kBN) * kRowBytes;  // 32 KiB
-constexpr int kGemmLds = 2 * kStageBytes;             // 64 KiB
+// 64 KiB for the double-buffered K loop; the f32 epilogue tile (128 x 132 x 4 B) needs 66 KiB
+constexpr int kGemmLds = 128 * (kBN + 4) * 4;
 
 struct GemmArgs {
   const void* A;  // (M, K) elements of T, leading dim a_ld, member stride a_batch
@@ -47,10 +48,13 @@ struct EpiArgs {
   float scale;  // 1/sqrt(fan_in) folded into the accumulator
   int32_t off_bias, off_layer_scale, off_act_weight;
   // activations: row-major (rows, ld) and transposed (ld, ldt) copies
-  void* out_a;         // FWD: pre-activation A_l
-  void* out_h;         // FWD: H_{l+1} ; DGRAD: dZ_l
-  void* out_t;         // FWD: H_{l+1}^T ; DGRAD: dZ_l^T (may be null)
-  const void* in_a;    // DGRAD: A_l
+  void* out_a;         // FWD: pre-activation A_l^T (transposed only)
+  void* out_h;         // FWD: H_{l+1} row-major (null for the last layer) ; DGRAD: dZ_l
+  void* out_t;         // FWD: H_{l+1}^T (may be null) ; DGRAD: dZ_l^T
+  const void* in_a;    // DGRAD: A_l^T
+  float* vdot;         // FWD (last layer): (members, vdot_batch) += H . k_o (un-normalised)
+  int64_t vdot_batch;
+  int32_t off_ko;      // offset of the output-layer kernel
   int64_t act_batch;   // elements between members, row-major buffers
   int64_t actt_batch;  // elements between members, transposed buffers
   int32_t ld, ldt;
@@ -61,6 +65,9 @@ struct EpiArgs {
   float* out_f32;      // DGRAD0 / PLAIN: (members, M, ld_f32)
   int64_t f32_batch;
   int32_t ld_f32;
+  int32_t ablate;      // perf experiments only (env BNF_ABLATE): 1 no transposed stores,
+                       // 2 no row-major stores, 4 no activation math, 8 no row dot,
+                       // 16 no K loop, 32 no transposed loads
 };
 
 template <typename T>
@@ -118,7 +125,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total) {
 }
 
 template <typename T, int EPI, int TAG>
-__global__ __launch_bounds__(kThreads) void gemm_nt(const GemmArgs g, const EpiArgs ep) {
+__global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const EpiArgs ep) {
   using M_ = Mma<T>;
   constexpr bool FAST = Elem<T>::kFast;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -167,6 +174,26 @@ __global__ __launch_bounds__(kThreads) void gemm_nt(const GemmArgs g, const EpiA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // DGRAD: this lane's 2x2x4 groups of four consecutive rows of A_l^T, fetched
+  // (undecoded) before the K loop so the scattered, HBM-latency loads hide under
+  // the MFMAs.  A_l^T has ldt >= tiles_m * 128 zero-padded columns, so the
+  // 4-row vector is always in bounds.
+  typename Raw<T>::R4 apre[(EPI == EPI_DGRAD) ? 2 : 1][(EPI == EPI_DGRAD) ? 2 : 1][(EPI == EPI_DGRAD) ? 4 : 1];
+  if constexpr (EPI == EPI_DGRAD) {
+    const T* iat = reinterpret_cast<const T*>(ep.in_a) + (int64_t)e * ep.actt_batch;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = min(n0 + wc * 64 + j * 32 + (lane & 31), g.N - 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int mb = m0 + wr * 64 + 4 * (lane >> 5) + i * 32 + 8 * rg;
+          apre[j][i][rg] = load_raw4(iat + (int64_t)n * ep.ldt + mb);
+        }
+    }
+  }
+
   u32x4 ra[4], rb[4];
   auto gload = [&](int kt) {
     const int64_t koff = (int64_t)kt * kRowBytes;
@@ -197,7 +224,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt(const GemmArgs g, const EpiA
     b_swz[i] = (b_row[i] >> 1) & 7;
   }
 
-  if (kt0 < kt1) {
+  if (kt0 < kt1 && !(ep.ablate & 16)) {
     gload(kt0);
     lstore(0);
     __syncthreads();
@@ -227,10 +254,31 @@ __global__ __launch_bounds__(kThreads) void gemm_nt(const GemmArgs g, const EpiA
   // ---- epilogues --------------------------------------------------------------
   // accumulator element (i, j, r): row m = m0 + wr*64 + i*32 + 8*(r>>2) + 4*kg + (r&3)
   //                                col n = n0 + wc*64 + j*32 + frow
+  // A lane therefore owns, per (i, j, r>>2), FOUR CONSECUTIVE ROWS of one column:
+  // transposed (column-major) activations are written / read as 8- or 16-byte
+  // vectors straight from the registers, while row-major tiles are staged through
+  // LDS (free after the K loop) and leave as coalesced 16-byte stores.
   const int mw = m0 + wr * 64 + 4 * kg;
   const int nw = n0 + wc * 64 + frow;
+  constexpr int kEpc = 16 / Elem<T>::kBytes;   // elements per 16-byte chunk
+  constexpr int kPitch = kBN + kEpc;           // LDS tile pitch (elements), 1 chunk of padding
 
-  if constexpr (EPI == EPI_PLAIN || EPI == EPI_DGRAD0) {
+  // cooperative copy of the staged (kBM x kBN) tile of T to a row-major array
+  auto tile_to_global = [&](T* dst, int ld) {
+    const T* tile = reinterpret_cast<const T*>(smem);
+    constexpr int kCpr = kBN / kEpc;  // chunks per row
+#pragma unroll
+    for (int c = 0; c < (kBM * kCpr) / kThreads; ++c) {
+      const int q = tid + c * kThreads;
+      const int row = q / kCpr, cc = q % kCpr;
+      const int m = m0 + row, n = n0 + cc * kEpc;
+      if (m < g.M && n < g.N)
+        *reinterpret_cast<u32x4*>(dst + (int64_t)m * ld + n) =
+            *reinterpret_cast<const u32x4*>(tile + row * kPitch + cc * kEpc);
+    }
+  };
+
+  if constexpr (EPI == EPI_PLAIN) {
     float* out = ep.out_f32 + (int64_t)e * ep.f32_batch;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -242,6 +290,30 @@ __global__ __launch_bounds__(kThreads) void gemm_nt(const GemmArgs g, const EpiA
         for (int r = 0; r < 16; ++r) {
           const int m = mw + i * 32 + 8 * (r >> 2) + (r & 3);
           if (m < g.M) out[(int64_t)m * ep.ld_f32 + n] = acc[i][j][r] * ep.scale;
+        }
+    }
+  } else if constexpr (EPI == EPI_DGRAD0) {
+    // dH0^T (Fp, ldt) f32: column n of the tile is a row of the output
+    float* out = ep.out_f32 + (int64_t)e * ep.f32_batch;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = nw + j * 32;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int mb = mw + i * 32 + 8 * rg;
+          float* p = out + (int64_t)n * ep.ld_f32 + mb;
+          const float s = ep.scale;
+          if (mb + 3 < g.M) {
+            store4(p, acc[i][j][rg * 4] * s, acc[i][j][rg * 4 + 1] * s, acc[i][j][rg * 4 + 2] * s,
+                   acc[i][j][rg * 4 + 3] * s);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (mb + q < g.M) p[q] = acc[i][j][rg * 4 + q] * s;
+          }
         }
     }
   } else if constexpr (EPI == EPI_WGRAD) {
@@ -266,48 +338,78 @@ __global__ __launch_bounds__(kThreads) void gemm_nt(const GemmArgs g, const EpiA
     const float* th = ep.theta + (int64_t)e * ep.theta_stride;
     const float gamma = softplusf(th[ep.off_layer_scale]);
     const float alpha = sigmoidf(th[ep.off_act_weight]);
-    T* oa = reinterpret_cast<T*>(ep.out_a) + (int64_t)e * ep.act_batch;
-    T* oh = reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch;
+    T* oat = reinterpret_cast<T*>(ep.out_a) + (int64_t)e * ep.actt_batch;   // A_l^T (W, ldt)
+    T* oh = ep.out_h ? reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch : nullptr;
     T* ot = ep.out_t ? reinterpret_cast<T*>(ep.out_t) + (int64_t)e * ep.actt_batch : nullptr;
+    float* vd = ep.vdot ? ep.vdot + (int64_t)e * ep.vdot_batch : nullptr;
+    T* tile = reinterpret_cast<T*>(smem);
+    float pdot[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pdot[i][r] = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = nw + j * 32;
       if (n >= g.N) continue;
       const float bias = th[ep.off_bias + n];
+      const float kov = vd ? th[ep.off_ko + n] : 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int mb = mw + i * 32 + 8 * rg;
-          float hv[4];
+          float av[4], hv[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float a = gamma * (acc[i][j][rg * 4 + q] * ep.scale + bias);
-            const float h = act_fwd<FAST>(a, alpha);
-            hv[q] = h;
-            const int m = mb + q;
-            if (m < g.M) {
-              Elem<T>::store(oa + (int64_t)m * ep.ld + n, a);
-              Elem<T>::store(oh + (int64_t)m * ep.ld + n, h);
-            }
+            av[q] = gamma * (acc[i][j][rg * 4 + q] * ep.scale + bias);
+            hv[q] = (ep.ablate & 4) ? av[q] : act_fwd<FAST>(av[q], alpha);
+            pdot[i][rg * 4 + q] += hv[q] * kov;
           }
-          if (ot) {
-            T* p = ot + (int64_t)n * ep.ldt + mb;
-            if (mb + 3 < g.M) store4(p, hv[0], hv[1], hv[2], hv[3]);
-            else
+          if (oh && !(ep.ablate & 2)) {
+            const int lr = wr * 64 + 4 * kg + i * 32 + 8 * rg, lc = wc * 64 + j * 32 + frow;
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
-                if (mb + q < g.M) Elem<T>::store(p + q, hv[q]);
+            for (int q = 0; q < 4; ++q) Elem<T>::store(tile + (lr + q) * kPitch + lc, hv[q]);
+          }
+          T* pa = oat + (int64_t)n * ep.ldt + mb;
+          if (ep.ablate & 1) {
+            asm volatile("" ::"v"(av[0] + av[1] + av[2] + av[3] + hv[0] + hv[1] + hv[2] + hv[3]));
+          } else if (mb + 3 < g.M) {
+            store4(pa, av[0], av[1], av[2], av[3]);
+            if (ot) store4(ot + (int64_t)n * ep.ldt + mb, hv[0], hv[1], hv[2], hv[3]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (mb + q < g.M) {
+                Elem<T>::store(pa + q, av[q]);
+                if (ot) Elem<T>::store(ot + (int64_t)n * ep.ldt + mb + q, hv[q]);
+              }
           }
         }
+    }
+    if (vd && !(ep.ablate & 8)) {
+      // output-layer row dot (models.py:269-273): sum over this tile's columns,
+      // then one atomic per row and wave.
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sacc = half_wave_sum_dpp(pdot[i][r]);
+          const int m = mw + i * 32 + 8 * (r >> 2) + (r & 3);
+          if (frow == 16 && m < g.M) atomicAdd(&vd[m], sacc);
+        }
+    }
+    if (oh && !(ep.ablate & 2)) {
+      __syncthreads();
+      tile_to_global(oh, ep.ld);
     }
   } else if constexpr (EPI == EPI_DGRAD) {
     const float* th = ep.theta + (int64_t)e * ep.theta_stride;
     const float gamma = softplusf(th[ep.off_layer_scale]);
     const float alpha = sigmoidf(th[ep.off_act_weight]);
-    const T* ia = reinterpret_cast<const T*>(ep.in_a) + (int64_t)e * ep.act_batch;
     T* oz = reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch;
-    T* ot = ep.out_t ? reinterpret_cast<T*>(ep.out_t) + (int64_t)e * ep.actt_batch : nullptr;
+    T* ot = reinterpret_cast<T*>(ep.out_t) + (int64_t)e * ep.actt_batch;
+    T* tile = reinterpret_cast<T*>(smem);
     float s_alpha = 0.f, s_gamma = 0.f, colsum[2] = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -318,35 +420,39 @@ __global__ __launch_bounds__(kThreads) void gemm_nt(const GemmArgs g, const EpiA
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int mb = mw + i * 32 + 8 * rg;
-          float zv[4];
+          float av[4], zv[4];
+          const bool full = mb + 3 < g.M;
+          unpack(apre[j][i][rg], av);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int m = mb + q;
-            zv[q] = 0.f;
-            if (m < g.M) {
-              const float a = Elem<T>::load(ia + (int64_t)m * ep.ld + n);
-              const float dh = acc[i][j][rg * 4 + q] * ep.scale;
-              const ActOut o = act_eval<FAST>(a, alpha);
-              s_alpha += dh * o.ediff;
-              const float da = dh * o.dact;
-              s_gamma += da * a;
-              const float dz = gamma * da;
-              colsum[j] += dz;
-              zv[q] = dz;
-              Elem<T>::store(oz + (int64_t)m * ep.ld + n, dz);
-            }
+            const float dh = (mb + q < g.M) ? acc[i][j][rg * 4 + q] * ep.scale : 0.f;
+            ActOut o;
+            if (ep.ablate & 4) { o.h = av[q]; o.dact = 1.f; o.ediff = av[q]; }
+            else o = act_eval<FAST>(av[q], alpha);
+            s_alpha += dh * o.ediff;
+            const float da = dh * o.dact;
+            s_gamma += da * av[q];
+            zv[q] = gamma * da;
+            colsum[j] += zv[q];
           }
-          if (ot) {
-            T* p = ot + (int64_t)n * ep.ldt + mb;
-            if (mb + 3 < g.M) store4(p, zv[0], zv[1], zv[2], zv[3]);
-            else
+          const int lr = wr * 64 + 4 * kg + i * 32 + 8 * rg, lc = wc * 64 + j * 32 + frow;
+          if (!(ep.ablate & 2)) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
-                if (mb + q < g.M) Elem<T>::store(p + q, zv[q]);
+            for (int q = 0; q < 4; ++q) Elem<T>::store(tile + (lr + q) * kPitch + lc, zv[q]);
           }
+          T* pt = ot + (int64_t)n * ep.ldt + mb;
+          if (ep.ablate & 1) asm volatile("" ::"v"(zv[0] + zv[1] + zv[2] + zv[3]));
+          else if (full) store4(pt, zv[0], zv[1], zv[2], zv[3]);
+          else
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (mb + q < g.M) Elem<T>::store(pt + q, zv[q]);
         }
     }
-    // block reduction through LDS (free after the last barrier of the K loop)
+    __syncthreads();
+    if (!(ep.ablate & 2)) tile_to_global(oz, ep.ld);
+    __syncthreads();
+    // block reduction of bias / scale gradients through LDS
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {

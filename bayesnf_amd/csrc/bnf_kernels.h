@@ -75,77 +75,98 @@ __global__ void k_seasonal_table(const float* __restrict__ X, int64_t n_rows, in
 }
 
 // ---------------------------------------------------------------------------
-// featurise forward (models.py:218-252): one thread per batch row.
-//   writes H0 (rows, Fp) and H0^T (Fp, ldt) in T, plus the gathered target.
+// featurise forward (models.py:218-252): one thread per batch row, 128 rows per
+// block.  The row-major tile (rows, Fp) is staged in LDS and leaves as coalesced
+// 16-byte stores; the transposed copy H0^T (Fp, ldt) is written directly (lanes
+// are consecutive rows).  Also gathers the target of the row.
 // ---------------------------------------------------------------------------
+constexpr int kFeatRows = 128;
+
 template <typename T>
-__global__ __launch_bounds__(256) void k_featurize(
+__global__ __launch_bounds__(kFeatRows) void k_featurize(
     NetDev nd, RowSrc rs, const float* __restrict__ X, const float* __restrict__ Stab,
     const float* __restrict__ y, const float* __restrict__ theta, int64_t theta_stride, int64_t B,
     T* __restrict__ H0, int64_t h0_batch, T* __restrict__ H0t, int64_t h0t_batch, int32_t ldt,
     float* __restrict__ ybat, int64_t ybat_batch) {
+  extern __shared__ __attribute__((aligned(16))) char fsm[];
+  constexpr int kEpc = 16 / Elem<T>::kBytes;
+  T* tile = reinterpret_cast<T*>(fsm);
+  const int pitch = nd.Fp + kEpc;
   const int e = blockIdx.y;
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= B) return;
+  const int64_t r0 = (int64_t)blockIdx.x * kFeatRows;
+  const int64_t r = r0 + threadIdx.x;
   const float* th = theta + (int64_t)e * theta_stride;
-  const int64_t row = row_of(rs, e, r);
-  const float* x = X + row * nd.D;
-  float u[BNF_MAX_INPUTS];
+  if (r < B) {
+    const int64_t row = row_of(rs, e, r);
+    const float* x = X + row * nd.D;
+    float u[BNF_MAX_INPUTS];
 #pragma unroll
-  for (int d = 0; d < BNF_MAX_INPUTS; ++d)
-    if (d < nd.D) u[d] = x[d] / (nd.in_scale[d] * expf(th[nd.off_lsa + d]));
-  T* hrow = H0 + (int64_t)e * h0_batch + r * nd.Fp;
-  T* hcol = H0t ? H0t + (int64_t)e * h0t_batch + r : nullptr;
-  auto put = [&](int col, float v) {
-    Elem<T>::store(hrow + col, v);
-    if (hcol) Elem<T>::store(hcol + (int64_t)col * ldt, v);
-  };
-  for (int g = 0; g < nd.n_groups; ++g) {
-    const float sp = softplusf(th[nd.group_scale_off[g]]);
-    const int c0 = nd.group_col0[g], nc = nd.group_ncols[g];
-    const int kind = nd.group_kind[g];
-    if (kind == BNF_GROUP_INPUT) {
-      for (int d = 0; d < nd.D; ++d) put(c0 + d, u[d] * sp);
-    } else if (kind == BNF_GROUP_FOURIER) {
-      const int deg = nc >> 1;
-      float ud = 0.f;
+    for (int d = 0; d < BNF_MAX_INPUTS; ++d)
+      if (d < nd.D) u[d] = x[d] / (nd.in_scale[d] * expf(th[nd.off_lsa + d]));
+    T* trow = tile + threadIdx.x * pitch;
+    T* hcol = H0t ? H0t + (int64_t)e * h0t_batch + r : nullptr;
+    auto put = [&](int col, float v) {
+      Elem<T>::store(trow + col, v);
+      if (hcol) Elem<T>::store(hcol + (int64_t)col * ldt, v);
+    };
+    for (int g = 0; g < nd.n_groups; ++g) {
+      const float sp = softplusf(th[nd.group_scale_off[g]]);
+      const int c0 = nd.group_col0[g], nc = nd.group_ncols[g];
+      const int kind = nd.group_kind[g];
+      if (kind == BNF_GROUP_INPUT) {
+        for (int d = 0; d < nd.D; ++d) put(c0 + d, u[d] * sp);
+      } else if (kind == BNF_GROUP_FOURIER) {
+        const int deg = nc >> 1;
+        float ud = 0.f;
 #pragma unroll
-      for (int d = 0; d < BNF_MAX_INPUTS; ++d)
-        if (d == nd.group_arg[g]) ud = u[d];
-      const float y0 = kTwoPiF * ud;
-      for (int k = 0; k < deg; ++k) {
-        float s, c;
-        sincosf(y0 * (float)(1u << k), &s, &c);
-        const float den = (float)(k + 1);
-        put(c0 + k, (c / den) * sp);
-        put(c0 + deg + k, (s / den) * sp);
-      }
-    } else if (kind == BNF_GROUP_SEASONAL) {
-      const float* srow = Stab + row * nc;
-      for (int j = 0; j < nc; ++j) put(c0 + j, srow[j] * sp);
-    } else {
-      for (int k = 0; k < nc; ++k) {
-        float up = 0.f, uq = 0.f;
-#pragma unroll
-        for (int d = 0; d < BNF_MAX_INPUTS; ++d) {
-          if (d == nd.interact[k][0]) up = u[d];
-          if (d == nd.interact[k][1]) uq = u[d];
+        for (int d = 0; d < BNF_MAX_INPUTS; ++d)
+          if (d == nd.group_arg[g]) ud = u[d];
+        const float y0 = kTwoPiF * ud;
+        for (int k = 0; k < deg; ++k) {
+          float sn, cs;
+          sincosf(y0 * (float)(1u << k), &sn, &cs);
+          const float den = (float)(k + 1);
+          put(c0 + k, (cs / den) * sp);
+          put(c0 + deg + k, (sn / den) * sp);
         }
-        put(c0 + k, (up * uq) * sp);
+      } else if (kind == BNF_GROUP_SEASONAL) {
+        const float* srow = Stab + row * nc;
+        for (int j = 0; j < nc; ++j) put(c0 + j, srow[j] * sp);
+      } else {
+        for (int k = 0; k < nc; ++k) {
+          float up = 0.f, uq = 0.f;
+#pragma unroll
+          for (int d = 0; d < BNF_MAX_INPUTS; ++d) {
+            if (d == nd.interact[k][0]) up = u[d];
+            if (d == nd.interact[k][1]) uq = u[d];
+          }
+          put(c0 + k, (up * uq) * sp);
+        }
       }
     }
+    for (int c = nd.F; c < nd.Fp; ++c) Elem<T>::store(trow + c, 0.f);  // K padding of the contraction
+    if (ybat) ybat[(int64_t)e * ybat_batch + r] = y ? y[row] : 0.f;
   }
-  if (ybat) ybat[(int64_t)e * ybat_batch + r] = y ? y[row] : 0.f;
+  __syncthreads();
+  const int cpr = nd.Fp / kEpc;  // 16-byte chunks per row
+  T* dst = H0 + (int64_t)e * h0_batch;
+  for (int q = threadIdx.x; q < kFeatRows * cpr; q += kFeatRows) {
+    const int lr = q / cpr, cc = q % cpr;
+    if (r0 + lr < B)
+      *reinterpret_cast<u32x4*>(dst + (r0 + lr) * nd.Fp + cc * kEpc) =
+          *reinterpret_cast<const u32x4*>(tile + lr * pitch + cc * kEpc);
+  }
 }
 
 // ---------------------------------------------------------------------------
 // featurise backward: d feature scales, d log_scale_adjustment.
-// dH0 (rows, Fp) f32 comes from the layer-0 dgrad contraction.
+// dH0^T (Fp, ldt) f32 comes from the layer-0 dgrad contraction (transposed so
+// that a thread-per-row read is coalesced).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_feat_bwd(
     NetDev nd, RowSrc rs, const float* __restrict__ X, const float* __restrict__ Stab,
     const float* __restrict__ theta, int64_t theta_stride, int64_t B,
-    const float* __restrict__ dH0, int64_t dh0_batch, float* __restrict__ grad,
+    const float* __restrict__ dH0t, int64_t dh0_batch, int32_t ldt, float* __restrict__ grad,
     int64_t grad_stride) {
   __shared__ float red[4][BNF_MAX_GROUPS + BNF_MAX_INPUTS];
   const int e = blockIdx.y;
@@ -166,7 +187,8 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
       u[d] = 0.f;
       if (d < nd.D) u[d] = x[d] / (nd.in_scale[d] * expf(th[nd.off_lsa + d]));
     }
-    const float* dh = dH0 + (int64_t)e * dh0_batch + r * nd.Fp;
+    const float* dhp = dH0t + (int64_t)e * dh0_batch + r;
+    auto dh = [&](int col) { return dhp[(int64_t)col * ldt]; };
 #pragma unroll
     for (int g = 0; g < BNF_MAX_GROUPS; ++g) {
       if (g >= nd.n_groups) continue;
@@ -178,7 +200,7 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
 #pragma unroll
         for (int d = 0; d < BNF_MAX_INPUTS; ++d)
           if (d < nd.D) {
-            const float dhv = dh[c0 + d];
+            const float dhv = dh(c0 + d);
             acc += dhv * u[d];
             du[d] += sp * dhv;
           }
@@ -195,7 +217,7 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
           const float sc = (float)(1u << k);
           sincosf(y0 * sc, &s, &c);
           const float den = (float)(k + 1);
-          const float dc = dh[c0 + k], ds = dh[c0 + deg + k];
+          const float dc = dh(c0 + k), ds = dh(c0 + deg + k);
           acc += dc * (c / den) + ds * (s / den);
           dud += (kTwoPiF * sc) * (-s * dc + c * ds) / den;
         }
@@ -204,7 +226,7 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
           if (d == nd.group_arg[g]) du[d] += sp * dud;
       } else if (kind == BNF_GROUP_SEASONAL) {
         const float* srow = Stab + row * nc;
-        for (int j = 0; j < nc; ++j) acc += dh[c0 + j] * srow[j];
+        for (int j = 0; j < nc; ++j) acc += dh(c0 + j) * srow[j];
       } else {
         for (int k = 0; k < nc; ++k) {
           const int p = nd.interact[k][0], q = nd.interact[k][1];
@@ -214,7 +236,7 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
             if (d == p) up = u[d];
             if (d == q) uq = u[d];
           }
-          const float dhv = dh[c0 + k];
+          const float dhv = dh(c0 + k);
           acc += dhv * up * uq;
 #pragma unroll
           for (int d = 0; d < BNF_MAX_INPUTS; ++d) {
@@ -252,30 +274,24 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
 }
 
 // ---------------------------------------------------------------------------
-// output layer + likelihood (+ backward of the last hidden activation).
-//   block = 4 waves; wave w owns rows r0 + 8w .. +7; lane owns 8 consecutive
-//   columns per 512-column pass.
-//   forward  (models.py:269-273, 157-164): v = (H_L/sqrt W) k_o + b_o, out = gamma_o v
+// output layer + likelihood, one thread per row.  The last forward contraction
+// has already accumulated vacc[row] = sum_j H_L[row][j] k_o[j] (EPI_FWD vdot).
+//   forward  (models.py:269-273, 157-164): v = vacc/sqrt W + b_o, out = gamma_o v
 //   loss     (inference.py:558-569):       -(N/B) * lik_scale * loglik
-//   backward: d out, d log_noise_scale, d output scale/bias/kernel,
-//            dZ_{L-1} = gamma (dv k_o^T/sqrt W) . act'(A_{L-1}) (+ bias/scale/alpha grads)
-// TRAIN=false: forward only (predict path).
+//   backward: d out -> dv = gamma_o * dout, d log_noise_scale,
+//            d output scale / bias
+// vacc is cleared for the next step.  TRAIN=false: forward only (predict path).
 // ---------------------------------------------------------------------------
-struct OutArgs {
+struct RowLossArgs {
   const float* theta;
   int64_t theta_stride;
-  int64_t B;             // rows in this launch
-  const void* H;         // (rows, W) last hidden output, T
-  const void* A;         // (rows, W) last pre-activation, T
-  int64_t act_batch;
-  void* dZ;              // (rows, W)
-  void* dZt;             // (W, ldt)
-  int64_t actt_batch;
-  int32_t ldt;
-  const float* ybat;     // (members, ybat_batch)
-  int64_t ybat_batch;
+  int64_t B;
+  float* vacc;           // (members, vacc_batch)
+  int64_t vacc_batch;
+  const float* ybat;     // (members, vacc_batch)
   float* out;            // (members, out_batch) network output
   int64_t out_batch;
+  float* dv;             // (members, vacc_batch)
   float* grad;
   int64_t grad_stride;
   float* loss;           // loss[(e / S) * loss_stride] += loss_scale * step loss
@@ -283,190 +299,165 @@ struct OutArgs {
   int32_t S;
   float loss_scale;
   float c;               // (N/B) * lik_scale
-  float* loss_raw;       // optional (members,) un-scaled per-virtual-member loss (debug)
+  float* loss_raw;
 };
 
-template <typename T, bool TRAIN>
-__global__ __launch_bounds__(256) void k_out_loss(NetDev nd, OutArgs a) {
-  constexpr bool FAST = Elem<T>::kFast;
-  __shared__ float s_dv[32];
-  __shared__ float s_red[4][8];
-  __shared__ float s_col[4][2][512];
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void k_row_loss(NetDev nd, RowLossArgs a) {
+  __shared__ float s_red[4][4];
   const int e = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t r0 = (int64_t)blockIdx.x * 32 + wave * 8;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const float* th = a.theta + (int64_t)e * a.theta_stride;
-  const int W = nd.W, L = nd.depth;
-  const float inv_sw = 1.0f / sqrtf((float)W);
-  const float* ko = th + nd.off_kernel[L];
-  const float bo = th[nd.off_bias[L]];
+  const int L = nd.depth;
   const float gam_o = softplusf(th[nd.off_os]);
-  const T* H = reinterpret_cast<const T*>(a.H) + (int64_t)e * a.act_batch;
-
-  // ---- phase 1: row dots -----------------------------------------------------
-  float p[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) p[i] = 0.f;
-  for (int cb = 0; cb < W; cb += 512) {
-    const int j0 = cb + lane * 8;
-    if (j0 < W) {
-      float kv[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) kv[c] = ko[j0 + c];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int64_t r = r0 + i;
-        if (r < a.B) {
-          const T* hp = H + r * W + j0;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) p[i] += Elem<T>::load(hp + c) * kv[c];
-        }
-      }
-    }
-  }
-  float v_mine = 0.f;  // lane i (< 8) of the wave keeps row i
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float s = wave_sum(p[i]);
-    if (lane == i) v_mine = s;
-  }
   float ll = 0.f, s_doutv = 0.f, s_dvsum = 0.f, s_lns = 0.f;
-  if (lane < 8) {
-    const int64_t r = r0 + lane;
-    float dv = 0.f;
-    if (r < a.B) {
-      const float v = v_mine * inv_sw + bo;
-      const float out = gam_o * v;
-      a.out[(int64_t)e * a.out_batch + r] = out;
-      if constexpr (TRAIN) {
-        const float yv = a.ybat[(int64_t)e * a.ybat_batch + r];
-        // NORMAL (models.py:157-164): sigma = 0.01 + exp(lns)
-        const float lns = th[nd.off_lns];
-        const float sigma = 0.01f + expf(lns);
-        const float res = yv - out;
-        const float z = res / sigma;
-        ll = -0.5f * z * z - logf(sigma) - 0.918938533204672742f;
-        const float dout = -a.c * res / (sigma * sigma);
-        s_doutv = dout * v;
-        dv = gam_o * dout;
-        s_dvsum = dv;
-        s_lns = -a.c * (res * res / (sigma * sigma * sigma) - 1.0f / sigma) * expf(lns);
-      }
+  if (r < a.B) {
+    const int64_t vi = (int64_t)e * a.vacc_batch + r;
+    const float v = a.vacc[vi] * (1.0f / sqrtf((float)nd.W)) + th[nd.off_bias[L]];
+    a.vacc[vi] = 0.f;
+    const float out = gam_o * v;
+    a.out[(int64_t)e * a.out_batch + r] = out;
+    if constexpr (TRAIN) {
+      const float yv = a.ybat[vi];
+      // NORMAL (models.py:157-164): sigma = 0.01 + exp(lns)
+      const float lns = th[nd.off_lns];
+      const float sigma = 0.01f + expf(lns);
+      const float res = yv - out;
+      const float z = res / sigma;
+      ll = -0.5f * z * z - logf(sigma) - 0.918938533204672742f;
+      const float dout = -a.c * res / (sigma * sigma);
+      s_doutv = dout * v;
+      const float dvv = gam_o * dout;
+      a.dv[vi] = dvv;
+      s_dvsum = dvv;
+      s_lns = -a.c * (res * res / (sigma * sigma * sigma) - 1.0f / sigma) * expf(lns);
     }
-    if constexpr (TRAIN) s_dv[wave * 8 + lane] = dv;
   }
   if constexpr (!TRAIN) return;
-
-  // block sums of the 4 row scalars
-  {
-    const float t0 = wave_sum(ll), t1 = wave_sum(s_doutv), t2 = wave_sum(s_dvsum),
-                t3 = wave_sum(s_lns);
-    if (lane == 0) {
-      s_red[wave][0] = t0; s_red[wave][1] = t1; s_red[wave][2] = t2; s_red[wave][3] = t3;
-    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float t0 = wave_sum(ll), t1 = wave_sum(s_doutv), t2 = wave_sum(s_dvsum), t3 = wave_sum(s_lns);
+  if (lane == 0) {
+    s_red[wave][0] = t0; s_red[wave][1] = t1; s_red[wave][2] = t2; s_red[wave][3] = t3;
   }
   __syncthreads();
-  float* gr = a.grad + (int64_t)e * a.grad_stride;
   if (threadIdx.x == 0) {
-    const float t0 = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
-    const float t1 = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
-    const float t2 = s_red[0][2] + s_red[1][2] + s_red[2][2] + s_red[3][2];
-    const float t3 = s_red[0][3] + s_red[1][3] + s_red[2][3] + s_red[3][3];
-    const float step_loss = -a.c * t0;
+    float* gr = a.grad + (int64_t)e * a.grad_stride;
+    const float u0 = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+    const float u1 = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
+    const float u2 = s_red[0][2] + s_red[1][2] + s_red[2][2] + s_red[3][2];
+    const float u3 = s_red[0][3] + s_red[1][3] + s_red[2][3] + s_red[3][3];
+    const float step_loss = -a.c * u0;
     atomicAdd(&a.loss[(int64_t)(e / a.S) * a.loss_stride], a.loss_scale * step_loss);
     if (a.loss_raw) atomicAdd(&a.loss_raw[e], step_loss);
-    atomicAdd(&gr[nd.off_os], sigmoidf(th[nd.off_os]) * t1);
-    atomicAdd(&gr[nd.off_bias[L]], t2);
-    atomicAdd(&gr[nd.off_lns], t3);
+    atomicAdd(&gr[nd.off_os], sigmoidf(th[nd.off_os]) * u1);
+    atomicAdd(&gr[nd.off_bias[L]], u2);
+    atomicAdd(&gr[nd.off_lns], u3);
   }
+}
 
-  // ---- phase 2: last hidden layer backward -------------------------------------
-  const int l = L - 1;
+// ---------------------------------------------------------------------------
+// backward of the last hidden activation (layer l = L-1):
+//   dH = dv k_o^T / sqrt W ;  dZ = gamma_l (dH . act'(A)) ; d bias_l, d gamma_l,
+//   d alpha ; d k_o = H^T dv / sqrt W with H = act(A) recomputed (the last hidden
+//   output is never stored).
+// One wave owns a 64-column strip and walks `row_tiles` 64-row tiles; lane
+// (rg = lane & 7, cg = lane >> 3) holds an 8 x 8 block, so A^T / dZ^T (8 rows
+// contiguous) and dZ (8 columns contiguous) all move as 16-byte vectors and every
+// wave instruction covers full 128-byte lines.
+// ---------------------------------------------------------------------------
+struct LastBwdArgs {
+  const float* theta;
+  int64_t theta_stride;
+  const void* At;        // (W, ldt) last pre-activation, transposed
+  void* dZ;              // (rows, W)
+  void* dZt;             // (W, ldt)
+  int64_t act_batch, actt_batch;
+  int32_t ldt;
+  const float* dv;       // (members, dv_batch)
+  int64_t dv_batch;
+  float* grad;
+  int64_t grad_stride;
+  int32_t n_row_tiles;   // 64-row tiles in the (padded) batch
+  int32_t tiles_per_task;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_last_bwd(NetDev nd, const LastBwdArgs a) {
+  constexpr bool FAST = Elem<T>::kFast;
+  const int e = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int W = nd.W, L = nd.depth, l = L - 1;
+  const int strips = W / 64;
+  const int task = blockIdx.x * 4 + wave;
+  const int n_chunks = (a.n_row_tiles + a.tiles_per_task - 1) / a.tiles_per_task;
+  if (task >= strips * n_chunks) return;
+  const int strip = task % strips, chunk = task / strips;
+  const int rg = lane & 7, cg = lane >> 3;
+  const int j0 = strip * 64 + cg * 8;
+  const float* th = a.theta + (int64_t)e * a.theta_stride;
+  const float inv_sw = 1.0f / sqrtf((float)W);
   const float gamma = softplusf(th[nd.off_ls[l]]);
   const float alpha = sigmoidf(th[nd.off_law]);
-  const T* Ap = reinterpret_cast<const T*>(a.A) + (int64_t)e * a.act_batch;
-  T* dZ = reinterpret_cast<T*>(a.dZ) + (int64_t)e * a.act_batch;
-  T* dZt = reinterpret_cast<T*>(a.dZt) + (int64_t)e * a.actt_batch;
-  float dvr[8];
+  const T* __restrict__ At = reinterpret_cast<const T*>(a.At) + (int64_t)e * a.actt_batch;
+  T* __restrict__ dZ = reinterpret_cast<T*>(a.dZ) + (int64_t)e * a.act_batch;
+  T* __restrict__ dZt = reinterpret_cast<T*>(a.dZt) + (int64_t)e * a.actt_batch;
+  const float* __restrict__ dv = a.dv + (int64_t)e * a.dv_batch;
+  float kv[8], cs_b[8], cs_k[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) dvr[i] = s_dv[wave * 8 + i];
+  for (int c = 0; c < 8; ++c) {
+    kv[c] = th[nd.off_kernel[L] + j0 + c] * inv_sw;
+    cs_b[c] = cs_k[c] = 0.f;
+  }
   float s_alpha = 0.f, s_gamma = 0.f;
-  for (int cb = 0; cb < W; cb += 512) {
-    const int j0 = cb + lane * 8;
-    float cs_b[8], cs_k[8];
+  const int t_end = min(a.n_row_tiles, (chunk + 1) * a.tiles_per_task);
+  for (int t = chunk * a.tiles_per_task; t < t_end; ++t) {
+    const int64_t r0 = (int64_t)t * 64 + rg * 8;
+    float dvr[8];
+    load8(dv + r0, dvr);
+    float dz[8][8];  // [row i][col c]
+    typename Raw<T>::R8 raws[8];  // all eight column loads of the tile in flight together
 #pragma unroll
-    for (int c = 0; c < 8; ++c) cs_b[c] = cs_k[c] = 0.f;
-    if (j0 < W) {
-      float kv[8], dz[8][8];
+    for (int c = 0; c < 8; ++c) raws[c] = load_raw8(At + (int64_t)(j0 + c) * a.ldt + r0);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) kv[c] = ko[j0 + c] * inv_sw;
+    for (int c = 0; c < 8; ++c) {
+      float zc[8], avc[8];
+      unpack(raws[c], avc);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int64_t r = r0 + i;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) dz[i][c] = 0.f;
-        if (r < a.B) {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            const float av = Elem<T>::load(Ap + r * W + j0 + c);
-            const float hv = Elem<T>::load(H + r * W + j0 + c);
-            const float dh = dvr[i] * kv[c];
-            const ActOut o = act_eval<FAST>(av, alpha);
-            s_alpha += dh * o.ediff;
-            const float da = dh * o.dact;
-            s_gamma += da * av;
-            const float z = gamma * da;
-            dz[i][c] = z;
-            cs_b[c] += z;
-            cs_k[c] += hv * dvr[i];
-            Elem<T>::store(dZ + r * W + j0 + c, z);
-          }
-        }
+        const float avv = avc[i];
+        const float dh = dvr[i] * kv[c];
+        const ActOut o = act_eval<FAST>(avv, alpha);
+        s_alpha += dh * o.ediff;
+        const float da = dh * o.dact;
+        s_gamma += da * avv;
+        const float z = gamma * da;
+        zc[i] = z;
+        dz[i][c] = z;
+        cs_b[c] += z;
+        cs_k[c] += o.h * dvr[i];
       }
-      // transposed copy: 8 consecutive rows of each column
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        T* tp = dZt + (int64_t)(j0 + c) * a.ldt + r0;
-        if (r0 + 7 < a.B) {
-          store4(tp, dz[0][c], dz[1][c], dz[2][c], dz[3][c]);
-          store4(tp + 4, dz[4][c], dz[5][c], dz[6][c], dz[7][c]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-            if (r0 + i < a.B) Elem<T>::store(tp + i, dz[i][c]);
-        }
-      }
+      store8(dZt + (int64_t)(j0 + c) * a.ldt + r0, zc);
     }
-    // column sums over the 4 waves (32 rows), then one atomic per column
-    if (j0 < W) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        s_col[wave][0][lane * 8 + c] = cs_b[c];
-        s_col[wave][1][lane * 8 + c] = cs_k[c];
-      }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < 1024; t += 256) {
-      const int which = t >> 9, col = t & 511;
-      if (cb + col < W) {
-        const float s = s_col[0][which][col] + s_col[1][which][col] + s_col[2][which][col] +
-                        s_col[3][which][col];
-        if (which == 0) atomicAdd(&gr[nd.off_bias[l] + cb + col], s);
-        else atomicAdd(&gr[nd.off_kernel[L] + cb + col], s * inv_sw);
-      }
-    }
-    __syncthreads();
+    for (int i = 0; i < 8; ++i) store8(dZ + (r0 + i) * W + j0, dz[i]);
   }
-  {
-    const float t0 = wave_sum(s_alpha), t1 = wave_sum(s_gamma);
-    if (lane == 0) {
-      s_red[wave][4] = t0; s_red[wave][5] = t1;
+  // column sums: reduce over the 8 row groups (lane bits 0..2), then one atomic per column
+  float* gr = a.grad + (int64_t)e * a.grad_stride;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float b = cs_b[c], k = cs_k[c];
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+      b += __shfl_xor(b, off, 64);
+      k += __shfl_xor(k, off, 64);
+    }
+    if (rg == 0) {
+      atomicAdd(&gr[nd.off_bias[l] + j0 + c], b);
+      atomicAdd(&gr[nd.off_kernel[L] + j0 + c], k * inv_sw);
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float ta = s_red[0][4] + s_red[1][4] + s_red[2][4] + s_red[3][4];
-    const float tg = s_red[0][5] + s_red[1][5] + s_red[2][5] + s_red[3][5];
+  const float ta = wave_sum(s_alpha), tg = wave_sum(s_gamma);
+  if (lane == 0) {
     atomicAdd(&gr[nd.off_law], alpha * (1.f - alpha) * ta);
     atomicAdd(&gr[nd.off_ls[l]], sigmoidf(th[nd.off_ls[l]]) * tg / gamma);
   }
@@ -525,29 +516,46 @@ struct AdamArgs {
   float* loss_raw;
 };
 
+template <int VEC>
 __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
   __shared__ float red[4];
   const int e = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   float lp = 0.f;
-  if (p < a.P) {
-    const int64_t i = (int64_t)e * a.stride + p;
-    const float th = a.theta[i];
-    float g = a.grad[i];
-    if (a.prior_weight != 0.f) {
-      const float z = th - (p == a.off_shape ? -1.5f : 0.f);
-      g += a.prior_weight * tanhf(0.5f * z);
-      lp = -z - 2.f * softplusf(-z);
-    }
-    if (a.apply) {
-      const float m = 0.9f * a.m[i] + 0.1f * g;
-      const float v = 0.999f * a.v[i] + 0.001f * g * g;
-      a.m[i] = m;
-      a.v[i] = v;
-      a.theta[i] = th - a.lr * (m / a.bc1) / (sqrtf(v / a.bc2) + 1e-8f);
-      a.grad[i] = 0.f;
+  if (p0 < a.P) {
+    const int64_t i0 = (int64_t)e * a.stride + p0;
+    float th[VEC], g[VEC], m[VEC], v[VEC];
+    if constexpr (VEC == 4) {
+      load4(a.theta + i0, th); load4(a.grad + i0, g);
+      if (a.apply) { load4(a.m + i0, m); load4(a.v + i0, v); }
     } else {
-      a.grad[i] = g;
+      th[0] = a.theta[i0]; g[0] = a.grad[i0];
+      if (a.apply) { m[0] = a.m[i0]; v[0] = a.v[i0]; }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if (a.prior_weight != 0.f) {
+        const float z = th[k] - ((p0 + k) == a.off_shape ? -1.5f : 0.f);
+        g[k] += a.prior_weight * tanhf(0.5f * z);
+        lp += -z - 2.f * softplusf(-z);
+      }
+      if (a.apply) {
+        m[k] = 0.9f * m[k] + 0.1f * g[k];
+        v[k] = 0.999f * v[k] + 0.001f * g[k] * g[k];
+        th[k] = th[k] - a.lr * (m[k] / a.bc1) / (sqrtf(v[k] / a.bc2) + 1e-8f);
+        g[k] = 0.f;  // ready for the next step's atomics
+      }
+    }
+    if constexpr (VEC == 4) {
+      store4(a.grad + i0, g[0], g[1], g[2], g[3]);
+      if (a.apply) {
+        store4(a.theta + i0, th[0], th[1], th[2], th[3]);
+        store4(a.m + i0, m[0], m[1], m[2], m[3]);
+        store4(a.v + i0, v[0], v[1], v[2], v[3]);
+      }
+    } else {
+      a.grad[i0] = g[0];
+      if (a.apply) { a.theta[i0] = th[0]; a.m[i0] = m[0]; a.v[i0] = v[0]; }
     }
   }
   const float s = wave_sum(lp);
@@ -695,13 +703,14 @@ __global__ void k_forecast_aux(const float* theta, int64_t stride, int32_t n, in
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ void k_to_f32(const T* __restrict__ src, int64_t src_batch, int32_t src_ld,
-                         int64_t rows, int32_t cols, float* __restrict__ dst) {
+                         int64_t rows, int32_t cols, float* __restrict__ dst, int transposed) {
   const int e = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * cols) return;
   const int64_t r = i / cols;
   const int c = (int)(i % cols);
-  dst[(int64_t)e * rows * cols + i] = Elem<T>::load(src + (int64_t)e * src_batch + r * src_ld + c);
+  const int64_t off = transposed ? (int64_t)c * src_ld + r : r * src_ld + c;
+  dst[(int64_t)e * rows * cols + i] = Elem<T>::load(src + (int64_t)e * src_batch + off);
 }
 
 template <typename T>

@@ -187,8 +187,9 @@ int bnf_debug_row_index(bnf_handle* h, int64_t epoch, int64_t step, int32_t* out
 /* VI noise of a step: out DEVICE (members, S, P) f32. */
 int bnf_debug_vi_eps(bnf_handle* h, int64_t step, float* out);
 /* Copy of an internal activation buffer, as f32: what = 0 features H0 (E',B,F),
- * 1+l hidden output H_{l+1} (E',B,W), 100+l pre-activation A_l (E',B,W),
- * 200 network output (E',B). Valid after bnf_debug_loss_and_grad. */
+ * 1+l hidden output H_{l+1} (E',B,W) for l < depth-1 (the last hidden output is
+ * never stored), 100+l pre-activation A_l (E',B,W), 200 network output (E',B),
+ * 300+l dZ_l (E',B,W), 400 dH0 (E',B,F). Valid after bnf_debug_loss_and_grad. */
 int bnf_debug_activation(bnf_handle* h, int32_t what, float* out);
 /* Raw C = A * Bt^T of the dense-contraction core (A (M,K), Bt (N,K), K a multiple
  * of 64, dtype = handle dtype, inputs given as f32 and converted) -> C (M,N) f32. */

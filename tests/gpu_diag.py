@@ -57,7 +57,8 @@ def stage_diag(dtype, depth=2, width=64, n_rows=300, pw=1.0):
   print('  H0 max abs err', float(np.max(np.abs(eng.debug_activation(0) - ch['Hs'][0]))))
   for l in range(depth):
     print(f'  A{l} rel', util.rel_err(eng.debug_activation(100 + l), ch['As'][l]),
-          f' H{l+1} rel', util.rel_err(eng.debug_activation(1 + l), ch['Hs'][l + 1]))
+          f' H{l+1} rel', util.rel_err(eng.debug_activation(1 + l), ch['Hs'][l + 1])
+          if l < depth - 1 else '(not stored)')
   print('  out rel', util.rel_err(eng.debug_activation(200), out_o))
   print('  loss dev', loss_d, ' oracle', loss_o)
   errs = util.per_leaf_rel_err(model, g_d, g_o)

@@ -58,7 +58,8 @@ def test_forward_and_grad_fp32(depth, width, n_rows):
     assert np.max(np.abs(H0 - ch['Hs'][0])) < 5e-5
     for l in range(depth):
       assert util.rel_err(eng.debug_activation(100 + l), ch['As'][l]) < 2e-4, l
-      assert util.rel_err(eng.debug_activation(1 + l), ch['Hs'][l + 1]) < 2e-4, l
+      if l < depth - 1:   # the last hidden output is consumed in registers, never stored
+        assert util.rel_err(eng.debug_activation(1 + l), ch['Hs'][l + 1]) < 2e-4, l
     assert util.rel_err(eng.debug_activation(200), out_o) < 2e-4
     np.testing.assert_allclose(loss_d, loss_o, rtol=2e-5)
     errs = util.per_leaf_rel_err(model, g_d, g_o)
