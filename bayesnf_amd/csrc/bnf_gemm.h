@@ -15,7 +15,8 @@
 // 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 f32 VGPRs).  K advances in
 // 128-byte rows (64 bf16 / 32 f32) through a double-buffered, XOR-swizzled LDS
 // image (row pitch 128 B, 16-byte chunk index ^= (row >> 1) & 7, which makes
-// every 16-lane ds_read_b128 group hit 16 distinct 16-byte slots).  bf16 uses
+// every 16-lane ds_read_b128 group hit 16 distinct 16-byte slots), filled by
+// LDS-DMA (global_load_lds_dwordx4) with the swizzle applied to the source address.  bf16 uses
 // v_mfma_f32_32x32x16_bf16, f32 uses the exact v_mfma_f32_32x32x2_f32.
 // Workgroup ids are remapped so each XCD (private 4 MiB L2) owns a contiguous
 // range of (member, tile) work: a member's weights and activation panels stay
@@ -152,18 +153,23 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
   const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)e * g.a_batch * Elem<T>::kBytes;
   const char* Bb = reinterpret_cast<const char*>(g.B) + (int64_t)e * g.b_batch * Elem<T>::kBytes;
 
-  // ---- staging map: 4 A chunks + 4 B chunks of 16 B per thread per tile ------
+  // ---- staging map: global -> LDS by LDS-DMA (global_load_lds, 16 B per lane) ---
+  // One wave instruction fills 8 consecutive 128-byte rows (lane l -> row l/8,
+  // physical chunk l%8).  The XOR swizzle lives on the SOURCE side: physical chunk
+  // c' of a row holds logical chunk c' ^ ((row >> 1) & 7).  No staging VGPRs and no
+  // ds_write traffic; each wave issues 4 A + 4 B instructions per K tile.
   const char* a_src[4];
   const char* b_src[4];
-  int lds_off[4];
+  int lds_base[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int q = tid + i * kThreads;
-    const int row = q >> 3, c = q & 7;
+    const int r0 = (wave * 4 + i) * 8;
+    const int row = r0 + (lane >> 3), cp = lane & 7;
+    const int c = cp ^ ((row >> 1) & 7);
     const int am = min(m0 + row, g.M - 1), bn = min(n0 + row, g.N - 1);
     a_src[i] = Ab + ((int64_t)am * g.a_ld) * Elem<T>::kBytes + c * 16;
     b_src[i] = Bb + ((int64_t)bn * g.b_ld) * Elem<T>::kBytes + c * 16;
-    lds_off[i] = row * kRowBytes + ((c ^ ((row >> 1) & 7)) << 4);
+    lds_base[i] = r0 * kRowBytes;
   }
 
   f32x16 acc[2][2];
@@ -194,22 +200,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
     }
   }
 
-  u32x4 ra[4], rb[4];
-  auto gload = [&](int kt) {
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef __attribute__((address_space(1))) const void glb_void_t;
+  auto stage = [&](int buf, int kt) {
     const int64_t koff = (int64_t)kt * kRowBytes;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + koff);
-      rb[i] = *reinterpret_cast<const u32x4*>(b_src[i] + koff);
-    }
-  };
-  auto lstore = [&](int buf) {
     char* sA = smem + buf * kStageBytes;
     char* sB = sA + kBM * kRowBytes;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4*>(sA + lds_off[i]) = ra[i];
-      *reinterpret_cast<u32x4*>(sB + lds_off[i]) = rb[i];
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[i] + koff), (lds_void_t*)(sA + lds_base[i]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(b_src[i] + koff), (lds_void_t*)(sB + lds_base[i]), 16, 0, 0);
     }
   };
 
@@ -225,12 +225,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
   }
 
   if (kt0 < kt1 && !(ep.ablate & 16)) {
-    gload(kt0);
-    lstore(0);
-    __syncthreads();
+    stage(0, kt0);
+    __syncthreads();  // (the barrier's fence drains the LDS-DMA: vmcnt(0))
     for (int kt = kt0; kt < kt1; ++kt) {
       const int buf = (kt - kt0) & 1;
-      if (kt + 1 < kt1) gload(kt + 1);
+      if (kt + 1 < kt1) stage(buf ^ 1, kt + 1);
       const char* sA = smem + buf * kStageBytes;
       const char* sB = sA + kBM * kRowBytes;
 #pragma unroll
@@ -246,7 +245,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
 #pragma unroll
           for (int j = 0; j < 2; ++j) M_::mma(acc[i][j], fa[i], fb[j]);
       }
-      if (kt + 1 < kt1) lstore(buf ^ 1);
       __syncthreads();
     }
   }
