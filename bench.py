@@ -38,6 +38,34 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 
+# engine kernel name (bnf_profile_read) -> device symbol (rocprofv3 Kernel_Name), {T} = element type
+KERNEL_SYMBOL = {
+    'gemm_fwd_l0': 'void bnf::gemm_nt<{T}, 0, 0>(bnf::GemmArgs, bnf::EpiArgs)',
+    'gemm_fwd': 'void bnf::gemm_nt<{T}, 0, 1>(bnf::GemmArgs, bnf::EpiArgs)',
+    'gemm_dgrad': 'void bnf::gemm_nt<{T}, 1, 1>(bnf::GemmArgs, bnf::EpiArgs)',
+    'gemm_dgrad0': 'void bnf::gemm_nt<{T}, 2, 0>(bnf::GemmArgs, bnf::EpiArgs)',
+    'gemm_wgrad_l0': 'void bnf::gemm_nt<{T}, 3, 0>(bnf::GemmArgs, bnf::EpiArgs)',
+    'gemm_wgrad': 'void bnf::gemm_nt<{T}, 3, 1>(bnf::GemmArgs, bnf::EpiArgs)',
+    'fused_fwd_bwd': 'void bnf::k_fused_fwd_bwd<{T}',
+}
+
+
+def pmc_traffic(kernel, dtype, members):
+  """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this
+  same command (profiles/pmc_traffic.json, made by scripts/gpu_pmc.sh; FETCH_SIZE and
+  WRITE_SIZE in separate passes, 2*FETCH + WRITE KiB, see scripts/pmc_summary.py).
+  None when no matching measurement is committed."""
+  path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+  if members != 64 or kernel not in KERNEL_SYMBOL or not os.path.exists(path):
+    return None
+  sym = KERNEL_SYMBOL[kernel].format(T='bnf::bf16_t' if dtype == 'bf16' else 'float')
+  with open(path) as f:
+    table = json.load(f)
+  for name, rec in table.items():
+    if name.startswith(sym):
+      return rec['hbm_bytes']
+  return None
+
 
 def synthetic_grid(seed=1234):
   """C2 data: x=(t, lat, lon), y = 3 sin(2 pi t/p1) + sin(2 pi t/p2)
@@ -175,7 +203,8 @@ def main():
         'algorithmic_tflops': flops_step * args.steps / elapsed / 1e12,
         'final_loss_mean': final_loss,
         'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': peak,
-                     'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                     'unit': 'TFLOP/s', 'frac': achieved / peak,
+                     'traffic': pmc_traffic(dominant, args.dtype, E),
                      'avg_launch_us': d['avg_ms'] * 1e3, 'launches': d['calls'],
                      'flops_per_launch': d['flops']},
     }
