@@ -29,7 +29,7 @@ EXPORTS = (
     'bnf_init_params', 'bnf_train', 'bnf_vi_posterior_draws', 'bnf_forward',
     'bnf_normal_mixture_quantiles', 'bnf_debug_loss_and_grad',
     'bnf_debug_row_index', 'bnf_debug_vi_eps', 'bnf_debug_activation',
-    'bnf_debug_gemm_nt', 'bnf_profile_enable', 'bnf_profile_read',
+    'bnf_debug_gemm_nt', 'bnf_debug_gemm_tn', 'bnf_profile_enable', 'bnf_profile_read',
     'bnf_kernel_flops')
 
 
@@ -107,6 +107,7 @@ def load():
   lib.bnf_debug_vi_eps.argtypes = [vp, i64, vp]
   lib.bnf_debug_activation.argtypes = [vp, i32, vp]
   lib.bnf_debug_gemm_nt.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+  lib.bnf_debug_gemm_tn.argtypes = [vp, vp, vp, i32, i32, i32, vp]
   lib.bnf_profile_enable.argtypes = [vp, C.c_char_p]
   lib.bnf_profile_read.argtypes = [
       vp, C.POINTER(i32), C.POINTER(C.c_char_p), C.POINTER(C.c_double),

@@ -125,13 +125,13 @@ static size_t carve(bnf_handle* h, char* base) {
   h->stab = (float*)take((size_t)std::max<int64_t>(1, h->N * nf2) * 4);
   h->stab_pred = (float*)take((size_t)std::max<int64_t>(1, Bp * nf2) * 4);
   h->H0 = take((size_t)Ev * Bp * Fp * es);
-  h->H0t = fo ? nullptr : take((size_t)Ev * Fp * Bp * es);
+  h->H0t = nullptr;   // no transposed copies: the weight-gradient contraction reads row-major (gemm_tn)
   for (int l = 0; l < h->L; ++l) {
     h->A[l] = take((size_t)Ev * W * Bp * es);                                  // A_l^T (W, Bp)
     h->H[l] = (l < h->L - 1) ? take((size_t)Ev * Bp * W * es) : nullptr;       // H_{l+1} (Bp, W)
-    h->Ht[l] = (!fo && l < h->L - 1) ? take((size_t)Ev * W * Bp * es) : nullptr;
+    h->Ht[l] = nullptr;
     h->dZ[l] = fo ? nullptr : take((size_t)Ev * Bp * W * es);
-    h->dZt[l] = fo ? nullptr : take((size_t)Ev * W * Bp * es);
+    h->dZt[l] = nullptr;
     const int64_t npad = (l == 0) ? Fp : W;
     h->pack_batch[l] = npad * W;
     h->Kn[l] = take((size_t)Ev * npad * W * es);
@@ -212,6 +212,22 @@ static void launch_gemm(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep) {
   hipLaunchKernelGGL((gemm_nt<T, EPI, TAG>), dim3(blocks), dim3(kThreads), kGemmLds, h->stream, g, ep2);
 }
 
+template <typename T, int TAG>
+static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep) {
+  g.tiles_m = (g.M + kBM - 1) / kBM;
+  g.tiles_n = (g.N + kBN - 1) / kBN;
+  if (g.splitk < 1) g.splitk = 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn<T, TAG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
+    attr_set = true;
+  }
+  const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
+  LaunchScope ls(h, kid);
+  hipLaunchKernelGGL((gemm_tn<T, TAG>), dim3(blocks), dim3(kThreads), kGemmLds, h->stream, g, ep);
+}
+
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------
@@ -248,7 +264,7 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
     }
     hipLaunchKernelGGL((k_featurize<T>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, X, stab,
                        y, theta, (int64_t)h->P, rows, (T*)h->H0, Bp * h->Fp,
-                       train ? (T*)h->H0t : (T*)nullptr, (int64_t)h->Fp * Bp, (int32_t)Bp,
+                       (T*)nullptr, (int64_t)h->Fp * Bp, (int32_t)Bp,
                        train ? h->ybat : (float*)nullptr, Bp);
   }
   for (int l = 0; l < h->L; ++l) {
@@ -274,7 +290,7 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
     ep.off_act_weight = h->nd.off_law;
     ep.out_a = h->A[l];
     ep.out_h = last ? nullptr : h->H[l];
-    ep.out_t = (train && !last) ? h->Ht[l] : nullptr;
+    ep.out_t = nullptr;
     ep.vdot = last ? h->vacc : nullptr;
     ep.vdot_batch = Bp;
     ep.off_ko = h->nd.off_kernel[h->L];
@@ -313,7 +329,7 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
   {
     LastBwdArgs a{};
     a.theta = theta; a.theta_stride = h->P;
-    a.At = h->A[L - 1]; a.dZ = h->dZ[L - 1]; a.dZt = h->dZt[L - 1];
+    a.At = h->A[L - 1]; a.dZ = h->dZ[L - 1];
     a.act_batch = Bp * h->W; a.actt_batch = (int64_t)h->W * Bp; a.ldt = (int32_t)Bp;
     a.dv = h->dv; a.dv_batch = Bp; a.grad = h->grad; a.grad_stride = h->P;
     a.n_row_tiles = (int32_t)((rows + 63) / 64);
@@ -340,7 +356,7 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
       ep.off_act_weight = h->nd.off_law;
       ep.in_a = h->A[l - 1];
       ep.out_h = h->dZ[l - 1];
-      ep.out_t = h->dZt[l - 1];
+      ep.out_t = nullptr;
       ep.act_batch = Bp * h->W; ep.actt_batch = (int64_t)h->W * Bp;
       ep.ld = h->W; ep.ldt = (int32_t)Bp;
       launch_gemm<T, EPI_DGRAD, 1>(h, KID_DGRAD, g, ep);
@@ -360,11 +376,12 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
                        (int64_t)h->P);
   }
   for (int l = 0; l < L; ++l) {
-    // dK_l = H_l^T . dZ_l / sqrt(fan_in_l)   (contraction over the batch rows)
+    // dK_l = H_l^T . dZ_l / sqrt(fan_in_l): contraction over the batch rows of the
+    // row-major activations (transpose reads in LDS, no transposed copies in HBM)
     GemmArgs g{};
-    g.A = (l == 0) ? h->H0t : h->Ht[l - 1];
-    g.a_ld = (int32_t)Bp; g.a_batch = (int64_t)((l == 0) ? h->Fp : h->W) * Bp;
-    g.B = h->dZt[l]; g.b_ld = (int32_t)Bp; g.b_batch = (int64_t)h->W * Bp;
+    g.A = (l == 0) ? h->H0 : h->H[l - 1];
+    g.a_ld = (l == 0) ? h->Fp : h->W; g.a_batch = Bp * g.a_ld;
+    g.B = h->dZ[l]; g.b_ld = h->W; g.b_batch = Bp * h->W;
     g.M = (l == 0) ? h->F : h->W; g.N = h->W; g.K = (int)Bp; g.members = nmem;
     const int tiles = ((g.M + kBM - 1) / kBM) * ((g.N + kBN - 1) / kBN);
     const int nk = (int)(Bp / (h->bf16 ? 64 : 32));
@@ -374,8 +391,8 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
     EpiArgs ep{};
     ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->W));
     ep.grad = h->grad; ep.grad_stride = h->P; ep.off_out = h->nd.off_kernel[l]; ep.ld_f32 = h->W;
-    if (l == 0) launch_gemm<T, EPI_WGRAD, 0>(h, KID_WGRAD0, g, ep);
-    else launch_gemm<T, EPI_WGRAD, 1>(h, KID_WGRAD, g, ep);
+    if (l == 0) launch_gemm_tn<T, 0>(h, KID_WGRAD0, g, ep);
+    else launch_gemm_tn<T, 1>(h, KID_WGRAD, g, ep);
   }
 }
 
@@ -866,6 +883,36 @@ int bnf_debug_gemm_nt(bnf_handle* h, const float* A, const float* Bt, int32_t M,
     hipLaunchKernelGGL((k_from_f32<float>), dim3(cdiv((int64_t)M * K, 256)), dim3(256), 0, st, A, (int64_t)M, K, (float*)dA, K);
     hipLaunchKernelGGL((k_from_f32<float>), dim3(cdiv((int64_t)N * K, 256)), dim3(256), 0, st, Bt, (int64_t)N, K, (float*)dB, K);
     launch_gemm<float, EPI_PLAIN, 2>(h, KID_FWD, g, ep);
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipFree(dA));
+  HIPCHK(hipFree(dB));
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
+int bnf_debug_gemm_tn(bnf_handle* h, const float* A, const float* B, int32_t R, int32_t M, int32_t N,
+                      float* C) {
+  if (!h || !A || !B || !C) return fail(BNF_ERR_INVALID, "null");
+  if (R < 64 || R % 64 != 0 || M < 1 || N < 1 || M % 8 != 0 || N % 8 != 0)
+    return fail(BNF_ERR_INVALID, "R must be a multiple of 64, M and N multiples of 8");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  hipStream_t st = h->stream;
+  void *dA = nullptr, *dB = nullptr;
+  HIPCHK(hipMalloc(&dA, (size_t)R * M * h->es));
+  HIPCHK(hipMalloc(&dB, (size_t)R * N * h->es));
+  GemmArgs g{};
+  g.A = dA; g.B = dB; g.a_ld = M; g.b_ld = N; g.M = M; g.N = N; g.K = R; g.splitk = 1; g.members = 1;
+  EpiArgs ep{};
+  ep.scale = 1.f; ep.out_f32 = C; ep.f32_batch = 0; ep.ld_f32 = N;
+  if (h->bf16) {
+    hipLaunchKernelGGL((k_from_f32<bf16_t>), dim3(cdiv((int64_t)R * M, 256)), dim3(256), 0, st, A, (int64_t)R, M, (bf16_t*)dA, M);
+    hipLaunchKernelGGL((k_from_f32<bf16_t>), dim3(cdiv((int64_t)R * N, 256)), dim3(256), 0, st, B, (int64_t)R, N, (bf16_t*)dB, N);
+    launch_gemm_tn<bf16_t, 2>(h, KID_WGRAD, g, ep);
+  } else {
+    hipLaunchKernelGGL((k_from_f32<float>), dim3(cdiv((int64_t)R * M, 256)), dim3(256), 0, st, A, (int64_t)R, M, (float*)dA, M);
+    hipLaunchKernelGGL((k_from_f32<float>), dim3(cdiv((int64_t)R * N, 256)), dim3(256), 0, st, B, (int64_t)R, N, (float*)dB, N);
+    launch_gemm_tn<float, 2>(h, KID_WGRAD, g, ep);
   }
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipFree(dA));

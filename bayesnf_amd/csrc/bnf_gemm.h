@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
     const float gamma = softplusf(th[ep.off_layer_scale]);
     const float alpha = sigmoidf(th[ep.off_act_weight]);
     T* oz = reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch;
-    T* ot = reinterpret_cast<T*>(ep.out_t) + (int64_t)e * ep.actt_batch;
+    T* ot = ep.out_t ? reinterpret_cast<T*>(ep.out_t) + (int64_t)e * ep.actt_batch : nullptr;
     T* tile = reinterpret_cast<T*>(smem);
     float s_alpha = 0.f, s_gamma = 0.f, colsum[2] = {0.f, 0.f};
 #pragma unroll
@@ -438,13 +438,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
 #pragma unroll
             for (int q = 0; q < 4; ++q) Elem<T>::store(tile + (lr + q) * kPitch + lc, zv[q]);
           }
-          T* pt = ot + (int64_t)n * ep.ldt + mb;
-          if (ep.ablate & 1) asm volatile("" ::"v"(zv[0] + zv[1] + zv[2] + zv[3]));
-          else if (full) store4(pt, zv[0], zv[1], zv[2], zv[3]);
-          else
+          if (ot) {
+            T* pt = ot + (int64_t)n * ep.ldt + mb;
+            if (full) store4(pt, zv[0], zv[1], zv[2], zv[3]);
+            else
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (mb + q < g.M) Elem<T>::store(pt + q, zv[q]);
+              for (int q = 0; q < 4; ++q)
+                if (mb + q < g.M) Elem<T>::store(pt + q, zv[q]);
+          }
         }
     }
     __syncthreads();
@@ -474,6 +475,210 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
       atomicAdd(&gr[ep.off_act_weight], alpha * (1.f - alpha) * ta);
       atomicAdd(&gr[ep.off_layer_scale], sigmoidf(th[ep.off_layer_scale]) * tg / gamma);
     }
+  }
+}
+
+// ===========================================================================
+// gemm_tn -- weight-gradient contraction on ROW-MAJOR operands:
+//     C[i][j] = scale * sum_r A[r][i] * B[r][j]        (dK_l = H_l^T dZ_l / sqrt n_l)
+// A (rows, a_ld) and B (rows, b_ld) are the activations exactly as the forward /
+// backward kernels leave them (batch row = slow axis), so no transposed copies
+// exist anywhere.  The contraction index r is the slow axis of both LDS tiles; the
+// MFMA fragments (8 consecutive r for one column) come from the gfx950 transpose
+// read ds_read_b64_tr_b16 (semantics measured with scripts/probes/tr_read_probe.hip:
+// within each 16-lane group, lane i receives element (i % 4) of the 8-byte datum
+// addressed by lane 4j + i/4, j = 0..3 -- i.e. a 4 x 16 block read by rows comes
+// back by columns).  f32 operands use plain 4-byte reads (the f32 MFMA takes one
+// value per lane).
+// Tile: 128 (i) x 128 (j) per block, 4 waves (2 x 2), K tile = 128-byte... rows:
+// kTnRows batch rows per stage, row pitch 256 B (bf16) / 512 B (f32), 64-byte
+// segments XOR-swizzled with (row & 3) so the four rows of a transpose read fall
+// on disjoint banks; filled by LDS-DMA with the swizzle on the source address.
+// ===========================================================================
+template <typename T>
+struct TnCfg;
+template <>
+struct TnCfg<bf16_t> {
+  static constexpr int kRows = 64;        // batch rows per K tile
+  static constexpr int kRowBytes = 256;   // 128 columns x 2 B
+};
+template <>
+struct TnCfg<float> {
+  static constexpr int kRows = 32;
+  static constexpr int kRowBytes = 512;
+};
+
+template <typename T, int TAG>
+__global__ __launch_bounds__(kThreads, 2) void gemm_tn(const GemmArgs g, const EpiArgs ep) {
+  using C_ = TnCfg<T>;
+  constexpr int kRows = C_::kRows, kRB = C_::kRowBytes;
+  constexpr int kOpBytes = kRows * kRB;       // 16 KiB per operand per stage
+  constexpr int kStage = 2 * kOpBytes;        // 32 KiB
+  constexpr int kChunksPerRow = kRB / 16;     // 16 (bf16) / 32 (f32)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const uint32_t per_member = (uint32_t)(g.tiles_m * g.tiles_n * g.splitk);
+  uint32_t w = xcd_remap(blockIdx.x, gridDim.x);
+  const int e = (int)(w / per_member);
+  w -= (uint32_t)e * per_member;
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int split = (int)(w / (uint32_t)tiles);
+  w -= (uint32_t)split * tiles;
+  const int tm = (int)(w / (uint32_t)g.tiles_n), tn = (int)(w % (uint32_t)g.tiles_n);
+  const int m0 = tm * kBM, n0 = tn * kBN;   // m: columns of A (i), n: columns of B (j)
+
+  const int nk_total = g.K / kRows;           // g.K = padded batch rows, multiple of 64
+  const int nk_per = (nk_total + g.splitk - 1) / g.splitk;
+  const int kt0 = split * nk_per;
+  const int kt1 = min(nk_total, kt0 + nk_per);
+
+  const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)e * g.a_batch * Elem<T>::kBytes;
+  const char* Bb = reinterpret_cast<const char*>(g.B) + (int64_t)e * g.b_batch * Elem<T>::kBytes;
+
+  // ---- LDS-DMA staging: one wave instruction = 1 KiB = 1024/kRB rows ---------------
+  constexpr int kInstrPerOp = kOpBytes / 1024;          // 16 per operand per tile
+  constexpr int kPerWave = kInstrPerOp / 4;             // 4
+  constexpr int kRowsPerInstr = 1024 / kRB;             // 4 (bf16) / 2 (f32)
+  int src_off_a[kPerWave], src_off_b[kPerWave], lds_base[kPerWave];
+  // valid bytes of a tile row, from the (16-byte aligned, zero padded) leading dimensions
+  const int a_cols_bytes = min(g.a_ld - m0, kBM) * Elem<T>::kBytes;
+  const int b_cols_bytes = min(g.b_ld - n0, kBN) * Elem<T>::kBytes;
+#pragma unroll
+  for (int i = 0; i < kPerWave; ++i) {
+    const int q = wave * kPerWave + i;                  // instruction index 0..15
+    const int row = q * kRowsPerInstr + lane / kChunksPerRow;
+    const int cp = lane % kChunksPerRow;                // physical 16-byte chunk
+    const int c = cp ^ ((row & 3) << 2);                // logical chunk: 64-byte segment ^= row & 3
+    // columns beyond the matrix edge are clamped to the last valid 16-byte chunk
+    // (their products land in masked output rows / columns)
+    const int ca = min(c * 16, max(a_cols_bytes - 16, 0));
+    const int cb = min(c * 16, max(b_cols_bytes - 16, 0));
+    src_off_a[i] = row * g.a_ld * Elem<T>::kBytes + m0 * Elem<T>::kBytes + ca;
+    src_off_b[i] = row * g.b_ld * Elem<T>::kBytes + n0 * Elem<T>::kBytes + cb;
+    lds_base[i] = q * 1024;
+  }
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef __attribute__((address_space(1))) const void glb_void_t;
+  auto stage = [&](int buf, int kt) {
+    const int64_t ra = (int64_t)kt * kRows * g.a_ld * Elem<T>::kBytes;
+    const int64_t rb = (int64_t)kt * kRows * g.b_ld * Elem<T>::kBytes;
+    char* sA = smem + buf * kStage;
+    char* sB = sA + kOpBytes;
+#pragma unroll
+    for (int i = 0; i < kPerWave; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(Ab + ra + src_off_a[i]), (lds_void_t*)(sA + lds_base[i]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(Bb + rb + src_off_b[i]), (lds_void_t*)(sB + lds_base[i]), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, kg = lane >> 5;
+
+  if (kt0 < kt1) {
+    stage(0, kt0);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      if (kt + 1 < kt1) stage(buf ^ 1, kt + 1);
+      const char* sA = smem + buf * kStage;
+      const char* sB = sA + kOpBytes;
+      if constexpr (Elem<T>::kBytes == 2) {
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((address_space(3))) s16x4 lds_v4;
+        const int p = lane & 15, half = (lane >> 4) & 1;
+        // per lane: row offset within a 4-row group and column (elements) inside a 32-column tile
+        const int prow = p >> 2, pcol = half * 16 + (p & 3) * 4;
+#pragma unroll
+        for (int ks = 0; ks < kRows / 16; ++ks) {
+          // fragments are assembled as raw dwords (two 64-bit transpose reads each) and
+          // bit-cast once: element-wise inserts into a __bf16 vector miscompile here
+          uint2 ra_[2][2], rb_[2][2];   // [t][i]
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int row = ks * 16 + kg * 8 + t * 4 + prow;
+            const int rsw = (row & 3) << 6;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int ba = (wr * 64 + i * 32 + pcol) * 2, bb = (wc * 64 + i * 32 + pcol) * 2;
+              const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (lds_v4*)(const_cast<char*>(sA) + row * kRB + ((ba & ~63) ^ rsw) + (ba & 63)));
+              const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (lds_v4*)(const_cast<char*>(sB) + row * kRB + ((bb & ~63) ^ rsw) + (bb & 63)));
+              ra_[t][i] = __builtin_bit_cast(uint2, va);
+              rb_[t][i] = __builtin_bit_cast(uint2, vb);
+            }
+          }
+          bf16x8 fa[2], fb[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const u32x4 wa = {ra_[0][i].x, ra_[0][i].y, ra_[1][i].x, ra_[1][i].y};
+            const u32x4 wb = {rb_[0][i].x, rb_[0][i].y, rb_[1][i].x, rb_[1][i].y};
+            fa[i] = __builtin_bit_cast(bf16x8, wa);
+            fb[i] = __builtin_bit_cast(bf16x8, wb);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+      } else {
+        // f32: MFMA step s of group ks contracts rows ks*16 + s (lanes 0-31) and ks*16 + 8 + s (32-63)
+#pragma unroll
+        for (int ks = 0; ks < kRows / 16; ++ks) {
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8) {
+            const int row = ks * 16 + kg * 8 + s8;
+            const int rsw = (row & 3) << 6;
+            float fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int ba = (wr * 64 + i * 32 + frow) * 4, bb = (wc * 64 + i * 32 + frow) * 4;
+              fa[i] = *reinterpret_cast<const float*>(sA + row * kRB + ((ba & ~63) ^ rsw) + (ba & 63));
+              fb[i] = *reinterpret_cast<const float*>(sB + row * kRB + ((bb & ~63) ^ rsw) + (bb & 63));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: scaled f32 store / atomic accumulate into the gradient vector ----
+  const int mw = m0 + wr * 64 + 4 * kg;
+  const int nw = n0 + wc * 64 + frow;
+  float* out = ep.out_f32 ? ep.out_f32 + (int64_t)e * ep.f32_batch
+                          : ep.grad + (int64_t)e * ep.grad_stride + ep.off_out;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = nw + j * 32;
+    if (n >= g.N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + i * 32 + 8 * (r >> 2) + (r & 3);
+        if (m < g.M) {
+          const float v = acc[i][j][r] * ep.scale;
+          if (g.splitk > 1) atomicAdd(&out[(int64_t)m * ep.ld_f32 + n], v);
+          else out[(int64_t)m * ep.ld_f32 + n] = v;
+        }
+      }
   }
 }
 

@@ -361,16 +361,15 @@ __global__ __launch_bounds__(256) void k_row_loss(NetDev nd, RowLossArgs a) {
 //   d alpha ; d k_o = H^T dv / sqrt W with H = act(A) recomputed (the last hidden
 //   output is never stored).
 // One wave owns a 64-column strip and walks `row_tiles` 64-row tiles; lane
-// (rg = lane & 7, cg = lane >> 3) holds an 8 x 8 block, so A^T / dZ^T (8 rows
-// contiguous) and dZ (8 columns contiguous) all move as 16-byte vectors and every
-// wave instruction covers full 128-byte lines.
+// (rg = lane & 7, cg = lane >> 3) holds an 8 x 8 block, so A^T (8 rows contiguous)
+// and dZ (8 columns contiguous) both move as 16-byte vectors and every wave
+// instruction covers full 128-byte lines.
 // ---------------------------------------------------------------------------
 struct LastBwdArgs {
   const float* theta;
   int64_t theta_stride;
   const void* At;        // (W, ldt) last pre-activation, transposed
   void* dZ;              // (rows, W)
-  void* dZt;             // (W, ldt)
   int64_t act_batch, actt_batch;
   int32_t ldt;
   const float* dv;       // (members, dv_batch)
@@ -382,7 +381,7 @@ struct LastBwdArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_last_bwd(NetDev nd, const LastBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_last_bwd(NetDev nd, const LastBwdArgs a) {
   constexpr bool FAST = Elem<T>::kFast;
   const int e = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -400,7 +399,6 @@ __global__ __launch_bounds__(256) void k_last_bwd(NetDev nd, const LastBwdArgs a
   const float alpha = sigmoidf(th[nd.off_law]);
   const T* __restrict__ At = reinterpret_cast<const T*>(a.At) + (int64_t)e * a.actt_batch;
   T* __restrict__ dZ = reinterpret_cast<T*>(a.dZ) + (int64_t)e * a.act_batch;
-  T* __restrict__ dZt = reinterpret_cast<T*>(a.dZt) + (int64_t)e * a.actt_batch;
   const float* __restrict__ dv = a.dv + (int64_t)e * a.dv_batch;
   float kv[8], cs_b[8], cs_k[8];
 #pragma unroll
@@ -420,7 +418,7 @@ __global__ __launch_bounds__(256) void k_last_bwd(NetDev nd, const LastBwdArgs a
     for (int c = 0; c < 8; ++c) raws[c] = load_raw8(At + (int64_t)(j0 + c) * a.ldt + r0);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      float zc[8], avc[8];
+      float avc[8];
       unpack(raws[c], avc);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -431,12 +429,10 @@ __global__ __launch_bounds__(256) void k_last_bwd(NetDev nd, const LastBwdArgs a
         const float da = dh * o.dact;
         s_gamma += da * avv;
         const float z = gamma * da;
-        zc[i] = z;
         dz[i][c] = z;
         cs_b[c] += z;
         cs_k[c] += o.h * dvr[i];
       }
-      store8(dZt + (int64_t)(j0 + c) * a.ldt + r0, zc);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) store8(dZ + (r0 + i) * W + j0, dz[i]);

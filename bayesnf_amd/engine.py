@@ -216,6 +216,16 @@ class Engine:
     torch.cuda.synchronize(self.device)
     return Cout.cpu().numpy()
 
+  def debug_gemm_tn(self, A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """A (R, M), B (R, N) row-major -> A^T B (M, N) through the weight-gradient core."""
+    A = torch.as_tensor(np.ascontiguousarray(A, dtype=np.float32)).to(self.device)
+    B = torch.as_tensor(np.ascontiguousarray(B, dtype=np.float32)).to(self.device)
+    Cout = torch.empty((A.shape[1], B.shape[1]), dtype=torch.float32, device=self.device)
+    _native.check(self.lib.bnf_debug_gemm_tn(self.handle, _ptr(A), _ptr(B), A.shape[0], A.shape[1],
+                                             B.shape[1], _ptr(Cout)), 'bnf_debug_gemm_tn')
+    torch.cuda.synchronize(self.device)
+    return Cout.cpu().numpy()
+
   def profile(self, kernel):
     """kernel: '*' (all), a kernel name, or None (off)."""
     arg = None if kernel is None else str(kernel).encode()

@@ -196,6 +196,12 @@ int bnf_debug_activation(bnf_handle* h, int32_t what, float* out);
 int bnf_debug_gemm_nt(bnf_handle* h, const float* A, const float* Bt, int32_t M,
                       int32_t N, int32_t K, float* C);
 
+/* Raw C = A^T * B of the weight-gradient core on row-major operands (A (R,M), B (R,N),
+ * R a multiple of 64, M and N multiples of 8; inputs f32, converted to the handle dtype)
+ * -> C (M,N) f32. */
+int bnf_debug_gemm_tn(bnf_handle* h, const float* A, const float* B, int32_t R, int32_t M,
+                      int32_t N, float* C);
+
 /* Per-kernel HIP-event timing on the handle's stream.  kernel = "*" brackets
  * every launch with an event pair, a kernel name (as reported by
  * bnf_profile_read, e.g. "gemm_fwd") only that kernel, NULL switches it off.

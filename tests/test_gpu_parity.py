@@ -42,6 +42,25 @@ def test_contraction_core(dtype, shape):
   eng.close()
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(64, 128, 128), (320, 64, 192), (1024, 512, 512), (128, 56, 200)])
+def test_weight_gradient_core(dtype, shape):
+  """C = A^T B on row-major operands (transpose reads in LDS)."""
+  R, M, N = shape
+  net, model, X, y = util.make_problem(n_rows=8, width=64, depth=1)
+  eng = _engine(net, X, y, members=1, compute_dtype=dtype)
+  rng = np.random.default_rng(R + M)
+  A = rng.standard_normal((R, M)).astype(np.float32)
+  B = rng.standard_normal((R, N)).astype(np.float32)
+  Cd = eng.debug_gemm_tn(A, B)
+  if dtype == 'bf16':
+    A = torch.tensor(A).bfloat16().float().numpy()
+    B = torch.tensor(B).bfloat16().float().numpy()
+  ref = A.astype(np.float64).T @ B.astype(np.float64)
+  assert util.rel_err(Cd, ref) < 2e-6, util.rel_err(Cd, ref)
+  eng.close()
+
+
 # --------------------------------------------------------------------------- forward / grads
 @pytest.mark.parametrize('depth,width,n_rows', [(2, 64, 300), (1, 128, 130), (3, 192, 257)])
 def test_forward_and_grad_fp32(depth, width, n_rows):
