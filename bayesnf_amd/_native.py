@@ -62,7 +62,7 @@ class BnfConfig(C.Structure):
       ('off_act_weight', C.c_int32),
       ('n_rows', C.c_int64), ('batch', C.c_int64),
       ('members', C.c_int32), ('member_offset', C.c_int64),
-      ('vi_samples', C.c_int32), ('forward_only', C.c_int32),
+      ('vi_samples', C.c_int32), ('forward_only', C.c_int32), ('pipeline', C.c_int32),
       ('learning_rate', C.c_float), ('prior_weight', C.c_float),
       ('kl_weight', C.c_float),
       ('seed', C.c_uint64),
@@ -158,7 +158,8 @@ def fold_in(seed_u64: int, data: int) -> int:
 
 def make_config(net: _spec.NetSpec, *, device, dtype, mode, n_rows, batch,
                 members, member_offset, seed, learning_rate=0.005,
-                prior_weight=1.0, kl_weight=1.0, vi_samples=1, forward_only=False) -> BnfConfig:
+                prior_weight=1.0, kl_weight=1.0, vi_samples=1, forward_only=False,
+                pipeline=0) -> BnfConfig:
   """Serialise a NetSpec + run arguments into the C struct."""
   if net.D > MAX_INPUTS:
     raise ValueError(f'at most {MAX_INPUTS} input columns are supported')
@@ -210,6 +211,7 @@ def make_config(net: _spec.NetSpec, *, device, dtype, mode, n_rows, batch,
   c.members, c.member_offset = int(members), int(member_offset)
   c.vi_samples = int(vi_samples)
   c.forward_only = 1 if forward_only else 0
+  c.pipeline = {'auto': 0, 'layers': 1, 'fused': 2}.get(pipeline, pipeline)
   c.learning_rate = float(learning_rate)
   c.prior_weight = float(prior_weight)
   c.kl_weight = float(kl_weight)

@@ -24,6 +24,7 @@
 #include "../../include/bnf.h"
 #include "bnf_gemm.h"
 #include "bnf_kernels.h"
+#include "bnf_fused.h"
 
 using namespace bnf;
 
@@ -51,11 +52,12 @@ static int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 enum KernelId {
   KID_PACK = 0, KID_FEAT, KID_FWD0, KID_FWD, KID_ROWLOSS, KID_LASTBWD, KID_DGRAD, KID_DGRAD0,
-  KID_FEATBWD, KID_WGRAD0, KID_WGRAD, KID_ADAM, KID_VISAMPLE, KID_VIADAM, KID_COUNT
+  KID_FEATBWD, KID_WGRAD0, KID_WGRAD, KID_ADAM, KID_VISAMPLE, KID_VIADAM, KID_FUSED, KID_COUNT
 };
 static const char* kKernelNames[KID_COUNT] = {
     "pack_weights", "featurize", "gemm_fwd_l0", "gemm_fwd", "row_loss", "last_bwd", "gemm_dgrad",
-    "gemm_dgrad0", "feat_bwd", "gemm_wgrad_l0", "gemm_wgrad", "adam_map", "vi_sample", "vi_adam"};
+    "gemm_dgrad0", "feat_bwd", "gemm_wgrad_l0", "gemm_wgrad", "adam_map", "vi_sample", "vi_adam",
+    "fused_fwd_bwd"};
 
 struct TimedLaunch {
   int kid;
@@ -93,6 +95,12 @@ struct bnf_handle {
   int64_t pack_batch[BNF_MAX_LAYERS];
   float* dH0 = nullptr; float* out = nullptr; float* ybat = nullptr; float* loss_raw = nullptr;
   float* vacc = nullptr; float* dv = nullptr;   // output-layer dot accumulator, d loss / d v
+  // fused row-panel pipeline
+  bool fused = false;
+  int fused_grid = 0;
+  size_t fused_lds = 0;
+  void* Wf[BNF_MAX_LAYERS]; void* Wb[BNF_MAX_LAYERS];   // fragment-major packed weights
+  void* spill = nullptr;
   float* qscratch = nullptr;  // quantile partials: 2*1024*2 + 2 floats
   float* dbg_a = nullptr; float* dbg_b = nullptr;  // small debug staging (gmu/grho)
   uint8_t* is_matrix = nullptr;
@@ -127,16 +135,23 @@ static size_t carve(bnf_handle* h, char* base) {
   h->H0 = take((size_t)Ev * Bp * Fp * es);
   h->H0t = nullptr;   // no transposed copies: the weight-gradient contraction reads row-major (gemm_tn)
   for (int l = 0; l < h->L; ++l) {
-    h->A[l] = take((size_t)Ev * W * Bp * es);                                  // A_l^T (W, Bp)
+    h->A[l] = h->fused ? nullptr : take((size_t)Ev * W * Bp * es);             // A_l^T (W, Bp)
     h->H[l] = (l < h->L - 1) ? take((size_t)Ev * Bp * W * es) : nullptr;       // H_{l+1} (Bp, W)
     h->Ht[l] = nullptr;
     h->dZ[l] = fo ? nullptr : take((size_t)Ev * Bp * W * es);
     h->dZt[l] = nullptr;
     const int64_t npad = (l == 0) ? Fp : W;
     h->pack_batch[l] = npad * W;
-    h->Kn[l] = take((size_t)Ev * npad * W * es);
-    h->Kt[l] = take((size_t)Ev * npad * W * es);
+    h->Kn[l] = h->fused ? nullptr : take((size_t)Ev * npad * W * es);
+    h->Kt[l] = h->fused ? nullptr : take((size_t)Ev * npad * W * es);
   }
+  for (int l = 0; l < h->L; ++l) {
+    const int64_t npad = (l == 0) ? Fp : W;
+    h->Wf[l] = h->fused ? take((size_t)Ev * npad * W * es) : nullptr;
+    h->Wb[l] = h->fused ? take((size_t)Ev * npad * W * es) : nullptr;
+  }
+  h->spill = (h->fused && h->L > 1)
+                 ? take((size_t)h->fused_grid * (h->L - 1) * kFusedBM * W * es) : nullptr;
   h->dH0 = fo ? nullptr : (float*)take((size_t)Ev * Fp * Bp * 4);            // dH0^T (Fp, Bp)
   h->out = (float*)take((size_t)Ev * Bp * 4);
   h->vacc = (float*)take((size_t)Ev * Bp * 4);
@@ -308,6 +323,32 @@ struct LossSink {
   float* raw;                                  // optional per-virtual-member raw loss
 };
 
+// weight gradients of every layer from the row-major H_l / dZ_l left in HBM
+template <typename T>
+static void run_wgrad(bnf_handle* h, int nmem) {
+  const int64_t Bp = h->Bp;
+  const int L = h->L;
+  for (int l = 0; l < L; ++l) {
+    // dK_l = H_l^T . dZ_l / sqrt(fan_in_l): contraction over the batch rows of the
+    // row-major activations (transpose reads in LDS, no transposed copies in HBM)
+    GemmArgs g{};
+    g.A = (l == 0) ? h->H0 : h->H[l - 1];
+    g.a_ld = (l == 0) ? h->Fp : h->W; g.a_batch = Bp * g.a_ld;
+    g.B = h->dZ[l]; g.b_ld = h->W; g.b_batch = Bp * h->W;
+    g.M = (l == 0) ? h->F : h->W; g.N = h->W; g.K = (int)Bp; g.members = nmem;
+    const int tiles = ((g.M + kBM - 1) / kBM) * ((g.N + kBN - 1) / kBN);
+    const int nk = (int)(Bp / (h->bf16 ? 64 : 32));
+    int sk = (1024 + nmem * tiles - 1) / (nmem * tiles);
+    sk = std::max(1, std::min(sk, std::max(1, nk / 4)));
+    g.splitk = sk;
+    EpiArgs ep{};
+    ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->W));
+    ep.grad = h->grad; ep.grad_stride = h->P; ep.off_out = h->nd.off_kernel[l]; ep.ld_f32 = h->W;
+    if (l == 0) launch_gemm_tn<T, 0>(h, KID_WGRAD0, g, ep);
+    else launch_gemm_tn<T, 1>(h, KID_WGRAD, g, ep);
+  }
+}
+
 // backward of one step: fills h->grad (likelihood part)
 template <typename T>
 static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs,
@@ -375,25 +416,93 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
                        (int64_t)h->P, rows, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->grad,
                        (int64_t)h->P);
   }
-  for (int l = 0; l < L; ++l) {
-    // dK_l = H_l^T . dZ_l / sqrt(fan_in_l): contraction over the batch rows of the
-    // row-major activations (transpose reads in LDS, no transposed copies in HBM)
-    GemmArgs g{};
-    g.A = (l == 0) ? h->H0 : h->H[l - 1];
-    g.a_ld = (l == 0) ? h->Fp : h->W; g.a_batch = Bp * g.a_ld;
-    g.B = h->dZ[l]; g.b_ld = h->W; g.b_batch = Bp * h->W;
-    g.M = (l == 0) ? h->F : h->W; g.N = h->W; g.K = (int)Bp; g.members = nmem;
-    const int tiles = ((g.M + kBM - 1) / kBM) * ((g.N + kBN - 1) / kBN);
-    const int nk = (int)(Bp / (h->bf16 ? 64 : 32));
-    int sk = (1024 + nmem * tiles - 1) / (nmem * tiles);
-    sk = std::max(1, std::min(sk, std::max(1, nk / 4)));
-    g.splitk = sk;
-    EpiArgs ep{};
-    ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->W));
-    ep.grad = h->grad; ep.grad_stride = h->P; ep.off_out = h->nd.off_kernel[l]; ep.ld_f32 = h->W;
-    if (l == 0) launch_gemm_tn<T, 0>(h, KID_WGRAD0, g, ep);
-    else launch_gemm_tn<T, 1>(h, KID_WGRAD, g, ep);
+  run_wgrad<T>(h, nmem);
+}
+
+// ---------------------------------------------------------------------------
+// fused row-panel pipeline: pack fragments -> k_fused_fwd_bwd -> gemm_tn weight gradients
+// ---------------------------------------------------------------------------
+template <typename T>
+static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
+  LaunchScope ls(h, KID_PACK);
+  for (int l = 0; l < h->L; ++l) {
+    const int n_in = (l == 0) ? h->F : h->W, n_pad = (l == 0) ? h->Fp : h->W;
+    const int64_t threads = (int64_t)n_pad * h->W / 8;
+    for (int which = 0; which < 2; ++which)
+      hipLaunchKernelGGL((k_pack_fragments<T>), dim3(cdiv(threads, 256), (unsigned)nmem), dim3(256), 0,
+                         h->stream, theta, (int64_t)h->P, h->nd.off_kernel[l], n_in, n_pad, h->W, which,
+                         (T*)(which == 0 ? h->Wf[l] : h->Wb[l]), h->pack_batch[l]);
   }
+}
+
+template <typename T, int NT>
+static void launch_fused(bnf_handle* h, const FusedArgs& fa) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_fwd_bwd<T, NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  LaunchScope ls(h, KID_FUSED);
+  hipLaunchKernelGGL((k_fused_fwd_bwd<T, NT>), dim3((unsigned)h->fused_grid), dim3(kFusedThreads),
+                     h->fused_lds, h->stream, fa);
+}
+
+template <typename T>
+static void run_fused(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs, float c,
+                      const LossSink& sink) {
+  const int64_t Bp = h->Bp;
+  run_pack_fragments<T>(h, theta, nmem);
+  {  // features (+ gathered targets) of every batch row, row-major: also the layer-0 wgrad operand
+    LaunchScope ls(h, KID_FEAT);
+    dim3 grid(cdiv(h->B, kFeatRows), (unsigned)nmem);
+    const size_t lds = (size_t)kFeatRows * (h->Fp + 16 / h->es) * h->es;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_featurize<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((k_featurize<T>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, h->X, h->stab,
+                       h->y, theta, (int64_t)h->P, h->B, (T*)h->H0, Bp * h->Fp, (T*)nullptr,
+                       (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp);
+  }
+  FusedArgs fa{};
+  fa.Fp = h->Fp; fa.F = h->F; fa.L = h->L;
+  for (int l = 0; l <= h->L; ++l) fa.off_bias[l] = h->nd.off_bias[l];
+  for (int l = 0; l < h->L; ++l) fa.off_ls[l] = h->nd.off_ls[l];
+  fa.off_ko = h->nd.off_kernel[h->L]; fa.off_os = h->nd.off_os; fa.off_lns = h->nd.off_lns;
+  fa.off_law = h->nd.off_law;
+  fa.theta = theta; fa.theta_stride = h->P; fa.B = h->B;
+  fa.n_tiles = (int32_t)((h->B + kFusedBM - 1) / kFusedBM); fa.members = nmem;
+  for (int l = 0; l < h->L; ++l) {
+    fa.Wfwd[l] = h->Wf[l]; fa.Wbwd[l] = h->Wb[l];
+    fa.wfwd_batch[l] = h->pack_batch[l]; fa.wbwd_batch[l] = h->pack_batch[l];
+    fa.H[l] = (l == 0) ? h->H0 : h->H[l - 1];
+    fa.dZ[l] = h->dZ[l];
+  }
+  fa.h0_batch = Bp * h->Fp; fa.act_batch = Bp * h->W;
+  fa.ybat = h->ybat; fa.yb_batch = Bp;
+  fa.dH0t = h->dH0; fa.dh0_batch = (int64_t)h->Fp * Bp; fa.ldt = (int32_t)Bp;
+  fa.spill = h->spill;
+  fa.out = h->out; fa.out_batch = Bp;
+  fa.grad = h->grad; fa.grad_stride = h->P;
+  fa.loss = sink.loss; fa.loss_stride = sink.stride; fa.S = h->S; fa.loss_scale = sink.scale;
+  fa.c = c; fa.loss_raw = sink.raw;
+  fa.ablate = h->ablate;
+  switch (h->W) {
+    case 128: launch_fused<T, 1>(h, fa); break;
+    case 256: launch_fused<T, 2>(h, fa); break;
+    default: launch_fused<T, 4>(h, fa); break;
+  }
+  {
+    LaunchScope ls(h, KID_FEATBWD);
+    dim3 grid(cdiv(h->B, 256), (unsigned)nmem);
+    hipLaunchKernelGGL(k_feat_bwd, grid, dim3(256), 0, h->stream, h->nd, rs, h->X, h->stab, theta,
+                       (int64_t)h->P, h->B, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->grad,
+                       (int64_t)h->P);
+  }
+  run_wgrad<T>(h, nmem);
 }
 
 static RowSrc make_rowsrc(const bnf_handle* h, int64_t epoch, int64_t step) {
@@ -421,10 +530,14 @@ template <typename T>
 static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& sink, bool apply) {
   const RowSrc rs = make_rowsrc(h, epoch, step);
   const int E = h->cfg.members;
-  run_pack<T>(h, h->params, E);
-  run_forward<T>(h, h->params, E, rs, h->X, h->stab, h->y, h->B, true);
   const float c = (float)((double)h->N / (double)h->B);
-  run_backward<T>(h, h->params, E, rs, h->B, c, sink);
+  if (h->fused) {
+    run_fused<T>(h, h->params, E, rs, c, sink);
+  } else {
+    run_pack<T>(h, h->params, E);
+    run_forward<T>(h, h->params, E, rs, h->X, h->stab, h->y, h->B, true);
+    run_backward<T>(h, h->params, E, rs, h->B, c, sink);
+  }
   AdamArgs a{};
   a.theta = h->params; a.m = h->state; a.v = h->state + (int64_t)E * h->P; a.grad = h->grad;
   a.stride = h->P; a.P = h->P; a.off_shape = h->nd.off_shape;
@@ -463,12 +576,16 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
                        h->cfg.member_offset, (uint64_t)step, (uint32_t)STREAM_VI_EPS, h->theta_c,
                        (int64_t)S * h->P, (int64_t)h->P);
   }
-  run_pack<T>(h, h->theta_c, h->Ev);
-  run_forward<T>(h, h->theta_c, h->Ev, rs, h->X, h->stab, h->y, h->B, true);
   const float kl = h->cfg.kl_weight;
   const float c = (float)((double)h->N / (double)h->B / (double)kl);
   LossSink sink{loss, loss_stride, kl / (float)S, nullptr};
-  run_backward<T>(h, h->theta_c, h->Ev, rs, h->B, c, sink);
+  if (h->fused) {
+    run_fused<T>(h, h->theta_c, h->Ev, rs, c, sink);
+  } else {
+    run_pack<T>(h, h->theta_c, h->Ev);
+    run_forward<T>(h, h->theta_c, h->Ev, rs, h->X, h->stab, h->y, h->B, true);
+    run_backward<T>(h, h->theta_c, h->Ev, rs, h->B, c, sink);
+  }
   ViAdamArgs a{};
   const int64_t EP = (int64_t)E * h->P;
   a.mu = mu; a.rho = rho;
@@ -589,6 +706,23 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   }
   for (int k = 0; k < KID_COUNT; ++k) { h->acc_ms[k] = 0; h->acc_calls[k] = 0; }
   if (const char* ab = getenv("BNF_ABLATE")) h->ablate = atoi(ab);
+  {
+    // fused row-panel pipeline: training handles with W = 128 / 256 / 512 and F <= 128
+    int want = cfg->pipeline;  // 0 auto, 1 unfused, 2 fused
+    if (const char* pf = getenv("BNF_PIPELINE")) want = atoi(pf);
+    const bool can = !cfg->forward_only && (h->W == 128 || h->W == 256 || h->W == 512) && h->Fp <= 128;
+    if (want == 2 && !can) {
+      delete h;
+      return fail(BNF_ERR_INVALID, "fused pipeline needs a training handle with width 128/256/512 and <= 128 features");
+    }
+    h->fused = can && want == 2;   // opt-in: measured slower than the layer kernels
+    if (h->fused) {
+      h->fused_lds = fused_lds_bytes(h->W, h->Fp, h->es);
+      const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / h->fused_lds)));
+      const int64_t items = (int64_t)h->Ev * ((h->B + kFusedBM - 1) / kFusedBM);
+      h->fused_grid = (int)std::min<int64_t>(items, (int64_t)prop.multiProcessorCount * per_cu);
+    }
+  }
   h->ws_bytes = carve(h, nullptr);
   *out = h;
   return BNF_OK;
@@ -713,6 +847,7 @@ int bnf_forward(bnf_handle* h, const float* theta, int64_t n_members, const floa
                 int64_t n_rows, float* loc, float* aux) {
   if (!h || !h->bound) return fail(BNF_ERR_STATE, "bnf_forward before bnf_bind");
   if (!theta || !Xnew || !loc || n_members < 1 || n_rows < 1) return fail(BNF_ERR_INVALID, "argument");
+  if (h->fused) return fail(BNF_ERR_STATE, "bnf_forward needs a forward_only (or pipeline=1) handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   const int64_t row_chunk = h->Bp, mem_chunk = h->Ev;
   RowSrc rs{};
@@ -963,6 +1098,8 @@ double bnf_kernel_flops(const bnf_handle* h, const char* name) {
     return 2.0 * Ev * B * F * W;
   if (!strcmp(name, "gemm_fwd") || !strcmp(name, "gemm_dgrad") || !strcmp(name, "gemm_wgrad"))
     return 2.0 * Ev * B * W * W;
+  if (!strcmp(name, "fused_fwd_bwd"))  // forward + dgrad contractions of every layer + output layer
+    return 4.0 * Ev * B * (F * W + (h->L - 1) * W * W) + 6.0 * Ev * B * W;
   return 0.0;
 }
 

@@ -159,15 +159,30 @@ struct ActOut {
   float h, dact, ediff;
 };
 
+#ifdef BNF_EXP_LIBM
+#define BNF_EXP2(x) exp2f(x)
+#else
+#define BNF_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
+#ifdef BNF_RCP_DIV
+#define BNF_RCP(x) (1.0f / (x))
+#else
+#define BNF_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
+
 template <bool FAST>
 __device__ __forceinline__ ActOut act_eval(float a, float alpha) {
   ActOut o;
   float th, el, dexp;
   if constexpr (FAST) {
     // one v_exp_f32 + one v_rcp_f32:  e1 = exp(-|a|), e2 = e1^2
-    const float e1 = __builtin_amdgcn_exp2f(fabsf(a) * -1.44269504088896340736f);
+    const float e1 = BNF_EXP2(fabsf(a) * -1.44269504088896340736f);
     const float e2 = e1 * e1;
-    const float r = __builtin_amdgcn_rcpf(1.f + e2);
+    float r = BNF_RCP(1.f + e2);
+    // Keep the reciprocal opaque: with both raw transcendental builtins visible, hipcc 7.2
+    // mis-optimises the column reductions that consume this value inside the fused kernel
+    // (wrong d bias / d k_o; every variant that hides either builtin is correct -- measured).
+    asm volatile("" : "+v"(r));
     th = copysignf((1.f - e2) * r, a);
     el = a > 0.f ? a : e1 - 1.f;
     dexp = a > 0.f ? 1.f : e1;
@@ -186,9 +201,10 @@ template <bool FAST>
 __device__ __forceinline__ float act_fwd(float a, float alpha) {
   float th, el;
   if constexpr (FAST) {
-    const float e1 = __builtin_amdgcn_exp2f(fabsf(a) * -1.44269504088896340736f);
+    const float e1 = BNF_EXP2(fabsf(a) * -1.44269504088896340736f);
     const float e2 = e1 * e1;
-    const float r = __builtin_amdgcn_rcpf(1.f + e2);
+    float r = BNF_RCP(1.f + e2);
+    asm volatile("" : "+v"(r));
     th = copysignf((1.f - e2) * r, a);
     el = a > 0.f ? a : e1 - 1.f;
   } else {

@@ -40,7 +40,7 @@ class Engine:
                members=1, member_offset=0, seed=0, learning_rate=0.005,
                prior_weight=1.0, kl_weight=1.0, vi_samples=1,
                compute_dtype=None, forward_only=False, row_capacity=None,
-               device_index=None):
+               device_index=None, pipeline='auto'):
     self.lib = _native.load()
     if not torch.cuda.is_available():
       raise RuntimeError(
@@ -74,7 +74,8 @@ class Engine:
         n_rows=n_rows, batch=batch, members=members,
         member_offset=member_offset, seed=_native.seed_to_u64(seed),
         learning_rate=learning_rate, prior_weight=prior_weight,
-        kl_weight=kl_weight, vi_samples=self.S, forward_only=forward_only)
+        kl_weight=kl_weight, vi_samples=self.S, forward_only=forward_only,
+        pipeline=pipeline)
     self.cfg = cfg
     handle = C.c_void_p()
     _native.check(self.lib.bnf_create(C.byref(cfg), C.byref(handle)), 'bnf_create')

@@ -104,6 +104,8 @@ typedef struct bnf_config {
   int32_t vi_samples;       /* S = sample_size_divergence (VI), else 1 */
   int32_t forward_only;     /* 1: handle is used for bnf_forward / quantiles only
                                (no backward buffers are carved, bnf_train refuses) */
+  int32_t pipeline;         /* train-step kernels: 0 auto, 1 layer-by-layer kernels, 2 fused row-panel
+                               forward+backward (needs width 128/256/512, <= 128 features) */
   float   learning_rate;
   float   prior_weight;     /* 1 MAP, 0 MLE (inference.py:561-569) */
   float   kl_weight;        /* VI (inference.py:689-702) */

@@ -44,21 +44,30 @@ def gemm_diag():
     eng.close()
 
 
-def stage_diag(dtype, depth=2, width=64, n_rows=300, pw=1.0):
+def stage_diag(dtype, depth=2, width=64, n_rows=300, pw=1.0, pipeline='auto'):
   net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth)
   E = 3
   theta = util.random_theta(model, E)
-  eng = Engine(net, X=X, y=y, members=E, prior_weight=pw, compute_dtype=dtype)
+  eng = Engine(net, X=X, y=y, members=E, prior_weight=pw, compute_dtype=dtype, pipeline=pipeline)
   eng.set_params(theta)
   loss_d, g_d = eng.debug_loss_and_grad()
   out_o, ch = O.forward(model, theta, X, keep=True)
   loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows, prior_weight=pw)
-  print(f'[{dtype} depth={depth} W={width} N={n_rows} pw={pw}]')
+  print(f'[{dtype} depth={depth} W={width} N={n_rows} pw={pw} pipeline={pipeline}]')
   print('  H0 max abs err', float(np.max(np.abs(eng.debug_activation(0) - ch['Hs'][0]))))
   for l in range(depth):
-    print(f'  A{l} rel', util.rel_err(eng.debug_activation(100 + l), ch['As'][l]),
-          f' H{l+1} rel', util.rel_err(eng.debug_activation(1 + l), ch['Hs'][l + 1])
-          if l < depth - 1 else '(not stored)')
+    try:
+      print(f'  A{l} rel', util.rel_err(eng.debug_activation(100 + l), ch['As'][l]))
+    except (RuntimeError, ValueError):
+      print(f'  A{l} (kept on chip)')
+    if l < depth - 1:
+      print(f'  H{l+1} rel', util.rel_err(eng.debug_activation(1 + l), ch['Hs'][l + 1]))
+  for l in range(depth):
+    try:
+      dz = eng.debug_activation(300 + l)
+      print(f'  dZ{l} finite', bool(np.all(np.isfinite(dz))), 'max', float(np.abs(dz).max()))
+    except (RuntimeError, ValueError):
+      pass
   print('  out rel', util.rel_err(eng.debug_activation(200), out_o))
   print('  loss dev', loss_d, ' oracle', loss_o)
   errs = util.per_leaf_rel_err(model, g_d, g_o)
@@ -88,6 +97,11 @@ if __name__ == '__main__':
   for name, fn in [('gemm', gemm_diag),
                    ('stages fp32', lambda: stage_diag('fp32')),
                    ('stages fp32 depth3 W192 N257', lambda: stage_diag('fp32', 3, 192, 257)),
+                   ('FUSED fp32 depth1 W128', lambda: stage_diag('fp32', 1, 128, 130, pipeline='fused')),
+                   ('FUSED fp32 depth2 W128', lambda: stage_diag('fp32', 2, 128, 300, pipeline='fused')),
+                   ('FUSED fp32 depth3 W256', lambda: stage_diag('fp32', 3, 256, 257, pipeline='fused')),
+                   ('FUSED fp32 depth2 W512', lambda: stage_diag('fp32', 2, 512, 100, pipeline='fused')),
+                   ('FUSED bf16 depth2 W256', lambda: stage_diag('bf16', 2, 256, 300, pipeline='fused')),
                    ('stages fp32 mle', lambda: stage_diag('fp32', pw=0.0)),
                    ('stages bf16', lambda: stage_diag('bf16')),
                    ('train fp32', lambda: train_diag('fp32')),

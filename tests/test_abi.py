@@ -37,7 +37,7 @@ def test_config_struct_layout_matches_c(tmp_path):
   probe = tmp_path / 'probe.c'
   fields = ['abi_version', 'n_groups', 'group_scale_off', 'input_scale', 'n_freqs', 'harmonic',
             'interact', 'off_bias', 'off_act_weight', 'n_rows', 'batch', 'members',
-            'member_offset', 'vi_samples', 'forward_only', 'learning_rate', 'kl_weight', 'seed']
+            'member_offset', 'vi_samples', 'forward_only', 'pipeline', 'learning_rate', 'kl_weight', 'seed']
   body = '\n'.join(f'  printf("{f} %zu\\n", offsetof(bnf_config, {f}));' for f in fields)
   probe.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bnf.h"\nint main(){\n'
                    f'  printf("sizeof %zu\\n", sizeof(bnf_config));\n{body}\n  return 0;}}\n')

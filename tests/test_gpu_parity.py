@@ -62,13 +62,16 @@ def test_weight_gradient_core(dtype, shape):
 
 
 # --------------------------------------------------------------------------- forward / grads
-@pytest.mark.parametrize('depth,width,n_rows', [(2, 64, 300), (1, 128, 130), (3, 192, 257)])
-def test_forward_and_grad_fp32(depth, width, n_rows):
+@pytest.mark.parametrize('depth,width,n_rows,pipeline', [
+    (2, 64, 300, 'layers'), (1, 128, 130, 'layers'), (3, 192, 257, 'layers'), (2, 256, 200, 'layers'),
+    (1, 128, 130, 'fused'), (2, 128, 300, 'fused'), (3, 256, 257, 'fused'), (2, 512, 100, 'fused')])
+def test_forward_and_grad_fp32(depth, width, n_rows, pipeline):
+  """Both train-step pipelines (layer-by-layer kernels / fused row-panel kernel)."""
   net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth)
   E = 3
   theta = util.random_theta(model, E)
   for pw in (1.0, 0.0):
-    eng = _engine(net, X, y, members=E, prior_weight=pw, compute_dtype='fp32')
+    eng = _engine(net, X, y, members=E, prior_weight=pw, compute_dtype='fp32', pipeline=pipeline)
     eng.set_params(theta)
     loss_d, g_d = eng.debug_loss_and_grad()
     out_o, ch = O.forward(model, theta, X, keep=True)
@@ -76,7 +79,8 @@ def test_forward_and_grad_fp32(depth, width, n_rows):
     H0 = eng.debug_activation(0)
     assert np.max(np.abs(H0 - ch['Hs'][0])) < 5e-5
     for l in range(depth):
-      assert util.rel_err(eng.debug_activation(100 + l), ch['As'][l]) < 2e-4, l
+      if pipeline == 'layers':   # the fused kernel keeps pre-activations on chip
+        assert util.rel_err(eng.debug_activation(100 + l), ch['As'][l]) < 2e-4, l
       if l < depth - 1:   # the last hidden output is consumed in registers, never stored
         assert util.rel_err(eng.debug_activation(1 + l), ch['Hs'][l + 1]) < 2e-4, l
     assert util.rel_err(eng.debug_activation(200), out_o) < 2e-4
@@ -87,10 +91,12 @@ def test_forward_and_grad_fp32(depth, width, n_rows):
     eng.close()
 
 
-def test_train_full_batch_fp32():
+@pytest.mark.parametrize('width,pipeline', [(64, 'layers'), (128, 'fused'), (256, 'fused')])
+def test_train_full_batch_fp32(width, pipeline):
   n_rows, E, steps = 200, 4, 30
-  net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=2)
-  eng = _engine(net, X, y, members=E, seed=11, learning_rate=0.005, compute_dtype='fp32')
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=2)
+  eng = _engine(net, X, y, members=E, seed=11, learning_rate=0.005, compute_dtype='fp32',
+                pipeline=pipeline)
   eng.init_params(float(np.log(np.nanstd(y) / 2)))
   theta0 = eng.get_params().astype(np.float64)
   mm = model.matrix_mask()
@@ -110,9 +116,10 @@ def test_train_full_batch_fp32():
   eng.close()
 
 
-def test_minibatch_shuffle_and_training_fp32():
+@pytest.mark.parametrize('width', [64, 128])
+def test_minibatch_shuffle_and_training_fp32(width):
   n_rows, B, E, epochs = 333, 100, 3, 2
-  net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=2)
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=2)
   eng = _engine(net, X, y, members=E, batch=B, seed=5, member_offset=7, compute_dtype='fp32')
   eng.init_params(0.3)
   theta0 = eng.get_params().astype(np.float64)
@@ -141,9 +148,10 @@ def test_minibatch_shuffle_and_training_fp32():
 
 
 # --------------------------------------------------------------------------- VI
-def test_vi_step_and_training_fp32():
+@pytest.mark.parametrize('width', [64, 128])
+def test_vi_step_and_training_fp32(width):
   n_rows, E, S = 150, 2, 3
-  net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=2)
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=2)
   eng = _engine(net, X, y, mode='vi', members=E, vi_samples=S, kl_weight=0.2, seed=3,
                 learning_rate=0.01, compute_dtype='fp32')
   eng.init_params(0.0)
@@ -222,12 +230,13 @@ def test_forward_only_and_quantiles():
 
 
 # --------------------------------------------------------------------------- bf16
-def test_bf16_tracks_fp32():
+@pytest.mark.parametrize('pipeline', ['layers', 'fused'])
+def test_bf16_tracks_fp32(pipeline):
   n_rows, E, steps = 512, 4, 40
   net, model, X, y = util.make_problem(n_rows=n_rows, width=128, depth=2)
   res = {}
   for dt in ('fp32', 'bf16'):
-    eng = _engine(net, X, y, members=E, seed=2, compute_dtype=dt)
+    eng = _engine(net, X, y, members=E, seed=2, compute_dtype=dt, pipeline=pipeline)
     eng.init_params(float(np.log(np.nanstd(y) / 2)))
     if dt == 'fp32':
       theta0 = eng.get_params()
