@@ -173,3 +173,21 @@ def test_netspec_matches_oracle_layout():
               interactions=[], seasonality_periods=[4, 52.1775], num_seasonal_harmonics=[2, 10])
   assert (n.F, n.P) == (57, 292880)
   assert n.flops_per_member_step(10232) == pytest.approx(1.79e10, rel=5e-3)
+
+
+def test_evaluate_tables_match_published_configs():
+  """Hyper-parameter tables of the experiment driver (data from the reference's
+  scripts/dataset_config.py:77-180 and scripts/evaluate.py:194-302)."""
+  from bayesnf_amd import evaluate as ev
+  assert sorted(ev.DATASET_CONFIG) == ['air', 'air_quality', 'chickenpox', 'coprecip', 'sst', 'wind']
+  assert ev.MODEL_CONFIG['chickenpox']['vi'] == dict(
+      width=256, depth=2, seasonality_periods=[4.0, 52.1775], num_seasonal_harmonics=[2.0, 10],
+      observation_model='NORMAL')
+  assert ev.MODEL_CONFIG['sst']['map']['width'] == 768 and ev.DATASET_CONFIG['sst']['feature_cols'][-1] == 'soi'
+  assert ev.INFERENCE_CONFIG['air_quality']['vi'] == dict(
+      num_particles=16, num_epochs=500, learning_rate=0.01, batch_size=3500, kl_weight=0.2,
+      sample_size_divergence=5)
+  assert ev.INFERENCE_CONFIG['wind']['mle'] is ev.INFERENCE_CONFIG['wind']['map']
+  assert ev.INFERENCE_CONFIG['sst']['vi']['learning_rate'] == 0.005
+  with pytest.raises(ValueError):
+    ev.run_experiment('chickenpox', '/nonexistent', '8', '/tmp/x', 'ais', {}, {}, {}, 0)

@@ -84,3 +84,22 @@ def test_minibatch_and_splits_api(golden_dir):
   assert not np.allclose(est.params_.var4[0, 0], est.params_.var4[0, 2])
   with pytest.raises(ValueError):
     BayesianNeuralFieldMAP(**MODEL).fit(df, seed=0, ensemble_size=0, num_epochs=1)
+
+
+def test_experiment_driver_writes_reference_file_layout(golden_dir, tmp_path):
+  """run_experiment on the reference's own fixture (tests/test_evaluate_mini.py:58-67 config):
+  same three output files and columns; half-width matches the golden (KAT K1)."""
+  from bayesnf_amd import evaluate as ev
+  icfg = {'num_particles': 4, 'num_epochs': 5, 'learning_rate': 0.005}
+  dcfg = ev.DATASET_CONFIG['chickenpox']
+  losses, means, qs = ev.run_experiment('chickenpox', golden_dir, '8', str(tmp_path), 'map', dcfg,
+                                        ev.MODEL_CONFIG['chickenpox']['map'], icfg, seed=0)
+  stem = tmp_path / 'bnf-map.chickenpox.8'
+  pred = pd.read_csv(str(stem) + '.pred.csv', index_col=0)
+  gold = pd.read_csv(os.path.join(golden_dir, 'bnf-map.chickenpox.8.mini.pred.csv'), index_col=0)
+  assert list(pred.columns) == list(gold.columns) and list(pred.index) == list(gold.index)
+  loss = pd.read_csv(str(stem) + '.loss.csv')
+  assert loss.shape == (5, 4) and os.path.exists(str(stem) + '.log.json')
+  hw = ((pred.yhat_upper - pred.yhat_lower) / 2).iloc[:100].mean()
+  np.testing.assert_allclose(hw, 37.9523, rtol=2e-4)
+  assert losses.shape == (1, 4, 5) and means.shape == (1, 4, 308) and qs.shape == (3, 308)
