@@ -27,7 +27,7 @@ EXPORTS = (
     'bnf_abi_version', 'bnf_last_error', 'bnf_create', 'bnf_destroy',
     'bnf_workspace_bytes', 'bnf_state_bytes', 'bnf_param_bytes', 'bnf_bind',
     'bnf_init_params', 'bnf_train', 'bnf_vi_posterior_draws', 'bnf_forward',
-    'bnf_normal_mixture_quantiles', 'bnf_debug_loss_and_grad',
+    'bnf_normal_mixture_quantiles', 'bnf_count_mixture_quantiles', 'bnf_debug_loss_and_grad',
     'bnf_debug_row_index', 'bnf_debug_vi_eps', 'bnf_debug_activation',
     'bnf_debug_gemm_nt', 'bnf_debug_gemm_tn', 'bnf_profile_enable', 'bnf_profile_read',
     'bnf_kernel_flops')
@@ -102,6 +102,8 @@ def load():
   lib.bnf_forward.argtypes = [vp, vp, i64, vp, i64, vp, vp]
   lib.bnf_normal_mixture_quantiles.argtypes = [
       vp, vp, vp, i64, i64, C.POINTER(C.c_float), i32, i32, vp]
+  lib.bnf_count_mixture_quantiles.argtypes = [
+      vp, vp, vp, i64, i64, C.POINTER(C.c_float), i32, vp, vp]
   lib.bnf_debug_loss_and_grad.argtypes = [vp, i64, i64, vp, vp]
   lib.bnf_debug_row_index.argtypes = [vp, i64, i64, vp]
   lib.bnf_debug_vi_eps.argtypes = [vp, i64, vp]

@@ -666,9 +666,8 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
                 cfg->device, prop.gcnArchName);
   if (cfg->dtype != BNF_DTYPE_F32 && cfg->dtype != BNF_DTYPE_BF16)
     return fail(BNF_ERR_INVALID, "dtype %d", cfg->dtype);
-  if (cfg->obs_model != BNF_OBS_NORMAL)
-    return fail(BNF_ERR_INVALID, "observation model %d not supported by this build (NORMAL only)",
-                cfg->obs_model);
+  if (cfg->obs_model != BNF_OBS_NORMAL && cfg->obs_model != BNF_OBS_NB && cfg->obs_model != BNF_OBS_ZINB)
+    return fail(BNF_ERR_INVALID, "observation model %d", cfg->obs_model);
   if (cfg->mode != BNF_MODE_MAP && cfg->mode != BNF_MODE_VI) return fail(BNF_ERR_INVALID, "mode");
   if (cfg->n_inputs < 1 || cfg->n_inputs > BNF_MAX_INPUTS) return fail(BNF_ERR_INVALID, "n_inputs");
   if (cfg->depth < 1 || cfg->depth > BNF_MAX_LAYERS) return fail(BNF_ERR_INVALID, "depth");
@@ -743,10 +742,11 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
     // fused row-panel pipeline: training handles with W = 128 / 256 / 512 and F <= 128
     int want = cfg->pipeline;  // 0 auto, 1 unfused, 2 fused
     if (const char* pf = getenv("BNF_PIPELINE")) want = atoi(pf);
-    const bool can = !cfg->forward_only && (h->W == 128 || h->W == 256 || h->W == 512) && h->Fp <= 128;
+    const bool can = !cfg->forward_only && (h->W == 128 || h->W == 256 || h->W == 512) && h->Fp <= 128 &&
+                     cfg->obs_model == BNF_OBS_NORMAL;
     if (want == 2 && !can) {
       delete h;
-      return fail(BNF_ERR_INVALID, "fused pipeline needs a training handle with width 128/256/512 and <= 128 features");
+      return fail(BNF_ERR_INVALID, "fused pipeline needs a NORMAL training handle with width 128/256/512 and <= 128 features");
     }
     h->fused = can && want == 2;   // opt-in: measured slower than the layer kernels
     if (h->fused) {
@@ -949,6 +949,31 @@ int bnf_normal_mixture_quantiles(bnf_handle* h, const float* means, const float*
   HIPCHK(hipGetLastError());
   return BNF_OK;
 }
+
+int bnf_count_mixture_quantiles(bnf_handle* h, const float* loc, const float* aux,
+                                int64_t n_members, int64_t n_rows, const float* q, int32_t n_q,
+                                float* means, float* out) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "not bound");
+  if (h->cfg.obs_model != BNF_OBS_NB && h->cfg.obs_model != BNF_OBS_ZINB)
+    return fail(BNF_ERR_STATE, "handle's observation model is not NB / ZINB");
+  if (!loc || !aux || !means || n_members < 1 || n_rows < 1 || n_q < 0 || (n_q > 0 && (!q || !out)))
+    return fail(BNF_ERR_INVALID, "argument");
+  for (int i = 0; i < n_q; ++i)
+    if (!(q[i] > 0.f && q[i] < 1.f)) return fail(BNF_ERR_INVALID, "quantile %g outside (0, 1)", q[i]);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  float* part = h->qscratch;
+  float* bracket = h->qscratch + 4096;
+  const int nb = (int)std::min<int64_t>(1024, cdiv(n_members * n_rows, 256));
+  hipLaunchKernelGGL(k_count_moments, dim3(nb), dim3(256), 0, h->stream, loc, aux, n_members, n_rows,
+                     h->cfg.obs_model, means, part);
+  hipLaunchKernelGGL(k_count_bracket, dim3(1), dim3(64), 0, h->stream, part, nb, bracket);
+  for (int i = 0; i < n_q; ++i)
+    hipLaunchKernelGGL(k_count_quantile_root, dim3(cdiv(n_rows, 64)), dim3(64), 0, h->stream, loc, aux,
+                       n_members, n_rows, h->cfg.obs_model, bracket, q[i], out + (int64_t)i * n_rows);
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
 
 // ---- debug / introspection ---------------------------------------------------
 int bnf_debug_loss_and_grad(bnf_handle* h, int64_t epoch, int64_t step, float* grads, float* loss) {

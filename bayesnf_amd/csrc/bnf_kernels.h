@@ -302,15 +302,30 @@ struct RowLossArgs {
   float* loss_raw;
 };
 
+// digamma for x > 0: shift to x >= 6 by the recurrence, then the asymptotic series
+// (|err| ~ 1e-7 relative in fp32 for the shifted argument).
+__device__ __forceinline__ float digammaf(float x) {
+  float acc = 0.f;
+#pragma unroll 1
+  while (x < 6.f) { acc -= 1.0f / x; x += 1.0f; }
+  const float r = 1.0f / x, r2 = r * r;
+  const float tail = r2 * (1.f / 12.f - r2 * (1.f / 120.f - r2 * (1.f / 252.f - r2 * (1.f / 240.f))));
+  return acc + logf(x) - 0.5f * r - tail;
+}
+
+// log(1 + e^x) / log sigmoid without overflow
+__device__ __forceinline__ float log_sigmoidf(float x) { return -softplusf(-x); }
+
 template <bool TRAIN>
 __global__ __launch_bounds__(256) void k_row_loss(NetDev nd, RowLossArgs a) {
-  __shared__ float s_red[4][4];
+  __shared__ float s_red[4][5];
   const int e = blockIdx.y;
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const float* th = a.theta + (int64_t)e * a.theta_stride;
   const int L = nd.depth;
   const float gam_o = softplusf(th[nd.off_os]);
-  float ll = 0.f, s_doutv = 0.f, s_dvsum = 0.f, s_lns = 0.f;
+  // s_par: d loss / d (log_noise_scale | shape) ; s_infl: d loss / d inflated_loc_probs
+  float ll = 0.f, s_doutv = 0.f, s_dvsum = 0.f, s_par = 0.f, s_infl = 0.f;
   if (r < a.B) {
     const int64_t vi = (int64_t)e * a.vacc_batch + r;
     const float v = a.vacc[vi] * (1.0f / sqrtf((float)nd.W)) + th[nd.off_bias[L]];
@@ -319,39 +334,80 @@ __global__ __launch_bounds__(256) void k_row_loss(NetDev nd, RowLossArgs a) {
     a.out[(int64_t)e * a.out_batch + r] = out;
     if constexpr (TRAIN) {
       const float yv = a.ybat[vi];
-      // NORMAL (models.py:157-164): sigma = 0.01 + exp(lns)
-      const float lns = th[nd.off_lns];
-      const float sigma = 0.01f + expf(lns);
-      const float res = yv - out;
-      const float z = res / sigma;
-      ll = -0.5f * z * z - logf(sigma) - 0.918938533204672742f;
-      const float dout = -a.c * res / (sigma * sigma);
+      float dout;   // d loss / d out
+      if (nd.obs == BNF_OBS_NORMAL) {
+        // NORMAL (models.py:157-164): sigma = 0.01 + exp(lns)
+        const float lns = th[nd.off_lns];
+        const float sigma = 0.01f + expf(lns);
+        const float res = yv - out;
+        const float z = res / sigma;
+        ll = -0.5f * z * z - logf(sigma) - 0.918938533204672742f;
+        dout = -a.c * res / (sigma * sigma);
+        s_par = -a.c * (res * res / (sigma * sigma * sigma) - 1.0f / sigma) * expf(lns);
+      } else {
+        // NB / ZINB (models.py:166-191): mean = softplus(out), shape = softplus(theta_shape),
+        // total_count = 1/shape, logits = -log shape - log mean;  TFP 0.24 log_prob:
+        //   tc logsig(-logits) + y logsig(logits) + lgamma(tc+y) - lgamma(1+y) - lgamma(tc)
+        const float ths = th[nd.off_shape];
+        const float shape = softplusf(ths);
+        const float tc = 1.0f / shape;
+        const float mean = softplusf(out);
+        const float logits = -logf(shape) - logf(mean);
+        const float sg = sigmoidf(logits);
+        const float lsn = log_sigmoidf(-logits);
+        float lp = tc * lsn + yv * log_sigmoidf(logits) + lgammaf(tc + yv) - lgammaf(1.0f + yv) -
+                   lgammaf(tc);
+        float dl_dlogits = yv * (1.0f - sg) - tc * sg;
+        float dl_dtc = lsn + digammaf(tc + yv) - digammaf(tc);
+        if (nd.obs == BNF_OBS_ZINB) {
+          // Mixture(cat = [1 - pi, pi], [NB, delta_0])
+          const float thp = th[nd.off_infl];
+          const float pi = sigmoidf(thp);
+          float dlp_dpi;
+          if (yv == 0.f) {
+            const float p0 = expf(lp);
+            const float den = (1.0f - pi) * p0 + pi;
+            const float w = (1.0f - pi) * p0 / den;
+            dlp_dpi = (1.0f - p0) / den;
+            lp = logf(den);
+            dl_dlogits *= w; dl_dtc *= w;
+          } else {
+            dlp_dpi = -1.0f / (1.0f - pi);
+            lp += log_sigmoidf(-thp);                 // log(1 - pi)
+          }
+          s_infl = -a.c * dlp_dpi * pi * (1.0f - pi);
+        }
+        ll = lp;
+        dout = -a.c * (-dl_dlogits / mean) * sigmoidf(out);
+        s_par = -a.c * (-dl_dlogits / shape - dl_dtc / (shape * shape)) * sigmoidf(ths);
+      }
       s_doutv = dout * v;
       const float dvv = gam_o * dout;
       a.dv[vi] = dvv;
       s_dvsum = dvv;
-      s_lns = -a.c * (res * res / (sigma * sigma * sigma) - 1.0f / sigma) * expf(lns);
     }
   }
   if constexpr (!TRAIN) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float t0 = wave_sum(ll), t1 = wave_sum(s_doutv), t2 = wave_sum(s_dvsum), t3 = wave_sum(s_lns);
+  const float t0 = wave_sum(ll), t1 = wave_sum(s_doutv), t2 = wave_sum(s_dvsum), t3 = wave_sum(s_par);
+  const float t4 = nd.obs == BNF_OBS_ZINB ? wave_sum(s_infl) : 0.f;
   if (lane == 0) {
     s_red[wave][0] = t0; s_red[wave][1] = t1; s_red[wave][2] = t2; s_red[wave][3] = t3;
+    s_red[wave][4] = t4;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     float* gr = a.grad + (int64_t)e * a.grad_stride;
-    const float u0 = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
-    const float u1 = s_red[0][1] + s_red[1][1] + s_red[2][1] + s_red[3][1];
-    const float u2 = s_red[0][2] + s_red[1][2] + s_red[2][2] + s_red[3][2];
-    const float u3 = s_red[0][3] + s_red[1][3] + s_red[2][3] + s_red[3][3];
-    const float step_loss = -a.c * u0;
+    float u[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) u[i] = s_red[0][i] + s_red[1][i] + s_red[2][i] + s_red[3][i];
+    const float step_loss = -a.c * u[0];
     atomicAdd(&a.loss[(int64_t)(e / a.S) * a.loss_stride], a.loss_scale * step_loss);
     if (a.loss_raw) atomicAdd(&a.loss_raw[e], step_loss);
-    atomicAdd(&gr[nd.off_os], sigmoidf(th[nd.off_os]) * u1);
-    atomicAdd(&gr[nd.off_bias[L]], u2);
-    atomicAdd(&gr[nd.off_lns], u3);
+    atomicAdd(&gr[nd.off_os], sigmoidf(th[nd.off_os]) * u[1]);
+    atomicAdd(&gr[nd.off_bias[L]], u[2]);
+    atomicAdd(&gr[nd.obs == BNF_OBS_NORMAL ? nd.off_lns : nd.off_shape], u[3]);
+    if (nd.obs == BNF_OBS_ZINB) atomicAdd(&gr[nd.off_infl], u[4]);
   }
 }
 
@@ -823,6 +879,155 @@ __global__ __launch_bounds__(256) void k_quantile_approx(const float* __restrict
   const float mm = s1 / (float)n_members;
   const float var = s2 / (float)n_members - mm * mm;
   out[r] = mm + sqrtf(fmaxf(var, 0.f)) * normcdfinvf(q);
+}
+
+// ---------------------------------------------------------------------------
+// count observation models: NB / ZINB forecast moments and mixture quantiles
+// (inference.py:271-333, 497-502; TFP 0.24 NegativeBinomial / Mixture).
+//   s = softplus(theta_shape) = aux[e][1], m = softplus(loc), tc = 1/s,
+//   logits = -log s - log m  =>  e^logits = 1/(s m), sigmoid(-logits) = s m/(1+s m)
+//   NB mean = tc e^logits = 1/(s^2 m), var = mean / sigmoid(-logits)
+//   ZINB = Mixture([1-pi, pi], [NB, delta_0])
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count_moments(const float* __restrict__ loc,
+                                                       const float* __restrict__ aux,
+                                                       int64_t n_members, int64_t n_rows, int32_t obs,
+                                                       float* __restrict__ means,
+                                                       float* __restrict__ part) {
+  __shared__ float smean[4], ssd[4];
+  float mx_mean = 0.f, mx_sd = 0.f;
+  const int64_t n = n_members * n_rows;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / n_rows;
+    const float s = aux[e * 3 + 1];
+    const float m = softplusf(loc[i]);
+    const float sm = s * m;
+    float mean = 1.0f / (s * sm);
+    float var = mean * (1.0f + sm) / sm;
+    if (obs == BNF_OBS_ZINB) {
+      const float pi = aux[e * 3 + 2];
+      const float zmean = (1.0f - pi) * mean;
+      var = (1.0f - pi) * (var + mean * mean) - zmean * zmean;
+      mean = zmean;
+    }
+    means[i] = mean;
+    mx_mean = fmaxf(mx_mean, mean);
+    mx_sd = fmaxf(mx_sd, sqrtf(fmaxf(var, 0.f)));
+  }
+  mx_mean = wave_max(mx_mean);
+  mx_sd = wave_max(mx_sd);
+  if ((threadIdx.x & 63) == 0) { smean[threadIdx.x >> 6] = mx_mean; ssd[threadIdx.x >> 6] = mx_sd; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2] = fmaxf(fmaxf(smean[0], smean[1]), fmaxf(smean[2], smean[3]));
+    part[blockIdx.x * 2 + 1] = fmaxf(fmaxf(ssd[0], ssd[1]), fmaxf(ssd[2], ssd[3]));
+  }
+}
+
+// bracket[2 + 0..1] = {max mean, max stddev}
+__global__ void k_count_bracket(const float* part, int n_part, float* bracket) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float mm = 0.f, ms = 0.f;
+  for (int i = 0; i < n_part; ++i) { mm = fmaxf(mm, part[2 * i]); ms = fmaxf(ms, part[2 * i + 1]); }
+  bracket[2] = mm;
+  bracket[3] = ms;
+}
+
+// continued fraction of the incomplete beta function (modified Lentz), f64: the
+// prefactor a log x + b log(1-x) - lbeta(a,b) cancels catastrophically in f32 for the
+// b ~ 1e3..1e5 the bracket reaches.
+__device__ inline double beta_cf(double a, double b, double x) {
+  const double tiny = 1e-300, eps = 1e-13;
+  const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+  double c = 1.0, d = 1.0 - qab * x / qap;
+  if (fabs(d) < tiny) d = tiny;
+  d = 1.0 / d;
+  double hh = d;
+#pragma unroll 1
+  for (int m = 1; m <= 2000; ++m) {
+    const double m2 = 2.0 * m;
+    double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+    d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+    c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+    d = 1.0 / d;
+    hh *= d * c;
+    aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+    d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+    c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+    d = 1.0 / d;
+    const double del = d * c;
+    hh *= del;
+    if (fabs(del - 1.0) < eps) break;
+  }
+  return hh;
+}
+
+// regularised incomplete beta I_x(a, b) with xc = 1 - x supplied separately
+__device__ inline double betainc_xc(double a, double b, double x, double xc) {
+  if (x <= 0.0) return 0.0;
+  if (xc <= 0.0) return 1.0;
+  const double lnpre = lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log(xc);
+  if (x < (a + 1.0) / (a + b + 2.0)) return exp(lnpre) * beta_cf(a, b, x) / a;
+  return 1.0 - exp(lnpre) * beta_cf(b, a, xc) / b;
+}
+
+// mean over members of the (ZI)NB cdf at x >= 0, row r
+__device__ inline float count_mix_cdf(const float* __restrict__ loc, const float* __restrict__ aux,
+                                      int64_t n_members, int64_t n_rows, int32_t obs, int64_t r,
+                                      float x) {
+  double acc = 0.0;
+  for (int64_t e = 0; e < n_members; ++e) {
+    const double s = aux[e * 3 + 1];
+    const double sm = s * (double)softplusf(loc[e * n_rows + r]);
+    double F = betainc_xc(1.0 / s, 1.0 + (double)x, sm / (1.0 + sm), 1.0 / (1.0 + sm));
+    if (obs == BNF_OBS_ZINB) {
+      const double pi = aux[e * 3 + 2];
+      F = pi + (1.0 - pi) * F;
+    }
+    acc += F;
+  }
+  return (float)(acc / (double)n_members);
+}
+
+// one thread per row: Chandrupatla on [0, max mean + 1.1 rsqrt(1-q) max sd], then ceil;
+// rows whose mixture pmf(0) already exceeds q are 0 (inference.py:319-333).
+__global__ __launch_bounds__(64) void k_count_quantile_root(const float* __restrict__ loc,
+                                                            const float* __restrict__ aux,
+                                                            int64_t n_members, int64_t n_rows,
+                                                            int32_t obs,
+                                                            const float* __restrict__ bracket, float q,
+                                                            float* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const float vtol = 1e-5f, ptol = 1e-8f;
+  float a = 0.f, b = bracket[2] + 1.1f * rsqrtf(1.0f - q) * bracket[3];
+  float fa = count_mix_cdf(loc, aux, n_members, n_rows, obs, r, a) - q;
+  if (fa > 0.f) { out[r] = 0.f; return; }
+  float fb = count_mix_cdf(loc, aux, n_members, n_rows, obs, r, b) - q;
+  float c = a, fc = fa, t = 0.5f;
+  float best = fabsf(fa) < fabsf(fb) ? a : b;
+  float fbest = fabsf(fa) < fabsf(fb) ? fa : fb;
+  for (int it = 0; it < 60 && fabsf(fbest) > vtol; ++it) {
+    const float xn = a + t * (b - a);
+    const float fn = count_mix_cdf(loc, aux, n_members, n_rows, obs, r, xn) - q;
+    const bool same = (fn > 0.f) == (fa > 0.f) && (fn < 0.f) == (fa < 0.f);
+    if (same) { c = a; fc = fa; }
+    else { c = b; fc = fb; b = a; fb = fa; }
+    a = xn; fa = fn;
+    if (fabsf(fa) < fabsf(fb)) { best = a; fbest = fa; } else { best = b; fbest = fb; }
+    const float tol = ptol / fabsf(b - c);
+    if (tol > 0.5f || fbest == 0.f) break;
+    const float xi = (a - b) / (c - b), phi = (fa - fb) / (fc - fb);
+    if (phi * phi < xi && (1.f - phi) * (1.f - phi) < 1.f - xi) {
+      t = (fa / (fb - fa)) * (fc / (fb - fc)) + ((c - a) / (b - a)) * (fa / (fc - fa)) * (fb / (fc - fb));
+    } else {
+      t = 0.5f;
+    }
+    t = fminf(fmaxf(t, tol), 1.f - tol);
+    if (!(t == t)) t = 0.5f;
+  }
+  out[r] = ceilf(best);
 }
 
 }  // namespace bnf

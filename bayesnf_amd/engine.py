@@ -167,6 +167,19 @@ class Engine:
         len(q), 1 if approximate else 0, _ptr(out)), 'bnf_normal_mixture_quantiles')
     return out
 
+  def count_mixture_quantiles(self, loc: torch.Tensor, aux: torch.Tensor, quantiles):
+    """NB / ZINB: loc (M, R) network output, aux (M, 3) -> (means (M, R), quantiles (n_q, R))."""
+    loc = loc.contiguous().float()
+    aux = aux.contiguous().float()
+    q = np.asarray(list(quantiles), dtype=np.float32)
+    means = torch.empty_like(loc)
+    out = torch.empty((len(q), loc.shape[1]), dtype=torch.float32, device=self.device)
+    qa = (C.c_float * max(1, len(q)))(*q.tolist())
+    _native.check(self.lib.bnf_count_mixture_quantiles(
+        self.handle, _ptr(loc), _ptr(aux), loc.shape[0], loc.shape[1], qa, len(q),
+        _ptr(means), _ptr(out)), 'bnf_count_mixture_quantiles')
+    return means, out
+
   # -- introspection (tests, bench) -------------------------------------------
   def debug_loss_and_grad(self, epoch=0, step=0):
     k = 2 if self.mode == 'vi' else 1

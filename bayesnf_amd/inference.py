@@ -182,17 +182,18 @@ def predict_bnf(features, observation_model, params, model_args, quantiles,
   """-> (means, [quantile arrays]).  means: leading ensemble dims of `params`
   + (n_rows,); each quantile array has shape (n_rows,)."""
   assert ensemble_dims >= 1
-  if observation_model != 'NORMAL':
-    raise NotImplementedError(
-        'predict for NB / ZINB observation models is not built yet (SURVEY row N4)')
   features = np.asarray(features, dtype=np.float64)
   net, eng, lead, loc_all, aux_all = _ensemble_forecast(
       features, observation_model, params, model_args, ensemble_dims, compute_dtype)
   n_rows = features.shape[0]
-  means = loc_all.reshape(-1, n_rows)
-  scales = aux_all.reshape(-1, 3)[:, 0]
-  q = eng.normal_mixture_quantiles(means, scales, quantiles,
-                                   approximate=approximate_quantiles)
+  loc = loc_all.reshape(-1, n_rows)
+  if observation_model == 'NORMAL':
+    means = loc
+    q = eng.normal_mixture_quantiles(means, aux_all.reshape(-1, 3)[:, 0], quantiles,
+                                     approximate=approximate_quantiles)
+  else:
+    # NB / ZINB (inference.py:493-502): distribution means + root-found integer quantiles
+    means, q = eng.count_mixture_quantiles(loc, aux_all.reshape(-1, 3), quantiles)
   torch.cuda.synchronize(eng.device)
   means_np = means.cpu().numpy().reshape(tuple(lead) + (n_rows,))
   q_np = q.cpu().numpy()
@@ -225,16 +226,65 @@ class EnsembleLikelihood:
     return self.loc + self.scale * rng.standard_normal(self.loc.shape)
 
 
+class CountEnsembleLikelihood:
+  """NB / ZINB counterpart (models.py:166-191): Independent (ZI)NegativeBinomial per member.
+  total_count (*ens, 1), logits (*ens, R), inflated_loc_probs (*ens, 1) or None."""
+
+  def __init__(self, total_count, logits, inflated_loc_probs=None):
+    self.total_count = total_count[..., None]
+    self.logits = logits
+    self.inflated_loc_probs = None if inflated_loc_probs is None else inflated_loc_probs[..., None]
+
+  def _nb_mean_var(self):
+    mean = self.total_count * np.exp(self.logits)
+    return mean, mean * (1.0 + np.exp(self.logits))       # mean / sigmoid(-logits)
+
+  def mean(self):
+    mean, _ = self._nb_mean_var()
+    return mean if self.inflated_loc_probs is None else (1.0 - self.inflated_loc_probs) * mean
+
+  def stddev(self):
+    mean, var = self._nb_mean_var()
+    if self.inflated_loc_probs is not None:
+      pi = self.inflated_loc_probs
+      var = (1.0 - pi) * (var + mean * mean) - ((1.0 - pi) * mean) ** 2
+    return np.sqrt(var)
+
+  def log_prob(self, y):
+    from scipy import special as sp
+    y = np.asarray(y, dtype=np.float64)
+    tc, lg = self.total_count, self.logits
+    lp = (tc * -np.logaddexp(lg, 0.0) + y * -np.logaddexp(-lg, 0.0) + sp.gammaln(tc + y) -
+          sp.gammaln(1.0 + y) - sp.gammaln(tc))
+    if self.inflated_loc_probs is not None:
+      pi = self.inflated_loc_probs
+      lp = np.where(y == 0, np.logaddexp(np.log1p(-pi) + lp, np.log(pi)), np.log1p(-pi) + lp)
+    return np.sum(lp, axis=-1)
+
+  def sample(self, seed=0):
+    rng = np.random.default_rng(_native.seed_to_u64(seed))
+    shape = np.broadcast_shapes(self.total_count.shape, self.logits.shape)
+    # NB(tc, p) as a Gamma-Poisson mixture: rate ~ Gamma(tc, scale = e^logits)
+    rate = rng.gamma(np.broadcast_to(self.total_count, shape), np.exp(self.logits))
+    draw = rng.poisson(rate).astype(np.float64)
+    if self.inflated_loc_probs is not None:
+      draw = np.where(rng.random(shape) < self.inflated_loc_probs, 0.0, draw)
+    return draw
+
+
 def likelihood_model(features, observation_model, params, model_args,
                      ensemble_dims=2, compute_dtype=None):
-  if observation_model != 'NORMAL':
-    raise NotImplementedError('NB / ZINB likelihood objects are not built yet')
   features = np.asarray(features, dtype=np.float64)
   net, eng, lead, loc_all, aux_all = _ensemble_forecast(
       features, observation_model, params, model_args, ensemble_dims, compute_dtype)
   torch.cuda.synchronize(eng.device)
   n_rows = features.shape[0]
-  loc = loc_all.cpu().numpy().reshape(tuple(lead) + (n_rows,))
-  scale = aux_all.cpu().numpy().reshape(tuple(lead) + (3,))[..., 0]
+  loc = loc_all.cpu().numpy().reshape(tuple(lead) + (n_rows,)).astype(np.float64)
+  aux = aux_all.cpu().numpy().reshape(tuple(lead) + (3,)).astype(np.float64)
   eng.close()
-  return EnsembleLikelihood(loc.astype(np.float64), scale.astype(np.float64))
+  if observation_model == 'NORMAL':
+    return EnsembleLikelihood(loc, aux[..., 0])
+  shape = aux[..., 1]
+  logits = -np.log(shape)[..., None] - np.log(np.logaddexp(loc, 0.0))
+  return CountEnsembleLikelihood(1.0 / shape, logits,
+                                 aux[..., 2] if observation_model == 'ZINB' else None)

@@ -174,6 +174,18 @@ int bnf_normal_mixture_quantiles(bnf_handle* h, const float* means, const float*
                                  int64_t n_members, int64_t n_rows, const float* q,
                                  int32_t n_q, int32_t approximate, float* out);
 
+/* Count observation models (handle created with BNF_OBS_NB / BNF_OBS_ZINB):
+ * per-member forecast means and quantiles of the equal-weight mixture over members
+ * (inference.py:271-333 and :497-502; TFP NegativeBinomial / ZeroInflatedNegativeBinomial
+ * mean, stddev, cdf).  loc DEVICE (n_members, n_rows) and aux DEVICE (n_members, 3) as
+ * written by bnf_forward; means DEVICE (n_members, n_rows) out; q HOST (n_q,) in (0,1);
+ * out DEVICE (n_q, n_rows) = ceil of the Chandrupatla root of mean_e cdf_e(x) - q on
+ * [0, max mean + 1.1 rsqrt(1-q) max stddev] (value tolerance 1e-5, <= 60 iterations),
+ * 0 where mean_e pmf_e(0) > q.  n_q = 0: means only. */
+int bnf_count_mixture_quantiles(bnf_handle* h, const float* loc, const float* aux,
+                                int64_t n_members, int64_t n_rows, const float* q,
+                                int32_t n_q, float* means, float* out);
+
 /* ---- introspection used by tests and bench.py ------------------------------ */
 /* One forward+backward of every local member on batch `step` of `epoch` WITHOUT
  * the optimiser update: grads DEVICE (members*S, P) f32 receives d(step loss)/d

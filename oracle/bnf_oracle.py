@@ -736,6 +736,50 @@ def chandrupatla(f, low, high, value_tol=1e-5, max_iter=60, pos_tol=1e-8):
   return best
 
 
+def count_forecast(model, theta, out):
+  """NB / ZINB forecast parameters and moments from the network output `out`
+  (E, N*) (inference.py:103-125, 271-295; TFP 0.24 NegativeBinomial / Mixture):
+
+     total_count = 1 / softplus(theta_shape)
+     logits      = -log softplus(theta_shape) - log softplus(out)
+     NB:   mean = tc e^logits,  var = mean / sigmoid(-logits)
+     ZINB: Mixture([1 - pi, pi], [NB, delta_0])
+  -> dict(tc (E,1), logits, pi (E,1) or None, mean, stddev)."""
+  theta = np.asarray(theta, dtype=np.float64)
+  tc, logits = nb_logits_total_count(model, theta, np.asarray(out, dtype=np.float64))
+  tc = tc[:, None]
+  mean = tc * np.exp(logits)
+  var = mean / sigmoid(-logits)
+  pi = None
+  if model.observation_model == 'ZINB':
+    pi = sigmoid(model.view(theta, 'inflated_loc_probs'))[:, None]
+    zmean = (1 - pi) * mean
+    var = (1 - pi) * (var + mean * mean) - zmean * zmean
+    mean = zmean
+  return dict(tc=tc, logits=logits, pi=pi, mean=mean, stddev=np.sqrt(var))
+
+
+def count_cdf(fc, x):
+  """cdf of each member's (ZI)NB at x >= 0 (TFP: betainc(tc, 1 + x, sigmoid(-logits)),
+  continuous in x; zero inflation adds the point mass at 0)."""
+  F = _sp.betainc(np.broadcast_to(fc['tc'], fc['logits'].shape), 1.0 + x,
+                  sigmoid(-fc['logits']))
+  if fc['pi'] is not None:
+    F = fc['pi'] + (1 - fc['pi']) * F
+  return F
+
+
+def count_quantile_via_root(fc, q):
+  """inference.py:298-333: ceil of the Chandrupatla root of mean_e cdf_e(x) - q on
+  [0, max mean + 1.1 rsqrt(1 - q) max stddev]; 0 where mean_e pmf_e(0) > q."""
+  high = np.max(fc['mean']) + 1.1 / np.sqrt(1.0 - q) * np.max(fc['stddev'])
+  n = fc['logits'].shape[-1]
+  root = chandrupatla(lambda x: count_cdf(fc, x[None, :]).mean(axis=0) - q,
+                      np.zeros(n), np.full(n, high))
+  p0 = count_cdf(fc, np.zeros((1, n))).mean(axis=0)
+  return np.ceil(np.where(p0 > q, 0.0, root))
+
+
 def normal_quantile_via_root(means, scales, q):
   """means (..., N*), scales (...,) ; mixture over all leading axes
   (inference.py:42-52)."""

@@ -103,3 +103,24 @@ def test_experiment_driver_writes_reference_file_layout(golden_dir, tmp_path):
   hw = ((pred.yhat_upper - pred.yhat_lower) / 2).iloc[:100].mean()
   np.testing.assert_allclose(hw, 37.9523, rtol=2e-4)
   assert losses.shape == (1, 4, 5) and means.shape == (1, 4, 308) and qs.shape == (3, 308)
+
+
+@pytest.mark.parametrize('obs', ['NB', 'ZINB'])
+def test_count_observation_models_end_to_end(golden_dir, obs):
+  """chickenpox counts under the NB / ZINB likelihoods (models.py:166-191) through fit / predict /
+  likelihood_model: shapes, integer quantiles in order, loss decreases."""
+  df = _train_frame(golden_dir)
+  kw = dict(MODEL, observation_model=obs, width=64)
+  est = BayesianNeuralFieldMAP(**kw).fit(df, seed=3, ensemble_size=4, num_epochs=60, learning_rate=0.01)
+  assert est.losses_.shape == (1, 4, 60) and np.all(est.losses_[..., -1] < est.losses_[..., 0])
+  means, qs = est.predict(df, quantiles=(0.5, 0.025, 0.975))
+  assert means.shape == (1, 4, 100) and np.all(means > 0)
+  lo, mid, hi = qs[1], qs[0], qs[2]
+  assert all(np.all(q == np.round(q)) and np.all(q >= 0) for q in qs)
+  assert np.all(lo <= mid) and np.all(mid <= hi) and np.any(hi > lo)
+  lik = est.likelihood_model(df)
+  np.testing.assert_allclose(lik.mean(), means, rtol=1e-4)
+  assert lik.log_prob(df['chickenpox'].to_numpy()).shape == (1, 4)
+  vi = BayesianNeuralFieldVI(**kw).fit(df, seed=1, ensemble_size=2, num_epochs=5, sample_size_posterior=3)
+  m2, q2 = vi.predict(df, quantiles=(0.5,))
+  assert m2.shape == (1, 3, 2, 100) and np.all(np.isfinite(m2)) and np.all(q2[0] >= 0)

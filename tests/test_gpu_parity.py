@@ -229,6 +229,74 @@ def test_forward_only_and_quantiles():
   eng.close()
 
 
+# --------------------------------------------------------------------------- count models
+@pytest.mark.parametrize('obs', ['NB', 'ZINB'])
+def test_count_models_loss_grad_and_training_fp32(obs):
+  """NB / ZINB likelihood (models.py:166-191): step loss, every gradient leaf (incl. `shape`
+  and `inflated_loc_probs`), then 25 Adam steps against the oracle."""
+  n_rows, E = 260, 3
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=2, observation_model=obs)
+  assert (y == 0).sum() > 40 and y.max() >= 3
+  theta = util.random_theta(model, E, scale=0.4)
+  for pw in (1.0, 0.0):
+    eng = _engine(net, X, y, members=E, prior_weight=pw, compute_dtype='fp32')
+    eng.set_params(theta)
+    loss_d, g_d = eng.debug_loss_and_grad()
+    loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows, prior_weight=pw)
+    np.testing.assert_allclose(loss_d, loss_o, rtol=3e-5)
+    errs = util.per_leaf_rel_err(model, g_d, g_o)
+    bad = {k: v for k, v in errs.items() if v > 5e-4}
+    assert not bad, bad
+    if pw == 0.0:   # likelihood-only gradient of the unused observation leaves is exactly 0
+      assert np.all(g_d[:, model.leaf['log_noise_scale'].offset] == 0)
+      if obs == 'NB':
+        assert np.all(g_d[:, model.leaf['inflated_loc_probs'].offset] == 0)
+    eng.close()
+  eng = _engine(net, X, y, members=E, seed=5, learning_rate=0.005, compute_dtype='fp32')
+  eng.init_params(float(np.log(np.nanstd(y) / 2)))
+  theta0 = eng.get_params().astype(np.float64)
+  losses = eng.train(0, 25)
+  torch.cuda.synchronize()
+  theta_o, losses_o = O.train_map(model, theta0, X, y, lr=0.005, num_epochs=25)
+  np.testing.assert_allclose(losses.cpu().numpy(), losses_o, rtol=1e-4)
+  assert util.rel_err(eng.get_params(), theta_o) < 2e-3
+  eng.close()
+  with pytest.raises(ValueError):
+    _engine(net, X, y, members=E, compute_dtype='fp32', pipeline='fused')
+
+
+@pytest.mark.parametrize('obs', ['NB', 'ZINB'])
+def test_count_models_forecast_means_and_quantiles(obs):
+  from bayesnf_amd.engine import Engine
+  net, model, X, y = util.make_problem(n_rows=333, width=64, depth=2, observation_model=obs)
+  M = 7
+  theta = util.random_theta(model, M, scale=0.4)
+  theta[:, model.leaf['shape'].offset] += np.linspace(-1.0, 1.5, M)
+  eng = Engine(net, members=4, forward_only=True, row_capacity=128, compute_dtype='fp32')
+  loc, aux = eng.forward(torch.tensor(theta, dtype=torch.float32, device=eng.device),
+                         torch.tensor(X, dtype=torch.float32, device=eng.device))
+  qs = (0.5, 0.025, 0.975, 0.2)
+  means, q_d = eng.count_mixture_quantiles(loc, aux, qs)
+  torch.cuda.synchronize()
+  fc = O.count_forecast(model, theta, O.forward(model, theta, X))
+  assert util.rel_err(means.cpu().numpy(), fc['mean']) < 3e-4
+  q_d = q_d.cpu().numpy()
+  assert np.all(q_d == np.round(q_d)) and np.all(q_d >= 0)
+  for i, q in enumerate(qs):
+    q_o = O.count_quantile_via_root(fc, q)
+    # the integer quantile is the smallest k with mixture cdf(k) >= q; roots that land within
+    # the 1e-5 value tolerance of an integer may round either way
+    agree = np.mean(q_d[i] == q_o)
+    assert agree > 0.98, (q, agree)
+    k = q_d[i]
+    assert np.all(O.count_cdf(fc, k[None, :]).mean(axis=0) >= q - 2e-5)
+    below = {kk: v for kk, v in fc.items()}
+    lo = np.maximum(k - 1, 0)
+    F_lo = O.count_cdf(below, lo[None, :]).mean(axis=0)
+    assert np.all((F_lo <= q + 2e-5) | (k == 0))
+  eng.close()
+
+
 # --------------------------------------------------------------------------- bf16
 @pytest.mark.parametrize('pipeline', ['layers', 'fused'])
 def test_bf16_tracks_fp32(pipeline):

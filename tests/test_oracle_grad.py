@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from oracle import bnf_oracle as O
+from tests import util
 
 
 def small_model(obs='NORMAL', depth=2, interactions=((0, 1), (1, 2))):
@@ -160,3 +161,30 @@ def test_chandrupatla_quantiles():
     np.testing.assert_allclose(O.mixture_cdf(means, scales, x), q, atol=1.1e-5)
   x = O.approximate_normal_quantile(means, scales, 0.5)
   np.testing.assert_allclose(x, means.reshape(-1, 50).mean(0), atol=1e-12)
+
+
+@pytest.mark.parametrize('obs', ['NB', 'ZINB'])
+def test_count_quantiles_against_pmf_summation(obs):
+  """count_forecast / count_quantile_via_root vs a brute-force cumulative sum of the pmf
+  (nb_log_prob / zinb_log_prob) and sampled moments."""
+  _, model, X, _ = util.make_problem(n_rows=40, width=16, depth=1, observation_model=obs)
+  theta = util.random_theta(model, 5, scale=0.4)
+  out = O.forward(model, theta, X)
+  fc = O.count_forecast(model, theta, out)
+  ks = np.arange(0, 4000, dtype=np.float64)
+  tc, logits = fc['tc'][:, 0], fc['logits']
+  lp = np.stack([(O.zinb_log_prob(np.full_like(logits, k), tc, logits, fc['pi']) if obs == 'ZINB'
+                  else O.nb_log_prob(np.full_like(logits, k), tc, logits)) for k in ks])
+  pmf = np.exp(lp)                                       # (K, E, N)
+  keep = pmf.sum(axis=0) > 1 - 1e-9                      # rows whose mass fits in [0, K)
+  assert keep.mean() > 0.5
+  np.testing.assert_allclose((pmf * ks[:, None, None]).sum(axis=0)[keep], fc['mean'][keep], rtol=1e-6)
+  cdf = np.cumsum(pmf, axis=0)
+  np.testing.assert_allclose(cdf[3][keep], O.count_cdf(fc, np.full((1, 1), 3.0))[keep], rtol=1e-9)
+  rows = keep.all(axis=0)
+  mix = cdf.mean(axis=1)                                 # (K, N)
+  for q in (0.1, 0.5, 0.9):
+    brute = np.argmax(mix >= q, axis=0).astype(np.float64)
+    got = O.count_quantile_via_root(fc, q)
+    assert np.mean(got[rows] == brute[rows]) > 0.95
+    assert np.all(np.abs(got[rows] - brute[rows]) <= 1)

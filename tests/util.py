@@ -8,7 +8,7 @@ from oracle import bnf_oracle as O
 
 def make_problem(n_rows=300, width=64, depth=2, seed=0, interactions=((0, 1), (1, 2)),
                  fourier_degrees=(5, 3, 2), periods=(4.0, 52.1775), harmonics=(2, 10),
-                 T=104):
+                 T=104, observation_model='NORMAL'):
   rng = np.random.default_rng(seed)
   t = rng.integers(0, T, n_rows).astype(np.float64)
   t[0], t[1] = 0, T - 1
@@ -16,8 +16,10 @@ def make_problem(n_rows=300, width=64, depth=2, seed=0, interactions=((0, 1), (1
   X = np.stack([t, lat, lon], axis=1).astype(np.float32).astype(np.float64)
   y = (3 * np.sin(2 * np.pi * t / periods[0]) + np.sin(2 * np.pi * t / periods[-1]) +
        2 * lat * lon + 0.5 * rng.standard_normal(n_rows))
+  if observation_model != 'NORMAL':   # counts with a fair share of zeros
+    y = rng.poisson(np.exp(0.4 * y)) * (rng.random(n_rows) > 0.25)
   y = y.astype(np.float32).astype(np.float64)
-  kw = dict(width=width, depth=depth, input_scales=[T - 1.0, 1.0, 1.0],
+  kw = dict(observation_model=observation_model, width=width, depth=depth, input_scales=[T - 1.0, 1.0, 1.0],
             fourier_degrees=list(fourier_degrees), interactions=[list(p) for p in interactions],
             seasonality_periods=list(periods), num_seasonal_harmonics=list(harmonics))
   return NetSpec(**kw), O.Model(**kw), X, y
