@@ -64,6 +64,11 @@ struct TimedLaunch {
   hipEvent_t t0, t1;
 };
 
+// Row pitch of the transposed pre-activations A_l^T is Bp + kAtPad elements: with pitch Bp
+// (a multiple of 4 KiB in bytes at the benchmark sizes) the 32 columns one store / load
+// instruction touches would all fall on the same L2 channel.
+static constexpr int64_t kAtPad = 128;
+
 struct bnf_handle {
   bnf_config cfg;
   NetDev nd;
@@ -105,6 +110,7 @@ struct bnf_handle {
   size_t fused_lds = 0;
   void* Wf[BNF_MAX_LAYERS]; void* Wb[BNF_MAX_LAYERS];   // fragment-major packed weights
   void* spill = nullptr;
+  bool big_tiles = true;      // env BNF_BIG_TILES=0: 128 x 128 tiles everywhere (perf experiments)
   float* qscratch = nullptr;  // quantile partials: 2*1024*2 + 2 floats
   float* dbg_a = nullptr; float* dbg_b = nullptr;  // small debug staging (gmu/grho)
   uint8_t* is_matrix = nullptr;
@@ -139,7 +145,7 @@ static size_t carve(bnf_handle* h, char* base) {
   h->H0 = take((size_t)Ev * Bp * Fp * es);
   h->H0t = nullptr;   // no transposed copies: the weight-gradient contraction reads row-major (gemm_tn)
   for (int l = 0; l < h->L; ++l) {
-    h->A[l] = h->fused ? nullptr : take((size_t)Ev * W * Bp * es);             // A_l^T (W, Bp)
+    h->A[l] = h->fused ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
     h->H[l] = (l < h->L - 1) ? take((size_t)Ev * Bp * W * es) : nullptr;       // H_{l+1} (Bp, W)
     h->Ht[l] = nullptr;
     h->dZ[l] = fo ? nullptr : take((size_t)Ev * Bp * W * es);
@@ -215,22 +221,39 @@ static void drain_timers(bnf_handle* h) {
 // ---------------------------------------------------------------------------
 // contraction launcher
 // ---------------------------------------------------------------------------
-template <typename T, int EPI, int TAG>
-static void launch_gemm(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep) {
-  g.tiles_m = (g.M + kBM - 1) / kBM;
-  g.tiles_n = (g.N + kBN - 1) / kBN;
+template <typename T, int EPI, int TAG, int WG>
+static void launch_gemm_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep) {
+  constexpr int kTile = 64 * WG, kLds = Mma<T>::lds_bytes(WG);
+  g.tiles_m = (g.M + kTile - 1) / kTile;
+  g.tiles_n = (g.N + kTile - 1) / kTile;
   if (g.splitk < 1) g.splitk = 1;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt<T, EPI, TAG>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt<T, EPI, TAG, WG>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     attr_set = true;
   }
   const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
   EpiArgs ep2 = ep;
   ep2.ablate = h->ablate;
   LaunchScope ls(h, kid);
-  hipLaunchKernelGGL((gemm_nt<T, EPI, TAG>), dim3(blocks), dim3(kThreads), kGemmLds, h->stream, g, ep2);
+  hipLaunchKernelGGL((gemm_nt<T, EPI, TAG, WG>), dim3(blocks), dim3(64 * WG * WG), kLds, h->stream, g, ep2);
+}
+
+// 256 x 256 tiles (16 waves) for the bf16 forward contractions whose output width is a
+// multiple of 256; 128 x 128 tiles otherwise (and always for f32, whose epilogue tile would
+// not fit in LDS).
+template <typename T, int EPI, int TAG>
+static void launch_gemm(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep) {
+  // (measured on C2: forward 916 -> 811 us, forward layer 0 497 -> 445 us; the backward-data
+  // epilogue needs more registers than 16 waves leave it and got slower, 864 -> 1172 us)
+  if constexpr (sizeof(T) == 2 && EPI == EPI_FWD) {
+    if (g.N % 256 == 0 && g.M >= 256 && h->big_tiles) {
+      launch_gemm_wg<T, EPI, TAG, 4>(h, kid, g, ep);
+      return;
+    }
+  }
+  launch_gemm_wg<T, EPI, TAG, 2>(h, kid, g, ep);
 }
 
 template <typename T, int TAG>
@@ -311,14 +334,13 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
     ep.off_act_weight = h->nd.off_law;
     ep.out_a = h->A[l];
     ep.out_h = last ? nullptr : h->H[l];
-    ep.out_t = nullptr;
     ep.vdot = last ? h->vacc : nullptr;
     ep.vdot_batch = Bp;
     ep.off_ko = h->nd.off_kernel[h->L];
     ep.act_batch = Bp * h->W;
-    ep.actt_batch = (int64_t)h->W * Bp;
+    ep.actt_batch = (int64_t)h->W * (Bp + kAtPad);
     ep.ld = h->W;
-    ep.ldt = (int32_t)Bp;
+    ep.ldt = (int32_t)(Bp + kAtPad);
     if (l == 0) launch_gemm<T, EPI_FWD, 0>(h, KID_FWD0, g, ep);
     else launch_gemm<T, EPI_FWD, 1>(h, KID_FWD, g, ep);
   }
@@ -400,7 +422,7 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
     LastBwdArgs a{};
     a.theta = theta; a.theta_stride = h->P;
     a.At = h->A[L - 1]; a.dZ = h->dZ[L - 1];
-    a.act_batch = Bp * h->W; a.actt_batch = (int64_t)h->W * Bp; a.ldt = (int32_t)Bp;
+    a.act_batch = Bp * h->W; a.actt_batch = (int64_t)h->W * (Bp + kAtPad); a.ldt = (int32_t)(Bp + kAtPad);
     a.dv = h->dv; a.dv_batch = Bp; a.grad = h->grad; a.grad_stride = h->P;
     a.n_row_tiles = (int32_t)((rows + 63) / 64);
     a.tiles_per_task = 4;
@@ -429,9 +451,8 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
       ep.off_act_weight = h->nd.off_law;
       ep.in_a = h->A[l - 1];
       ep.out_h = h->dZ[l - 1];
-      ep.out_t = nullptr;
-      ep.act_batch = Bp * h->W; ep.actt_batch = (int64_t)h->W * Bp;
-      ep.ld = h->W; ep.ldt = (int32_t)Bp;
+        ep.act_batch = Bp * h->W; ep.actt_batch = (int64_t)h->W * (Bp + kAtPad);
+      ep.ld = h->W; ep.ldt = (int32_t)(Bp + kAtPad);
       launch_gemm<T, EPI_DGRAD, 1>(h, KID_DGRAD, g, ep);
       wgrad_after_dz<T>(h, nmem, l - 1);
     } else {
@@ -738,6 +759,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   }
   for (int k = 0; k < KID_COUNT; ++k) { h->acc_ms[k] = 0; h->acc_calls[k] = 0; }
   if (const char* ab = getenv("BNF_ABLATE")) h->ablate = atoi(ab);
+  if (const char* bt = getenv("BNF_BIG_TILES")) h->big_tiles = atoi(bt) != 0;
   {
     // fused row-panel pipeline: training handles with W = 128 / 256 / 512 and F <= 128
     int want = cfg->pipeline;  // 0 auto, 1 unfused, 2 fused
@@ -1034,7 +1056,7 @@ int bnf_debug_activation(bnf_handle* h, int32_t what, float* out) {
   if (what == 0) { src = h->H0; batch = Bp * h->Fp; ld = h->Fp; cols = h->F; }
   else if (what >= 1 && what < h->L) { src = h->H[what - 1]; batch = Bp * h->W; ld = h->W; cols = h->W; }
   else if (what >= 100 && what < 100 + h->L) {
-    src = h->A[what - 100]; batch = (int64_t)h->W * Bp; ld = (int)Bp; cols = h->W; transposed = 1;
+    src = h->A[what - 100]; batch = (int64_t)h->W * (Bp + kAtPad); ld = (int)(Bp + kAtPad); cols = h->W; transposed = 1;
   } else if (what >= 300 && what < 300 + h->L) { src = h->dZ[what - 300]; batch = Bp * h->W; ld = h->W; cols = h->W; }
   else if (what == 200) {
     for (int e = 0; e < h->Ev; ++e)

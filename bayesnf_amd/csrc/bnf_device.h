@@ -11,6 +11,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Perf-experiment switches (env BNF_ABLATE) exist only in builds made with
+// -DBNF_ENABLE_ABLATE (make ABLATE=1); production kernels carry no such branches.
+#ifdef BNF_ENABLE_ABLATE
+#define BNF_ABL(args, bit) ((args).ablate & (bit))
+#else
+#define BNF_ABL(args, bit) false
+#endif
+
 namespace bnf {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_fused_fwd_bwd(const FusedA
     const int e = item / a.n_tiles, tile = item - e * a.n_tiles;
     const int64_t r0 = (int64_t)tile * BM;
     const int n_valid_true = (int)min((int64_t)BM, a.B - r0);
-    const int n_valid = (a.ablate & 8) ? 0 : n_valid_true;   // ablation: nothing copied, nothing "valid"
+    const int n_valid = BNF_ABL(a, 8) ? 0 : n_valid_true;   // ablation: nothing copied, nothing "valid"
     const float* th = a.theta + (int64_t)e * a.theta_stride;
     float* gr = a.grad + (int64_t)e * a.grad_stride;
     const float alpha = sigmoidf(th[a.off_law]);
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_fused_fwd_bwd(const FusedA
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
       const int K = (l == 0) ? Fp : W;
-      if (!(a.ablate & 1))
+      if (!BNF_ABL(a, 1))
         fused_gemm<T, NT>(acc, (l == 0) ? H0s : Xs, K * ES + 16,
                           reinterpret_cast<const T*>(a.Wfwd[l]) + (int64_t)e * a.wfwd_batch[l], K / 16, nt0,
                           lane);
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_fused_fwd_bwd(const FusedA
             const int col = (nt0 + j) * 32 + frow;
             const float bias = th[a.off_bias[l] + col];
             const int f = (i * NT + j) * 2;
-            if (!(a.ablate & 2)) tile_fwd_mid<T, kXPitch>(acc[i][j], gamma, scale, bias, alpha,
+            if (!BNF_ABL(a, 2)) tile_fwd_mid<T, kXPitch>(acc[i][j], gamma, scale, bias, alpha,
                                      xs_off + (i * 32 + 4 * kg) * kXPitch + col * ES,
                                      sp_base + ((int64_t)(wave * 4 * NT + f) * 64 + lane) * 8,
                                      sp_base + ((int64_t)(wave * 4 * NT + f + 1) * 64 + lane) * 8);
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_fused_fwd_bwd(const FusedA
               const int col = (nt0 + j) * 32 + frow;
               const float kov = th[a.off_ko + col] * inv_sw;
               TileSums ts{0.f, 0.f, 0.f, 0.f};
-              if (!(a.ablate & 2)) ts = tile_last_bwd<T, kXPitch>(acc[i][j], dvr, kov, gamma, alpha,
+              if (!BNF_ABL(a, 2)) ts = tile_last_bwd<T, kXPitch>(acc[i][j], dvr, kov, gamma, alpha,
                                                                   xs_off + (i * 32 + 4 * kg) * kXPitch + col * ES);
               s_alpha += ts.c;
               s_gamma += ts.d;
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_fused_fwd_bwd(const FusedA
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-      if (!(a.ablate & 1))
+      if (!BNF_ABL(a, 1))
         fused_gemm<T, NT>(acc, Xs, kXPitch,
                           reinterpret_cast<const T*>(a.Wbwd[l]) + (int64_t)e * a.wbwd_batch[l], W / 16, nt0,
                           lane);
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_fused_fwd_bwd(const FusedA
           const int col = (nt0 + j) * 32 + frow;
           const int f = (i * NT + j) * 2;
           TileSums ts{0.f, 0.f, 0.f, 0.f};
-          if (!(a.ablate & 2)) ts = tile_bwd_mid<T, kXPitch>(
+          if (!BNF_ABL(a, 2)) ts = tile_bwd_mid<T, kXPitch>(
               acc[i][j], inv_sw_b, gamma, alpha, xs_off + (i * 32 + 4 * kg) * kXPitch + col * ES,
               sp_base + ((int64_t)(wave * 4 * NT + f) * 64 + lane) * 8,
               sp_base + ((int64_t)(wave * 4 * NT + f + 1) * 64 + lane) * 8);
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_fused_fwd_bwd(const FusedA
       const T* wp = reinterpret_cast<const T*>(a.Wbwd[0]) + (int64_t)e * a.wbwd_batch[0];
       const int KS = W / 16;
       float* dh0 = a.dH0t + (int64_t)e * a.dh0_batch;
-      for (int t = wave; t < n_t && !(a.ablate & 32); t += 4) {
+      for (int t = wave; t < n_t && !BNF_ABL(a, 32); t += 4) {
         const int mi = t / ct, ni = t - mi * ct;
         f32x16 acc0;
 #pragma unroll

@@ -29,9 +29,8 @@ namespace bnf {
 
 enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_DGRAD0 = 2, EPI_WGRAD = 3, EPI_PLAIN = 4 };
 
-constexpr int kBM = 128, kBN = 128, kRowBytes = 128, kThreads = 256;
-constexpr int kStageBytes = (kBM + kBN) * kRowBytes;  // 32 KiB
-// 64 KiB for the double-buffered K loop; the f32 epilogue tile (128 x 132 x 4 B) needs 66 KiB
+constexpr int kBM = 128, kBN = 128, kThreads = 256;
+// gemm_tn: 2 x 32 KiB stages; gemm_nt<float>: the f32 epilogue tile (128 x 132 x 4 B) needs 66 KiB
 constexpr int kGemmLds = 128 * (kBN + 4) * 4;
 
 struct GemmArgs {
@@ -50,8 +49,7 @@ struct EpiArgs {
   int32_t off_bias, off_layer_scale, off_act_weight;
   // activations: row-major (rows, ld) and transposed (ld, ldt) copies
   void* out_a;         // FWD: pre-activation A_l^T (transposed only)
-  void* out_h;         // FWD: H_{l+1} row-major (null for the last layer) ; DGRAD: dZ_l
-  void* out_t;         // FWD: H_{l+1}^T (may be null) ; DGRAD: dZ_l^T
+  void* out_h;         // FWD: H_{l+1} row-major (null for the last layer) ; DGRAD: dZ_l row-major
   const void* in_a;    // DGRAD: A_l^T
   float* vdot;         // FWD (last layer): (members, vdot_batch) += H . k_o (un-normalised)
   int64_t vdot_batch;
@@ -74,10 +72,30 @@ struct EpiArgs {
 template <typename T>
 struct Mma;
 
+// K-tile geometry per element type.  An LDS operand tile is 128 rows of kRowBytes; one
+// LDS-DMA wave instruction (1 KiB) fills 1024 / kRowBytes consecutive rows, lane l ->
+// (row l / kChunks, physical 16-byte chunk l % kChunks), and physical chunk c' of a row holds
+// logical chunk c' ^ swz(row).  The swizzles make every ds_read_b128 lane group (16 lanes,
+// MI355X_MICROARCH.md LDS table) cover all 64 banks:
+//   128-byte rows (8 chunks): swz = (row >> 1) & 7      64-byte rows (4 chunks): swz = (row >> 2) & 3
+// bf16 uses the SHORT rows: a ring of three 16 KiB stages (48 KiB, also the epilogue tile), so
+// three workgroups share a CU and each keeps two K tiles of loads in flight while it
+// multiplies a third.
 template <>
 struct Mma<bf16_t> {
-  static constexpr int kTileK = 64;  // elements per 128-byte row
-  static constexpr int kSteps = 4;   // MFMA k-steps (16 elements) per tile
+  static constexpr int kRowBytes = 64;
+  static constexpr int kTileK = 32;  // elements per row
+  static constexpr int kSteps = 2;   // MFMA k-steps (16 elements) per tile
+  static constexpr int kStages = 3;   // ring of three K tiles
+  // LDS of a (64 WG x 64 WG) tile: the larger of the ring and the epilogue tile (pitch + 16 B)
+  __host__ __device__ static constexpr int lds_bytes(int wg) {
+    const int ring = kStages * 2 * 64 * wg * kRowBytes, tile = 64 * wg * (64 * wg + 8) * 2;
+    return ring > tile ? ring : tile;
+  }
+  // registers: 3 waves / SIMD for the 2 x 2 grid (LDS allows 3 workgroups per CU), 4 for the
+  // 4 x 4 grid (one 16-wave workgroup per CU)
+  __host__ __device__ static constexpr int min_waves(int wg) { return wg == 2 ? 3 : 4; }
+  __device__ static __forceinline__ int swz(int row) { return (row >> 2) & 3; }
   struct Frag {
     bf16x8 v;
   };
@@ -94,8 +112,16 @@ struct Mma<bf16_t> {
 
 template <>
 struct Mma<float> {
+  static constexpr int kRowBytes = 128;
   static constexpr int kTileK = 32;
   static constexpr int kSteps = 2;  // k-groups of 16 floats (64 bytes)
+  static constexpr int kStages = 2;
+  __host__ __device__ static constexpr int lds_bytes(int wg) {
+    const int ring = kStages * 2 * 64 * wg * kRowBytes, tile = 64 * wg * (64 * wg + 4) * 4;
+    return ring > tile ? ring : tile;
+  }
+  __host__ __device__ static constexpr int min_waves(int wg) { return 2; }
+  __device__ static __forceinline__ int swz(int row) { return (row >> 1) & 7; }
   struct Frag {
     f32x4 lo, hi;
   };
@@ -125,14 +151,26 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total) {
   return first + slot;
 }
 
-template <typename T, int EPI, int TAG>
-__global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const EpiArgs ep) {
+// WG x WG waves per workgroup, each wave a 64 x 64 sub-tile: WG = 2 -> 128 x 128 tiles (any
+// width), WG = 4 -> 256 x 256 tiles with 16 waves (bf16, widths that are multiples of 256).
+// The K loop of the small tile is bound by the L2 -> LDS operand stream (64 flop / byte; the
+// loop does not speed up with occupancy or prefetch depth, profiles/r01g); the large tile
+// halves that stream and quarters the number of workgroups and reduction atomics.
+template <typename T, int EPI, int TAG, int WG>
+__global__ __launch_bounds__(64 * WG * WG, Mma<T>::min_waves(WG)) void gemm_nt(const GemmArgs g, const EpiArgs ep) {
   using M_ = Mma<T>;
+  constexpr int kBM = 64 * WG, kBN = 64 * WG, kThreads = 64 * WG * WG, kWaves = WG * WG;
+  constexpr int kRowBytes = M_::kRowBytes;
+  constexpr int kStageBytes = (kBM + kBN) * kRowBytes;
+  constexpr int kChunks = kRowBytes / 16;           // 16-byte chunks per row
+  constexpr int kRowsPerInstr = 64 / kChunks;       // rows one LDS-DMA wave instruction fills
+  constexpr int kPerWave = kBM / kRowsPerInstr / kWaves;   // instructions per wave, operand and stage
+  static_assert(kPerWave >= 1 && kPerWave * kRowsPerInstr * kWaves == kBM, "staging map");
   constexpr bool FAST = Elem<T>::kFast;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WG, wc = wave % WG;
 
   // ---- which (member, k-split, tile) ----------------------------------------
   const uint32_t per_member = (uint32_t)(g.tiles_m * g.tiles_n * g.splitk);
@@ -154,18 +192,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
   const char* Bb = reinterpret_cast<const char*>(g.B) + (int64_t)e * g.b_batch * Elem<T>::kBytes;
 
   // ---- staging map: global -> LDS by LDS-DMA (global_load_lds, 16 B per lane) ---
-  // One wave instruction fills 8 consecutive 128-byte rows (lane l -> row l/8,
-  // physical chunk l%8).  The XOR swizzle lives on the SOURCE side: physical chunk
-  // c' of a row holds logical chunk c' ^ ((row >> 1) & 7).  No staging VGPRs and no
-  // ds_write traffic; each wave issues 4 A + 4 B instructions per K tile.
-  const char* a_src[4];
-  const char* b_src[4];
-  int lds_base[4];
+  // One wave instruction fills kRowsPerInstr consecutive rows.  The XOR swizzle lives on
+  // the SOURCE side, so there are no staging VGPRs and no ds_write traffic; each wave
+  // issues kPerWave A + kPerWave B instructions per K tile.
+  const char* a_src[kPerWave];
+  const char* b_src[kPerWave];
+  int lds_base[kPerWave];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r0 = (wave * 4 + i) * 8;
-    const int row = r0 + (lane >> 3), cp = lane & 7;
-    const int c = cp ^ ((row >> 1) & 7);
+  for (int i = 0; i < kPerWave; ++i) {
+    const int r0 = (wave * kPerWave + i) * kRowsPerInstr;
+    const int row = r0 + lane / kChunks, cp = lane % kChunks;
+    const int c = cp ^ M_::swz(row);
     const int am = min(m0 + row, g.M - 1), bn = min(n0 + row, g.N - 1);
     a_src[i] = Ab + ((int64_t)am * g.a_ld) * Elem<T>::kBytes + c * 16;
     b_src[i] = Bb + ((int64_t)bn * g.b_ld) * Elem<T>::kBytes + c * 16;
@@ -207,7 +244,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
     char* sA = smem + buf * kStageBytes;
     char* sB = sA + kBM * kRowBytes;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kPerWave; ++i) {
       __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[i] + koff), (lds_void_t*)(sA + lds_base[i]), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((glb_void_t*)(b_src[i] + koff), (lds_void_t*)(sB + lds_base[i]), 16, 0, 0);
     }
@@ -220,16 +257,36 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
   for (int i = 0; i < 2; ++i) {
     a_row[i] = wr * 64 + i * 32 + frow;
     b_row[i] = wc * 64 + i * 32 + frow;
-    a_swz[i] = (a_row[i] >> 1) & 7;
-    b_swz[i] = (b_row[i] >> 1) & 7;
+    a_swz[i] = M_::swz(a_row[i]);
+    b_swz[i] = M_::swz(b_row[i]);
   }
 
-  if (kt0 < kt1 && !(ep.ablate & 16)) {
-    stage(0, kt0);
-    __syncthreads();  // (the barrier's fence drains the LDS-DMA: vmcnt(0))
+  // K loop: a ring of kStages LDS stages, filled kStages-1 tiles ahead by LDS-DMA.  One
+  // s_barrier per K tile: passing it means (a) every wave's share of tile kt has landed
+  // (each wave first waits on its own vmcnt, allowing only the younger prefetches to stay in
+  // flight) and (b) every wave is done reading tile kt-1, whose buffer the next prefetch
+  // overwrites.  (__syncthreads() would drain vmcnt to 0 and serialise load and compute.)
+  constexpr int kStages = M_::kStages;
+  // s_waitcnt immediates (gfx9 encoding): vmcnt in [3:0] + [15:14], expcnt 7 / lgkmcnt 15 = no wait
+  constexpr int kAhead = (kStages - 2) * 2 * kPerWave;   // DMA instructions of the younger stages
+  static_assert(kAhead < 64, "vmcnt range");
+  constexpr int kWaitAhead = (kAhead & 15) | ((kAhead >> 4) << 14) | 0x0F70;
+  constexpr int kWaitAll = 0x0F70;
+  if (kt0 < kt1 && !BNF_ABL(ep, 16)) {
+#pragma unroll
+    for (int s = 0; s < kStages - 1; ++s)
+      if (kt0 + s < kt1) stage(s, kt0 + s);
+    int buf = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-      const int buf = (kt - kt0) & 1;
-      if (kt + 1 < kt1) stage(buf ^ 1, kt + 1);
+      if (kt + kStages - 2 < kt1) __builtin_amdgcn_s_waitcnt(kWaitAhead);
+      else __builtin_amdgcn_s_waitcnt(kWaitAll);
+      __builtin_amdgcn_s_barrier();
+      {
+        const int pre = kt + kStages - 1;
+        int pbuf = buf + kStages - 1;
+        if (pbuf >= kStages) pbuf -= kStages;
+        if (pre < kt1) stage(pbuf, pre);
+      }
       const char* sA = smem + buf * kStageBytes;
       const char* sB = sA + kBM * kRowBytes;
 #pragma unroll
@@ -245,8 +302,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
 #pragma unroll
           for (int j = 0; j < 2; ++j) M_::mma(acc[i][j], fa[i], fb[j]);
       }
-      __syncthreads();
+      if (++buf == kStages) buf = 0;
     }
+    __syncthreads();   // the epilogue reuses the stage buffers
   }
 
   // ---- epilogues --------------------------------------------------------------
@@ -338,7 +396,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
     const float alpha = sigmoidf(th[ep.off_act_weight]);
     T* oat = reinterpret_cast<T*>(ep.out_a) + (int64_t)e * ep.actt_batch;   // A_l^T (W, ldt)
     T* oh = ep.out_h ? reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch : nullptr;
-    T* ot = ep.out_t ? reinterpret_cast<T*>(ep.out_t) + (int64_t)e * ep.actt_batch : nullptr;
     float* vd = ep.vdot ? ep.vdot + (int64_t)e * ep.vdot_batch : nullptr;
     T* tile = reinterpret_cast<T*>(smem);
     float pdot[2][16];
@@ -361,31 +418,24 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             av[q] = gamma * (acc[i][j][rg * 4 + q] * ep.scale + bias);
-            hv[q] = (ep.ablate & 4) ? av[q] : act_fwd<FAST>(av[q], alpha);
+            hv[q] = BNF_ABL(ep, 4) ? av[q] : act_fwd<FAST>(av[q], alpha);
             pdot[i][rg * 4 + q] += hv[q] * kov;
           }
-          if (oh && !(ep.ablate & 2)) {
+          if (oh && !BNF_ABL(ep, 2)) {
             const int lr = wr * 64 + 4 * kg + i * 32 + 8 * rg, lc = wc * 64 + j * 32 + frow;
 #pragma unroll
             for (int q = 0; q < 4; ++q) Elem<T>::store(tile + (lr + q) * kPitch + lc, hv[q]);
           }
-          T* pa = oat + (int64_t)n * ep.ldt + mb;
-          if (ep.ablate & 1) {
-            asm volatile("" ::"v"(av[0] + av[1] + av[2] + av[3] + hv[0] + hv[1] + hv[2] + hv[3]));
-          } else if (mb + 3 < g.M) {
-            store4(pa, av[0], av[1], av[2], av[3]);
-            if (ot) store4(ot + (int64_t)n * ep.ldt + mb, hv[0], hv[1], hv[2], hv[3]);
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (mb + q < g.M) {
-                Elem<T>::store(pa + q, av[q]);
-                if (ot) Elem<T>::store(ot + (int64_t)n * ep.ldt + mb + q, hv[q]);
-              }
-          }
+          // A_l^T has ldt >= tiles_m * 128 columns: the four-row vector is always in bounds
+          // (rows past M hold copies of the last row -- the operand loader clamps -- which
+          // the backward pass masks out)
+          if (!BNF_ABL(ep, 1)) store4(oat + (int64_t)n * ep.ldt + mb, av[0], av[1], av[2], av[3]);
+          // keep the 32 four-row groups sequential: without the fence the scheduler
+          // interleaves all of them and the live ranges spill
+          __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (vd && !(ep.ablate & 8)) {
+    if (vd && !BNF_ABL(ep, 8)) {
       // output-layer row dot (models.py:269-273): sum over this tile's columns,
       // then one atomic per row and wave.
 #pragma unroll
@@ -397,7 +447,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
           if (frow == 16 && m < g.M) atomicAdd(&vd[m], sacc);
         }
     }
-    if (oh && !(ep.ablate & 2)) {
+    if (oh && !BNF_ABL(ep, 2)) {
       __syncthreads();
       tile_to_global(oh, ep.ld);
     }
@@ -406,7 +456,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
     const float gamma = softplusf(th[ep.off_layer_scale]);
     const float alpha = sigmoidf(th[ep.off_act_weight]);
     T* oz = reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch;
-    T* ot = ep.out_t ? reinterpret_cast<T*>(ep.out_t) + (int64_t)e * ep.actt_batch : nullptr;
     T* tile = reinterpret_cast<T*>(smem);
     float s_alpha = 0.f, s_gamma = 0.f, colsum[2] = {0.f, 0.f};
 #pragma unroll
@@ -419,13 +468,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
         for (int rg = 0; rg < 4; ++rg) {
           const int mb = mw + i * 32 + 8 * rg;
           float av[4], zv[4];
-          const bool full = mb + 3 < g.M;
           unpack(apre[j][i][rg], av);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float dh = (mb + q < g.M) ? acc[i][j][rg * 4 + q] * ep.scale : 0.f;
             ActOut o;
-            if (ep.ablate & 4) { o.h = av[q]; o.dact = 1.f; o.ediff = av[q]; }
+            if (BNF_ABL(ep, 4)) { o.h = av[q]; o.dact = 1.f; o.ediff = av[q]; }
             else o = act_eval<FAST>(av[q], alpha);
             s_alpha += dh * o.ediff;
             const float da = dh * o.dact;
@@ -434,44 +482,44 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt(const GemmArgs g, const E
             colsum[j] += zv[q];
           }
           const int lr = wr * 64 + 4 * kg + i * 32 + 8 * rg, lc = wc * 64 + j * 32 + frow;
-          if (!(ep.ablate & 2)) {
+          if (!BNF_ABL(ep, 2)) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) Elem<T>::store(tile + (lr + q) * kPitch + lc, zv[q]);
           }
-          if (ot) {
-            T* pt = ot + (int64_t)n * ep.ldt + mb;
-            if (full) store4(pt, zv[0], zv[1], zv[2], zv[3]);
-            else
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                if (mb + q < g.M) Elem<T>::store(pt + q, zv[q]);
-          }
+          __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
-    if (!(ep.ablate & 2)) tile_to_global(oz, ep.ld);
+    if (!BNF_ABL(ep, 2)) tile_to_global(oz, ep.ld);
     __syncthreads();
     // block reduction of bias / scale gradients through LDS
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const float c = colsum[j] + __shfl_xor(colsum[j], 32, 64);
-      if (lane < 32) red[wr * 128 + wc * 64 + j * 32 + lane] = c;
+      if (lane < 32) red[wr * kBN + wc * 64 + j * 32 + lane] = c;
     }
     const float sa = wave_sum(s_alpha), sg = wave_sum(s_gamma);
     if (lane == 0) {
-      red[256 + wave * 2] = sa;
-      red[257 + wave * 2] = sg;
+      red[WG * kBN + wave * 2] = sa;
+      red[WG * kBN + wave * 2 + 1] = sg;
     }
     __syncthreads();
     float* gr = ep.grad + (int64_t)e * ep.grad_stride;
-    if (tid < 128) {
+    if (tid < kBN) {
       const int n = n0 + tid;
-      if (n < g.N) atomicAdd(&gr[ep.off_bias + n], red[tid] + red[128 + tid]);
+      float c = 0.f;
+#pragma unroll
+      for (int r = 0; r < WG; ++r) c += red[r * kBN + tid];
+      if (n < g.N) atomicAdd(&gr[ep.off_bias + n], c);
     }
     if (tid == 0) {
-      const float ta = red[256] + red[258] + red[260] + red[262];
-      const float tg = red[257] + red[259] + red[261] + red[263];
+      float ta = 0.f, tg = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < kWaves; ++w2) {
+        ta += red[WG * kBN + w2 * 2];
+        tg += red[WG * kBN + w2 * 2 + 1];
+      }
       atomicAdd(&gr[ep.off_act_weight], alpha * (1.f - alpha) * ta);
       atomicAdd(&gr[ep.off_layer_scale], sigmoidf(th[ep.off_layer_scale]) * tg / gamma);
     }

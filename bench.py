@@ -44,8 +44,9 @@ KERNEL_SYMBOL = {
     'gemm_fwd': 'void bnf::gemm_nt<{T}, 0, 1>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_dgrad': 'void bnf::gemm_nt<{T}, 1, 1>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_dgrad0': 'void bnf::gemm_nt<{T}, 2, 0>(bnf::GemmArgs, bnf::EpiArgs)',
-    'gemm_wgrad_l0': 'void bnf::gemm_nt<{T}, 3, 0>(bnf::GemmArgs, bnf::EpiArgs)',
-    'gemm_wgrad': 'void bnf::gemm_nt<{T}, 3, 1>(bnf::GemmArgs, bnf::EpiArgs)',
+    'gemm_wgrad_l0': 'void bnf::gemm_tn<{T}, 0>(bnf::GemmArgs, bnf::EpiArgs)',
+    'gemm_wgrad': 'void bnf::gemm_tn<{T}, 1>(bnf::GemmArgs, bnf::EpiArgs)',
+    'last_bwd': 'void bnf::k_last_bwd<{T}>',
     'fused_fwd_bwd': 'void bnf::k_fused_fwd_bwd<{T}',
 }
 

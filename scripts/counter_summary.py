@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Per-kernel averages (per launch) of whatever counters the passes under <dir>/pass*/ hold."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def main(out_dir):
+  vals = defaultdict(lambda: defaultdict(list))
+  for path in glob.glob(os.path.join(out_dir, 'pass*', '**', '*counter_collection*.csv'), recursive=True):
+    with open(path) as f:
+      for row in csv.DictReader(f):
+        vals[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
+  counters = sorted({c for k in vals for c in vals[k]})
+  kernels = [k for k in vals if k.startswith(('void bnf', 'bnf::'))]
+  key = 'SQ_BUSY_CYCLES' if 'SQ_BUSY_CYCLES' in counters else (counters[0] if counters else None)
+  kernels.sort(key=lambda k: -sum(vals[k].get(key, [0])))
+  short = lambda k: (k.replace('void ', '').replace('bnf::', '').split('(')[0])[:34]
+  print('| counter (avg / launch) | ' + ' | '.join(short(k) for k in kernels) + ' |')
+  print('|---|' + '---|' * len(kernels))
+  for c in counters:
+    cells = []
+    for k in kernels:
+      v = vals[k].get(c)
+      cells.append(f'{sum(v) / len(v):.4g}' if v else '-')
+    print(f'| {c} | ' + ' | '.join(cells) + ' |')
+
+
+if __name__ == '__main__':
+  main(sys.argv[1])
