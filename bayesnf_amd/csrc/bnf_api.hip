@@ -52,12 +52,12 @@ static int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 enum KernelId {
   KID_PACK = 0, KID_FEAT, KID_FWD0, KID_FWD, KID_ROWLOSS, KID_LASTBWD, KID_DGRAD, KID_DGRAD0,
-  KID_FEATBWD, KID_WGRAD0, KID_WGRAD, KID_ADAM, KID_VISAMPLE, KID_VIADAM, KID_FUSED, KID_COUNT
+  KID_FEATBWD, KID_WGRAD0, KID_WGRAD, KID_ADAM, KID_VISAMPLE, KID_VIADAM, KID_FUSED, KID_FWDLAST, KID_COUNT
 };
 static const char* kKernelNames[KID_COUNT] = {
     "pack_weights", "featurize", "gemm_fwd_l0", "gemm_fwd", "row_loss", "last_bwd", "gemm_dgrad",
     "gemm_dgrad0", "feat_bwd", "gemm_wgrad_l0", "gemm_wgrad", "adam_map", "vi_sample", "vi_adam",
-    "fused_fwd_bwd"};
+    "fused_fwd_bwd", "gemm_fwd_last"};
 
 struct TimedLaunch {
   int kid;
@@ -110,6 +110,11 @@ struct bnf_handle {
   size_t fused_lds = 0;
   void* Wf[BNF_MAX_LAYERS]; void* Wb[BNF_MAX_LAYERS];   // fragment-major packed weights
   void* spill = nullptr;
+  unsigned long long* prof_buf = nullptr;   // phase clocks (ABLATE builds)
+  double prof_gap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double prof_blocks = 0;
+  int prof_threads = 0;
+  bool fuse_last = false;     // last layer + likelihood + its backward in one kernel (EPI_LAST)
   bool big_tiles = true;      // env BNF_BIG_TILES=0: 128 x 128 tiles everywhere (perf experiments)
   float* qscratch = nullptr;  // quantile partials: 2*1024*2 + 2 floats
   float* dbg_a = nullptr; float* dbg_b = nullptr;  // small debug staging (gmu/grho)
@@ -145,7 +150,7 @@ static size_t carve(bnf_handle* h, char* base) {
   h->H0 = take((size_t)Ev * Bp * Fp * es);
   h->H0t = nullptr;   // no transposed copies: the weight-gradient contraction reads row-major (gemm_tn)
   for (int l = 0; l < h->L; ++l) {
-    h->A[l] = h->fused ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
+    h->A[l] = (h->fused || (h->fuse_last && l == h->L - 1)) ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
     h->H[l] = (l < h->L - 1) ? take((size_t)Ev * Bp * W * es) : nullptr;       // H_{l+1} (Bp, W)
     h->Ht[l] = nullptr;
     h->dZ[l] = fo ? nullptr : take((size_t)Ev * Bp * W * es);
@@ -221,23 +226,62 @@ static void drain_timers(bnf_handle* h) {
 // ---------------------------------------------------------------------------
 // contraction launcher
 // ---------------------------------------------------------------------------
-template <typename T, int EPI, int TAG, int WG>
+// Phase clocks (perf experiments; ABLATE builds only): BNF_PHASE_PROF=<kernel name> makes every
+// launch of that contraction record clock64() at up to 8 marks per workgroup; the mean gaps
+// are printed when the handle is destroyed.
+static void phase_prof_begin(bnf_handle* h, int kid, unsigned blocks, EpiArgs* ep) {
+  ep->prof = nullptr;
+#ifdef BNF_ENABLE_ABLATE
+  const char* want = getenv("BNF_PHASE_PROF");
+  if (!want || strcmp(want, kKernelNames[kid]) != 0) return;
+  if (!h->prof_buf) (void)hipMalloc(&h->prof_buf, (size_t)(1 << 20) * 8 * sizeof(unsigned long long));
+  if (blocks > (1u << 20)) return;
+  (void)hipMemsetAsync(h->prof_buf, 0, (size_t)blocks * 64, h->stream);
+  ep->prof = h->prof_buf;
+#endif
+}
+static void phase_prof_end(bnf_handle* h, int kid, unsigned blocks, int threads) {
+#ifdef BNF_ENABLE_ABLATE
+  const char* want = getenv("BNF_PHASE_PROF");
+  if (!want || strcmp(want, kKernelNames[kid]) != 0 || !h->prof_buf || blocks > (1u << 20)) return;
+  std::vector<unsigned long long> host((size_t)blocks * 8);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipMemcpy(host.data(), h->prof_buf, host.size() * 8, hipMemcpyDeviceToHost);
+  for (unsigned b = 0; b < blocks; ++b) {
+    unsigned long long prev = host[(size_t)b * 8];
+    for (int k = 1; k < 8; ++k) {
+      const unsigned long long t = host[(size_t)b * 8 + k];
+      if (!t) continue;
+      h->prof_gap[k] += (double)(t - prev);
+      prev = t;
+    }
+    h->prof_gap[0] += (double)(prev - host[(size_t)b * 8]);
+  }
+  h->prof_blocks += blocks;
+  h->prof_threads = threads;
+#endif
+}
+
+template <typename T, int EPI, int TAG, int WGM, int WGN>
 static void launch_gemm_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep) {
-  constexpr int kTile = 64 * WG, kLds = Mma<T>::lds_bytes(WG);
-  g.tiles_m = (g.M + kTile - 1) / kTile;
-  g.tiles_n = (g.N + kTile - 1) / kTile;
+  constexpr int kLds = Mma<T>::lds_bytes(WGM, WGN, epi_extra_lds(EPI, WGM, WGN));
+  static_assert(kLds <= 160 * 1024, "LDS per workgroup");
+  g.tiles_m = (g.M + 64 * WGM - 1) / (64 * WGM);
+  g.tiles_n = (g.N + 64 * WGN - 1) / (64 * WGN);
   if (g.splitk < 1) g.splitk = 1;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt<T, EPI, TAG, WG>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt<T, EPI, TAG, WGM, WGN>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     attr_set = true;
   }
   const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
   EpiArgs ep2 = ep;
   ep2.ablate = h->ablate;
+  phase_prof_begin(h, kid, blocks, &ep2);
   LaunchScope ls(h, kid);
-  hipLaunchKernelGGL((gemm_nt<T, EPI, TAG, WG>), dim3(blocks), dim3(64 * WG * WG), kLds, h->stream, g, ep2);
+  hipLaunchKernelGGL((gemm_nt<T, EPI, TAG, WGM, WGN>), dim3(blocks), dim3(64 * WGM * WGN), kLds, h->stream, g, ep2);
+  phase_prof_end(h, kid, blocks, 64 * WGM * WGN);
 }
 
 // 256 x 256 tiles (16 waves) for the bf16 forward contractions whose output width is a
@@ -249,11 +293,36 @@ static void launch_gemm(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep) {
   // epilogue needs more registers than 16 waves leave it and got slower, 864 -> 1172 us)
   if constexpr (sizeof(T) == 2 && EPI == EPI_FWD) {
     if (g.N % 256 == 0 && g.M >= 256 && h->big_tiles) {
-      launch_gemm_wg<T, EPI, TAG, 4>(h, kid, g, ep);
+      launch_gemm_wg<T, EPI, TAG, 4, 4>(h, kid, g, ep);
       return;
     }
   }
-  launch_gemm_wg<T, EPI, TAG, 2>(h, kid, g, ep);
+  launch_gemm_wg<T, EPI, TAG, 2, 2>(h, kid, g, ep);
+}
+
+// Widths the one-kernel last layer (EPI_LAST: 128-row panels spanning the layer) supports.
+template <typename T>
+static bool fused_last_supported(int W) {
+  return W == 64 || W == 128 || W == 256 || (W == 512 && sizeof(T) == 2);
+}
+template <typename T, int TAG>
+static void launch_fwd_last_obs(bnf_handle* h, GemmArgs g, const EpiArgs& ep) {
+  switch (g.N) {
+    case 64: launch_gemm_wg<T, EPI_LAST, TAG, 2, 1>(h, KID_FWDLAST, g, ep); break;
+    case 128: launch_gemm_wg<T, EPI_LAST, TAG, 2, 2>(h, KID_FWDLAST, g, ep); break;
+    case 256: launch_gemm_wg<T, EPI_LAST, TAG, 2, 4>(h, KID_FWDLAST, g, ep); break;
+    case 512:
+      // 64-row panels: two 8-wave workgroups per CU (3.24 vs 3.28 ms/step for one 16-wave
+      // workgroup on 128-row panels, profiles/r01g)
+      if constexpr (sizeof(T) == 2) launch_gemm_wg<T, EPI_LAST, TAG, 1, 8>(h, KID_FWDLAST, g, ep);
+      break;
+  }
+}
+// TAG 3: NORMAL likelihood only; TAG 4: NB / ZINB as well (lgamma / digamma in the row phase)
+template <typename T>
+static void launch_fwd_last(bnf_handle* h, GemmArgs g, const EpiArgs& ep) {
+  if (ep.obs == BNF_OBS_NORMAL) launch_fwd_last_obs<T, 3>(h, g, ep);
+  else launch_fwd_last_obs<T, 4>(h, g, ep);
 }
 
 template <typename T, int TAG>
@@ -311,7 +380,8 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
                        (T*)nullptr, (int64_t)h->Fp * Bp, (int32_t)Bp,
                        train ? h->ybat : (float*)nullptr, Bp);
   }
-  for (int l = 0; l < h->L; ++l) {
+  const int n_layers = (train && h->fuse_last) ? h->L - 1 : h->L;   // EPI_LAST runs in run_backward
+  for (int l = 0; l < n_layers; ++l) {
     const bool last = l == h->L - 1;
     GemmArgs g{};
     g.A = (l == 0) ? h->H0 : h->H[l - 1];
@@ -406,34 +476,68 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
                          int64_t rows, float c, const LossSink& sink) {
   const int64_t Bp = h->Bp;
   const int L = h->L;
-  {
-    RowLossArgs a{};
-    a.theta = theta; a.theta_stride = h->P; a.B = rows;
-    a.vacc = h->vacc; a.vacc_batch = Bp; a.ybat = h->ybat;
-    a.out = h->out; a.out_batch = Bp; a.dv = h->dv;
-    a.grad = h->grad; a.grad_stride = h->P;
-    a.loss = sink.loss; a.loss_stride = sink.stride; a.S = h->S; a.loss_scale = sink.scale;
-    a.c = c; a.loss_raw = sink.raw;
-    LaunchScope ls(h, KID_ROWLOSS);
-    hipLaunchKernelGGL((k_row_loss<true>), dim3(cdiv(rows, 256), (unsigned)nmem), dim3(256), 0,
-                       h->stream, h->nd, a);
-  }
-  {
-    LastBwdArgs a{};
-    a.theta = theta; a.theta_stride = h->P;
-    a.At = h->A[L - 1]; a.dZ = h->dZ[L - 1];
-    a.act_batch = Bp * h->W; a.actt_batch = (int64_t)h->W * (Bp + kAtPad); a.ldt = (int32_t)(Bp + kAtPad);
-    a.dv = h->dv; a.dv_batch = Bp; a.grad = h->grad; a.grad_stride = h->P;
-    a.n_row_tiles = (int32_t)((rows + 63) / 64);
-    a.tiles_per_task = 4;
-    const int tasks = (h->W / 64) * ((a.n_row_tiles + a.tiles_per_task - 1) / a.tiles_per_task);
-    {
-      LaunchScope ls(h, KID_LASTBWD);
-      hipLaunchKernelGGL((k_last_bwd<T>), dim3(cdiv(tasks, 4), (unsigned)nmem), dim3(256), 0, h->stream,
-                         h->nd, a);
-    }
+  if (h->fuse_last) {
+    // last hidden layer forward + output layer + likelihood + backward through its
+    // activation in one kernel (EPI_LAST): writes out, dZ_{L-1} and every gradient the
+    // row-loss and last-backward kernels produce
+    const int l = L - 1;
+    GemmArgs g{};
+    g.A = (l == 0) ? h->H0 : h->H[l - 1];
+    g.a_ld = (l == 0) ? h->Fp : h->W;
+    g.a_batch = Bp * g.a_ld;
+    g.B = h->Kt[l];
+    g.b_ld = g.a_ld;
+    g.b_batch = h->pack_batch[l];
+    g.M = (int)rows; g.N = h->W; g.K = g.a_ld; g.splitk = 1; g.members = nmem;
+    EpiArgs ep{};
+    ep.theta = theta; ep.theta_stride = h->P;
+    ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->W));
+    ep.off_bias = h->nd.off_bias[l];
+    ep.off_layer_scale = h->nd.off_ls[l];
+    ep.off_act_weight = h->nd.off_law;
+    ep.off_ko = h->nd.off_kernel[L];
+    ep.out_h = h->dZ[l];
+    ep.act_batch = Bp * h->W; ep.ld = h->W;
+    ep.grad = h->grad; ep.grad_stride = h->P;
+    ep.ybat = h->ybat; ep.row_batch = Bp;
+    ep.out = h->out; ep.out_batch = Bp;
+    ep.loss = sink.loss; ep.loss_raw = sink.raw; ep.loss_stride = sink.stride; ep.S = h->S;
+    ep.loss_scale = sink.scale; ep.lik_c = c;
+    ep.off_os = h->nd.off_os; ep.off_bias_out = h->nd.off_bias[L];
+    ep.off_lns = h->nd.off_lns; ep.off_shape = h->nd.off_shape; ep.off_infl = h->nd.off_infl;
+    ep.obs = h->nd.obs;
+    launch_fwd_last<T>(h, g, ep);
     wgrad_after_dz<T>(h, nmem, L - 1);
-  }
+  } else {
+    {
+      RowLossArgs a{};
+      a.theta = theta; a.theta_stride = h->P; a.B = rows;
+      a.vacc = h->vacc; a.vacc_batch = Bp; a.ybat = h->ybat;
+      a.out = h->out; a.out_batch = Bp; a.dv = h->dv;
+      a.grad = h->grad; a.grad_stride = h->P;
+      a.loss = sink.loss; a.loss_stride = sink.stride; a.S = h->S; a.loss_scale = sink.scale;
+      a.c = c; a.loss_raw = sink.raw;
+      LaunchScope ls(h, KID_ROWLOSS);
+      hipLaunchKernelGGL((k_row_loss<true>), dim3(cdiv(rows, 256), (unsigned)nmem), dim3(256), 0,
+                         h->stream, h->nd, a);
+    }
+    {
+      LastBwdArgs a{};
+      a.theta = theta; a.theta_stride = h->P;
+      a.At = h->A[L - 1]; a.dZ = h->dZ[L - 1];
+      a.act_batch = Bp * h->W; a.actt_batch = (int64_t)h->W * (Bp + kAtPad); a.ldt = (int32_t)(Bp + kAtPad);
+      a.dv = h->dv; a.dv_batch = Bp; a.grad = h->grad; a.grad_stride = h->P;
+      a.n_row_tiles = (int32_t)((rows + 63) / 64);
+      a.tiles_per_task = 4;
+      const int tasks = (h->W / 64) * ((a.n_row_tiles + a.tiles_per_task - 1) / a.tiles_per_task);
+      {
+        LaunchScope ls(h, KID_LASTBWD);
+        hipLaunchKernelGGL((k_last_bwd<T>), dim3(cdiv(tasks, 4), (unsigned)nmem), dim3(256), 0, h->stream,
+                           h->nd, a);
+      }
+      wgrad_after_dz<T>(h, nmem, L - 1);
+    }
+}
   for (int l = L - 1; l >= 0; --l) {
     // dH_l = dZ_l . K_l^T / sqrt(fan_in_l)
     GemmArgs g{};
@@ -771,6 +875,10 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
       return fail(BNF_ERR_INVALID, "fused pipeline needs a NORMAL training handle with width 128/256/512 and <= 128 features");
     }
     h->fused = can && want == 2;   // opt-in: measured slower than the layer kernels
+    // pipeline 0 (auto): layer kernels with the one-kernel last layer where the width allows;
+    // pipeline 1: every layer kernel separate and every activation materialised (validation)
+    const bool fl_ok = h->bf16 ? fused_last_supported<bf16_t>(h->W) : fused_last_supported<float>(h->W);
+    h->fuse_last = !cfg->forward_only && !h->fused && want == 0 && fl_ok;
     if (h->fused) {
       h->fused_lds = fused_lds_bytes(h->W, h->Fp, h->es);
       const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / h->fused_lds)));
@@ -786,6 +894,15 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
 void bnf_destroy(bnf_handle* h) {
   if (!h) return;
   for (auto ev : h->event_pool) hipEventDestroy(ev);
+  if (h->prof_buf) {
+    if (h->prof_blocks > 0) {
+      fprintf(stderr, "[phase clocks] %s: %d threads/workgroup, mean cycles per workgroup: total %.0f |",
+              getenv("BNF_PHASE_PROF"), h->prof_threads, h->prof_gap[0] / h->prof_blocks);
+      for (int k = 1; k < 8; ++k) fprintf(stderr, " m%d %.0f", k, h->prof_gap[k] / h->prof_blocks);
+      fprintf(stderr, "\n");
+    }
+    (void)hipFree(h->prof_buf);
+  }
   delete h;
 }
 
@@ -1184,6 +1301,8 @@ double bnf_kernel_flops(const bnf_handle* h, const char* name) {
     return 2.0 * Ev * B * F * W;
   if (!strcmp(name, "gemm_fwd") || !strcmp(name, "gemm_dgrad") || !strcmp(name, "gemm_wgrad"))
     return 2.0 * Ev * B * W * W;
+  if (!strcmp(name, "gemm_fwd_last"))   // last hidden layer + output-layer dot
+    return 2.0 * Ev * B * (h->L > 1 ? W : F) * W + 2.0 * Ev * B * W;
   if (!strcmp(name, "fused_fwd_bwd"))  // forward + dgrad contractions of every layer + output layer
     return 4.0 * Ev * B * (F * W + (h->L - 1) * W * W) + 6.0 * Ev * B * W;
   return 0.0;

@@ -15,8 +15,10 @@
 // -DBNF_ENABLE_ABLATE (make ABLATE=1); production kernels carry no such branches.
 #ifdef BNF_ENABLE_ABLATE
 #define BNF_ABL(args, bit) ((args).ablate & (bit))
+#define BNF_MARK(args, k) do { if ((args).prof && threadIdx.x == 0) (args).prof[(size_t)blockIdx.x * 8 + (k)] = clock64(); } while (0)
 #else
 #define BNF_ABL(args, bit) false
+#define BNF_MARK(args, k) do { } while (0)
 #endif
 
 namespace bnf {
@@ -24,6 +26,7 @@ namespace bnf {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
@@ -163,6 +166,85 @@ __device__ __forceinline__ float sigmoidf(float x) {
 //   h     = act(a)
 //   dact  = alpha * (a > 0 ? 1 : exp(a)) + (1 - alpha) * (1 - tanh(a)^2)
 //   ediff = elu(a) - tanh(a)            (d act / d alpha)
+// digamma for x > 0: shift to x >= 6 by the recurrence, then the asymptotic series
+// (|err| ~ 1e-7 relative in fp32 for the shifted argument).
+__device__ __forceinline__ float digammaf(float x) {
+  float acc = 0.f;
+#pragma unroll 1
+  while (x < 6.f) { acc -= 1.0f / x; x += 1.0f; }
+  const float r = 1.0f / x, r2 = r * r;
+  const float tail = r2 * (1.f / 12.f - r2 * (1.f / 120.f - r2 * (1.f / 252.f - r2 * (1.f / 240.f))));
+  return acc + logf(x) - 0.5f * r - tail;
+}
+
+// log(1 + e^x) / log sigmoid without overflow
+__device__ __forceinline__ float log_sigmoidf(float x) { return -softplusf(-x); }
+
+
+// ---------------------------------------------------------------------------
+// likelihood of one row and its derivatives (models.py:157-191).
+//   ll      log p(y | out, theta)
+//   dout    d loss / d out            with loss = -c * ll
+//   d_par   d loss / d theta_par      par = log_noise_scale (NORMAL) or shape (NB / ZINB)
+//   d_infl  d loss / d inflated_loc_probs (ZINB)
+// ---------------------------------------------------------------------------
+struct RowLoss {
+  float ll, dout, d_par, d_infl;
+};
+
+__device__ __forceinline__ RowLoss row_loss_eval(int obs, const float* __restrict__ th, int off_lns,
+                                                 int off_shape, int off_infl, float yv, float out,
+                                                 float c) {
+  RowLoss o;
+  o.d_infl = 0.f;
+  if (obs == 0 /* BNF_OBS_NORMAL */) {
+    // sigma = 0.01 + exp(lns)
+    const float lns = th[off_lns];
+    const float sigma = 0.01f + expf(lns);
+    const float res = yv - out;
+    const float z = res / sigma;
+    o.ll = -0.5f * z * z - logf(sigma) - 0.918938533204672742f;
+    o.dout = -c * res / (sigma * sigma);
+    o.d_par = -c * (res * res / (sigma * sigma * sigma) - 1.0f / sigma) * expf(lns);
+    return o;
+  }
+  // NB / ZINB: mean = softplus(out), shape = softplus(theta_shape), total_count = 1/shape,
+  // logits = -log shape - log mean;  TFP 0.24 log_prob:
+  //   tc logsig(-logits) + y logsig(logits) + lgamma(tc+y) - lgamma(1+y) - lgamma(tc)
+  const float ths = th[off_shape];
+  const float shape = softplusf(ths);
+  const float tc = 1.0f / shape;
+  const float mean = softplusf(out);
+  const float logits = -logf(shape) - logf(mean);
+  const float sg = sigmoidf(logits);
+  const float lsn = log_sigmoidf(-logits);
+  float lp = tc * lsn + yv * log_sigmoidf(logits) + lgammaf(tc + yv) - lgammaf(1.0f + yv) - lgammaf(tc);
+  float dl_dlogits = yv * (1.0f - sg) - tc * sg;
+  float dl_dtc = lsn + digammaf(tc + yv) - digammaf(tc);
+  if (obs == 2 /* BNF_OBS_ZINB */) {
+    // Mixture(cat = [1 - pi, pi], [NB, delta_0])
+    const float thp = th[off_infl];
+    const float pi = sigmoidf(thp);
+    float dlp_dpi;
+    if (yv == 0.f) {
+      const float p0 = expf(lp);
+      const float den = (1.0f - pi) * p0 + pi;
+      const float w = (1.0f - pi) * p0 / den;
+      dlp_dpi = (1.0f - p0) / den;
+      lp = logf(den);
+      dl_dlogits *= w; dl_dtc *= w;
+    } else {
+      dlp_dpi = -1.0f / (1.0f - pi);
+      lp += log_sigmoidf(-thp);                 // log(1 - pi)
+    }
+    o.d_infl = -c * dlp_dpi * pi * (1.0f - pi);
+  }
+  o.ll = lp;
+  o.dout = -c * (-dl_dlogits / mean) * sigmoidf(out);
+  o.d_par = -c * (-dl_dlogits / shape - dl_dtc / (shape * shape)) * sigmoidf(ths);
+  return o;
+}
+
 struct ActOut {
   float h, dact, ediff;
 };
@@ -220,6 +302,42 @@ __device__ __forceinline__ float act_fwd(float a, float alpha) {
     el = a > 0.f ? a : expm1f(a);
   }
   return th + alpha * (el - th);
+}
+
+// Two-element versions for the epilogues: identical formulas, written on float2 so that the
+// adds / multiplies / fmas issue as packed v_pk_*_f32 (two elements per VALU slot; the
+// epilogues are VALU-bound).  exp2 / rcp / sign transfer / selects stay per element.
+struct ActOut2 {
+  f32x2 h, dact, ediff;
+};
+__device__ __forceinline__ f32x2 act_parts2(f32x2 a, f32x2& e1_out, f32x2& el_out) {
+  const f32x2 t = __builtin_elementwise_abs(a) * -1.44269504088896340736f;
+  f32x2 e1 = {BNF_EXP2(t.x), BNF_EXP2(t.y)};
+  const f32x2 e2 = e1 * e1;
+  const f32x2 den = e2 + 1.f;
+  f32x2 r = {BNF_RCP(den.x), BNF_RCP(den.y)};
+  asm volatile("" : "+v"(r));   // see act_eval
+  const f32x2 tha = (1.f - e2) * r;
+  const f32x2 th = {copysignf(tha.x, a.x), copysignf(tha.y, a.y)};
+  const f32x2 em1 = e1 - 1.f;
+  el_out = f32x2{a.x > 0.f ? a.x : em1.x, a.y > 0.f ? a.y : em1.y};
+  e1_out = e1;
+  return th;
+}
+__device__ __forceinline__ f32x2 act_fwd2(f32x2 a, float alpha) {
+  f32x2 e1, el;
+  const f32x2 th = act_parts2(a, e1, el);
+  return th + alpha * (el - th);
+}
+__device__ __forceinline__ ActOut2 act_eval2(f32x2 a, float alpha) {
+  ActOut2 o;
+  f32x2 e1, el;
+  const f32x2 th = act_parts2(a, e1, el);
+  const f32x2 dexp = {a.x > 0.f ? 1.f : e1.x, a.y > 0.f ? 1.f : e1.y};
+  o.ediff = el - th;
+  o.h = th + alpha * o.ediff;
+  o.dact = alpha * dexp + (1.f - alpha) * (1.f - th * th);
+  return o;
 }
 
 // ---------------------------------------------------------------------------

@@ -27,7 +27,7 @@
 
 namespace bnf {
 
-enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_DGRAD0 = 2, EPI_WGRAD = 3, EPI_PLAIN = 4 };
+enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_DGRAD0 = 2, EPI_WGRAD = 3, EPI_PLAIN = 4, EPI_LAST = 5 };
 
 constexpr int kBM = 128, kBN = 128, kThreads = 256;
 // gemm_tn: 2 x 32 KiB stages; gemm_nt<float>: the f32 epilogue tile (128 x 132 x 4 B) needs 66 KiB
@@ -64,6 +64,17 @@ struct EpiArgs {
   float* out_f32;      // DGRAD0 / PLAIN: (members, M, ld_f32)
   int64_t f32_batch;
   int32_t ld_f32;
+  // EPI_LAST (last hidden layer + output layer + likelihood + its backward, one kernel)
+  const float* ybat;   // (members, row_batch) targets of the batch rows
+  float* out;          // (members, out_batch) network output
+  int64_t row_batch, out_batch;
+  float* loss;         // loss[(e / S) * loss_stride] += loss_scale * step loss
+  float* loss_raw;     // optional (members,) raw step loss
+  int64_t loss_stride;
+  int32_t S;
+  float loss_scale, lik_c;   // lik_c = (N / B) * likelihood scale
+  int32_t off_os, off_bias_out, off_lns, off_shape, off_infl, obs;
+  unsigned long long* prof;   // -DBNF_ENABLE_ABLATE builds: per-workgroup phase clocks (8 marks)
   int32_t ablate;      // perf experiments only (env BNF_ABLATE): 1 no transposed stores,
                        // 2 no row-major stores, 4 no activation math, 8 no row dot,
                        // 16 no K loop, 32 no transposed loads
@@ -86,15 +97,16 @@ struct Mma<bf16_t> {
   static constexpr int kRowBytes = 64;
   static constexpr int kTileK = 32;  // elements per row
   static constexpr int kSteps = 2;   // MFMA k-steps (16 elements) per tile
-  static constexpr int kStages = 3;   // ring of three K tiles
+  // ring of three K tiles (two for the 64-row full-width panel, so two workgroups fit a CU)
+  __host__ __device__ static constexpr int stages(int wgm, int wgn) { return (wgm == 1 && wgn == 8) ? 2 : 3; }
   // LDS of a (64 WG x 64 WG) tile: the larger of the ring and the epilogue tile (pitch + 16 B)
-  __host__ __device__ static constexpr int lds_bytes(int wg) {
-    const int ring = kStages * 2 * 64 * wg * kRowBytes, tile = 64 * wg * (64 * wg + 8) * 2;
+  __host__ __device__ static constexpr int lds_bytes(int wgm, int wgn, int extra) {
+    const int ring = stages(wgm, wgn) * 64 * (wgm + wgn) * kRowBytes, tile = 64 * wgm * (64 * wgn + 8) * 2 + extra;
     return ring > tile ? ring : tile;
   }
-  // registers: 3 waves / SIMD for the 2 x 2 grid (LDS allows 3 workgroups per CU), 4 for the
-  // 4 x 4 grid (one 16-wave workgroup per CU)
-  __host__ __device__ static constexpr int min_waves(int wg) { return wg == 2 ? 3 : 4; }
+  // registers: 3 waves / SIMD for the 4-wave grid (LDS allows 3 workgroups per CU), 4 for
+  // the larger grids (16 waves: one workgroup per CU)
+  __host__ __device__ static constexpr int min_waves(int waves) { return waves <= 4 ? 3 : 4; }
   __device__ static __forceinline__ int swz(int row) { return (row >> 2) & 3; }
   struct Frag {
     bf16x8 v;
@@ -115,12 +127,12 @@ struct Mma<float> {
   static constexpr int kRowBytes = 128;
   static constexpr int kTileK = 32;
   static constexpr int kSteps = 2;  // k-groups of 16 floats (64 bytes)
-  static constexpr int kStages = 2;
-  __host__ __device__ static constexpr int lds_bytes(int wg) {
-    const int ring = kStages * 2 * 64 * wg * kRowBytes, tile = 64 * wg * (64 * wg + 4) * 4;
+  __host__ __device__ static constexpr int stages(int wgm, int wgn) { return 2; }
+  __host__ __device__ static constexpr int lds_bytes(int wgm, int wgn, int extra) {
+    const int ring = stages(wgm, wgn) * 64 * (wgm + wgn) * kRowBytes, tile = 64 * wgm * (64 * wgn + 4) * 4 + extra;
     return ring > tile ? ring : tile;
   }
-  __host__ __device__ static constexpr int min_waves(int wg) { return 2; }
+  __host__ __device__ static constexpr int min_waves(int waves) { return 2; }
   __device__ static __forceinline__ int swz(int row) { return (row >> 1) & 7; }
   struct Frag {
     f32x4 lo, hi;
@@ -151,26 +163,38 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total) {
   return first + slot;
 }
 
-// WG x WG waves per workgroup, each wave a 64 x 64 sub-tile: WG = 2 -> 128 x 128 tiles (any
-// width), WG = 4 -> 256 x 256 tiles with 16 waves (bf16, widths that are multiples of 256).
-// The K loop of the small tile is bound by the L2 -> LDS operand stream (64 flop / byte; the
-// loop does not speed up with occupancy or prefetch depth, profiles/r01g); the large tile
-// halves that stream and quarters the number of workgroups and reduction atomics.
-template <typename T, int EPI, int TAG, int WG>
-__global__ __launch_bounds__(64 * WG * WG, Mma<T>::min_waves(WG)) void gemm_nt(const GemmArgs g, const EpiArgs ep) {
+// Bytes of LDS an epilogue needs beyond the (rows x cols) output tile.
+__host__ __device__ constexpr int epi_extra_lds(int epi, int wgm, int wgn) {
+  // EPI_LAST: row-dot partials (rows x wgn), dv (rows), column sums 2 x (wgm x cols), scalars
+  return epi == EPI_LAST ? (64 * wgm * wgn + 64 * wgm + 2 * wgm * 64 * wgn + 16 + 2 * wgm * wgn) * 4 : 0;
+}
+
+// WGM x WGN waves per workgroup, each wave a 64 x 64 sub-tile:
+//   2 x 2  128 x 128 tiles, any width (the default);
+//   4 x 4  256 x 256 tiles, 16 waves: bf16 forward layers whose width is a multiple of 256.
+//          The K loop of the small tile is bound by the L2 -> LDS operand stream (64 flop /
+//          byte; it does not speed up with occupancy or prefetch depth); the large tile
+//          halves that stream and quarters the number of workgroups and reduction atomics;
+//   2 x N  128-row panels spanning the WHOLE layer width (EPI_LAST): the workgroup owns
+//          complete rows, so the output-layer dot, the likelihood and the backward pass of
+//          the last activation all happen on the accumulators (no A_L^T round trip).
+template <typename T, int EPI, int TAG, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void gemm_nt(const GemmArgs g, const EpiArgs ep) {
   using M_ = Mma<T>;
-  constexpr int kBM = 64 * WG, kBN = 64 * WG, kThreads = 64 * WG * WG, kWaves = WG * WG;
+  constexpr int kBM = 64 * WGM, kBN = 64 * WGN, kThreads = 64 * WGM * WGN, kWaves = WGM * WGN;
   constexpr int kRowBytes = M_::kRowBytes;
   constexpr int kStageBytes = (kBM + kBN) * kRowBytes;
   constexpr int kChunks = kRowBytes / 16;           // 16-byte chunks per row
   constexpr int kRowsPerInstr = 64 / kChunks;       // rows one LDS-DMA wave instruction fills
-  constexpr int kPerWave = kBM / kRowsPerInstr / kWaves;   // instructions per wave, operand and stage
-  static_assert(kPerWave >= 1 && kPerWave * kRowsPerInstr * kWaves == kBM, "staging map");
+  constexpr int kInstr = (kBM + kBN) / kRowsPerInstr;   // LDS-DMA instructions per stage
+  constexpr int kPerWave = (kInstr + kWaves - 1) / kWaves, kRem = kInstr % kWaves;
+  static_assert(kBM % 16 == 0, "the swizzle period must divide the A tile");
   constexpr bool FAST = Elem<T>::kFast;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave / WG, wc = wave % WG;
+  const int wr = wave / WGN, wc = wave % WGN;
+  BNF_MARK(ep, 0);
 
   // ---- which (member, k-split, tile) ----------------------------------------
   const uint32_t per_member = (uint32_t)(g.tiles_m * g.tiles_n * g.splitk);
@@ -192,20 +216,26 @@ __global__ __launch_bounds__(64 * WG * WG, Mma<T>::min_waves(WG)) void gemm_nt(c
   const char* Bb = reinterpret_cast<const char*>(g.B) + (int64_t)e * g.b_batch * Elem<T>::kBytes;
 
   // ---- staging map: global -> LDS by LDS-DMA (global_load_lds, 16 B per lane) ---
-  // One wave instruction fills kRowsPerInstr consecutive rows.  The XOR swizzle lives on
-  // the SOURCE side, so there are no staging VGPRs and no ds_write traffic; each wave
-  // issues kPerWave A + kPerWave B instructions per K tile.
-  const char* a_src[kPerWave];
-  const char* b_src[kPerWave];
+  // A stage is kBM rows of A followed by kBN rows of B.  One wave instruction fills
+  // kRowsPerInstr consecutive rows; instruction q of a stage belongs to wave q % kWaves.  The
+  // XOR swizzle lives on the SOURCE side, so there are no staging VGPRs and no ds_write
+  // traffic.  When kInstr is not a multiple of kWaves the first kRem waves issue one more.
+  const char* src[kPerWave];
   int lds_base[kPerWave];
+  const bool last_slot = (kRem == 0) || (wave < kRem);   // does slot kPerWave-1 exist for this wave
 #pragma unroll
   for (int i = 0; i < kPerWave; ++i) {
-    const int r0 = (wave * kPerWave + i) * kRowsPerInstr;
+    const int q = min(wave + i * kWaves, kInstr - 1);
+    const int r0 = q * kRowsPerInstr;
     const int row = r0 + lane / kChunks, cp = lane % kChunks;
     const int c = cp ^ M_::swz(row);
-    const int am = min(m0 + row, g.M - 1), bn = min(n0 + row, g.N - 1);
-    a_src[i] = Ab + ((int64_t)am * g.a_ld) * Elem<T>::kBytes + c * 16;
-    b_src[i] = Bb + ((int64_t)bn * g.b_ld) * Elem<T>::kBytes + c * 16;
+    if (row < kBM) {
+      const int am = min(m0 + row, g.M - 1);
+      src[i] = Ab + ((int64_t)am * g.a_ld) * Elem<T>::kBytes + c * 16;
+    } else {
+      const int bn = min(n0 + row - kBM, g.N - 1);
+      src[i] = Bb + ((int64_t)bn * g.b_ld) * Elem<T>::kBytes + c * 16;
+    }
     lds_base[i] = r0 * kRowBytes;
   }
 
@@ -241,13 +271,11 @@ __global__ __launch_bounds__(64 * WG * WG, Mma<T>::min_waves(WG)) void gemm_nt(c
   typedef __attribute__((address_space(1))) const void glb_void_t;
   auto stage = [&](int buf, int kt) {
     const int64_t koff = (int64_t)kt * kRowBytes;
-    char* sA = smem + buf * kStageBytes;
-    char* sB = sA + kBM * kRowBytes;
+    char* sS = smem + buf * kStageBytes;
 #pragma unroll
-    for (int i = 0; i < kPerWave; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[i] + koff), (lds_void_t*)(sA + lds_base[i]), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(b_src[i] + koff), (lds_void_t*)(sB + lds_base[i]), 16, 0, 0);
-    }
+    for (int i = 0; i < kPerWave; ++i)
+      if (i < kPerWave - 1 || last_slot)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src[i] + koff), (lds_void_t*)(sS + lds_base[i]), 16, 0, 0);
   };
 
   // fragment rows of this lane
@@ -266,20 +294,24 @@ __global__ __launch_bounds__(64 * WG * WG, Mma<T>::min_waves(WG)) void gemm_nt(c
   // (each wave first waits on its own vmcnt, allowing only the younger prefetches to stay in
   // flight) and (b) every wave is done reading tile kt-1, whose buffer the next prefetch
   // overwrites.  (__syncthreads() would drain vmcnt to 0 and serialise load and compute.)
-  constexpr int kStages = M_::kStages;
+  constexpr int kStages = M_::stages(WGM, WGN);
   // s_waitcnt immediates (gfx9 encoding): vmcnt in [3:0] + [15:14], expcnt 7 / lgkmcnt 15 = no wait
-  constexpr int kAhead = (kStages - 2) * 2 * kPerWave;   // DMA instructions of the younger stages
-  static_assert(kAhead < 64, "vmcnt range");
-  constexpr int kWaitAhead = (kAhead & 15) | ((kAhead >> 4) << 14) | 0x0F70;
+  constexpr int kAheadHi = (kStages - 2) * kPerWave;             // this wave's younger DMA instructions
+  constexpr int kAheadLo = (kStages - 2) * (kPerWave - 1);       // ... for waves without the last slot
+  static_assert(kAheadHi < 64, "vmcnt range");
+  constexpr int kWaitHi = (kAheadHi & 15) | ((kAheadHi >> 4) << 14) | 0x0F70;
+  constexpr int kWaitLo = (kAheadLo & 15) | ((kAheadLo >> 4) << 14) | 0x0F70;
   constexpr int kWaitAll = 0x0F70;
+  BNF_MARK(ep, 1);
   if (kt0 < kt1 && !BNF_ABL(ep, 16)) {
 #pragma unroll
     for (int s = 0; s < kStages - 1; ++s)
       if (kt0 + s < kt1) stage(s, kt0 + s);
     int buf = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-      if (kt + kStages - 2 < kt1) __builtin_amdgcn_s_waitcnt(kWaitAhead);
-      else __builtin_amdgcn_s_waitcnt(kWaitAll);
+      if (kt + kStages - 2 >= kt1) __builtin_amdgcn_s_waitcnt(kWaitAll);
+      else if (last_slot) __builtin_amdgcn_s_waitcnt(kWaitHi);
+      else __builtin_amdgcn_s_waitcnt(kWaitLo);
       __builtin_amdgcn_s_barrier();
       {
         const int pre = kt + kStages - 1;
@@ -306,6 +338,7 @@ __global__ __launch_bounds__(64 * WG * WG, Mma<T>::min_waves(WG)) void gemm_nt(c
     }
     __syncthreads();   // the epilogue reuses the stage buffers
   }
+  BNF_MARK(ep, 2);
 
   // ---- epilogues --------------------------------------------------------------
   // accumulator element (i, j, r): row m = m0 + wr*64 + i*32 + 8*(r>>2) + 4*kg + (r&3)
@@ -486,6 +519,8 @@ __global__ __launch_bounds__(64 * WG * WG, Mma<T>::min_waves(WG)) void gemm_nt(c
 #pragma unroll
             for (int q = 0; q < 4; ++q) Elem<T>::store(tile + (lr + q) * kPitch + lc, zv[q]);
           }
+          // pin the running sums (see EPI_LAST): keeps the add chains from sinking to their use
+          asm volatile("" : "+v"(s_alpha), "+v"(s_gamma), "+v"(colsum[0]), "+v"(colsum[1]));
           __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -501,8 +536,8 @@ __global__ __launch_bounds__(64 * WG * WG, Mma<T>::min_waves(WG)) void gemm_nt(c
     }
     const float sa = wave_sum(s_alpha), sg = wave_sum(s_gamma);
     if (lane == 0) {
-      red[WG * kBN + wave * 2] = sa;
-      red[WG * kBN + wave * 2 + 1] = sg;
+      red[WGM * kBN + wave * 2] = sa;
+      red[WGM * kBN + wave * 2 + 1] = sg;
     }
     __syncthreads();
     float* gr = ep.grad + (int64_t)e * ep.grad_stride;
@@ -510,20 +545,220 @@ __global__ __launch_bounds__(64 * WG * WG, Mma<T>::min_waves(WG)) void gemm_nt(c
       const int n = n0 + tid;
       float c = 0.f;
 #pragma unroll
-      for (int r = 0; r < WG; ++r) c += red[r * kBN + tid];
+      for (int r = 0; r < WGM; ++r) c += red[r * kBN + tid];
       if (n < g.N) atomicAdd(&gr[ep.off_bias + n], c);
     }
     if (tid == 0) {
       float ta = 0.f, tg = 0.f;
 #pragma unroll
       for (int w2 = 0; w2 < kWaves; ++w2) {
-        ta += red[WG * kBN + w2 * 2];
-        tg += red[WG * kBN + w2 * 2 + 1];
+        ta += red[WGM * kBN + w2 * 2];
+        tg += red[WGM * kBN + w2 * 2 + 1];
+      }
+      atomicAdd(&gr[ep.off_act_weight], alpha * (1.f - alpha) * ta);
+      atomicAdd(&gr[ep.off_layer_scale], sigmoidf(th[ep.off_layer_scale]) * tg / gamma);
+    }
+  } else if constexpr (EPI == EPI_LAST) {
+    // The workgroup owns kBM complete rows (kBN == N == layer width).
+    //   1. A = gamma (acc s + b) kept in the accumulators; H = act(A); row dots H . k_o
+    //   2. one thread per row: output, likelihood, d out  (row_loss_eval, models.py:157-191)
+    //   3. dZ = gamma (dv k_o / sqrt W) act'(A) -> LDS tile -> coalesced rows; column sums
+    // Rows past M carry copies of the last row (clamped operand loads) and dv = 0.
+    const float* th = ep.theta + (int64_t)e * ep.theta_stride;
+    const float gamma = softplusf(th[ep.off_layer_scale]);
+    const float alpha = sigmoidf(th[ep.off_act_weight]);
+    const float inv_sw = 1.0f / sqrtf((float)g.N);
+    T* tile = reinterpret_cast<T*>(smem);
+    float* xs = reinterpret_cast<float*>(smem + kBM * kPitch * (int)sizeof(T));
+    float* s_part = xs;                       // [kBM][WGN]
+    float* s_dv = s_part + kBM * WGN;         // [kBM]
+    float* s_col = s_dv + kBM;                // [2][WGM][kBN]
+    float* s_sc = s_col + 2 * WGM * kBN;      // scalars
+    {
+      float bias[2], kov[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bias[j] = th[ep.off_bias + nw + j * 32];
+        kov[j] = th[ep.off_ko + nw + j * 32];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          float pd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if constexpr (FAST) {
+#pragma unroll
+              for (int q = 0; q < 4; q += 2) {
+                const f32x2 raw = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
+                const f32x2 av = gamma * (raw * ep.scale + bias[j]);
+                acc[i][j][rg * 4 + q] = av.x;
+                acc[i][j][rg * 4 + q + 1] = av.y;
+                const f32x2 hk = act_fwd2(av, alpha) * kov[j];
+                pd[q] += hk.x;
+                pd[q + 1] += hk.y;
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float av = gamma * (acc[i][j][rg * 4 + q] * ep.scale + bias[j]);
+                acc[i][j][rg * 4 + q] = av;
+                pd[q] += act_fwd<FAST>(av, alpha) * kov[j];
+              }
+            }
+          }
+          const int lr = wr * 64 + i * 32 + 8 * rg + 4 * kg;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float sacc = half_wave_sum_dpp(pd[q]);
+            if (frow == 16) s_part[(lr + q) * WGN + wc] = sacc;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    BNF_MARK(ep, 3);
+    {
+      // waves 0 .. kBM/64-1: one row per lane
+      float ll = 0.f, s_doutv = 0.f, s_dvsum = 0.f, s_par = 0.f, s_infl = 0.f;
+      if (tid < kBM) {
+        const int m = m0 + tid;
+        float vsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < WGN; ++c) vsum += s_part[tid * WGN + c];
+        float dvv = 0.f;
+        if (m < g.M) {
+          const float gam_o = softplusf(th[ep.off_os]);
+          const float v = vsum * inv_sw + th[ep.off_bias_out];
+          const float outv = gam_o * v;
+          ep.out[(int64_t)e * ep.out_batch + m] = outv;
+          // TAG 3: NORMAL only (the count-model code, lgamma / digamma, is compiled out)
+          const RowLoss rl = row_loss_eval(TAG == 3 ? 0 : ep.obs, th, ep.off_lns, ep.off_shape, ep.off_infl,
+                                           ep.ybat[(int64_t)e * ep.row_batch + m], outv, ep.lik_c);
+          ll = rl.ll; s_par = rl.d_par; s_infl = rl.d_infl;
+          s_doutv = rl.dout * v;
+          dvv = gam_o * rl.dout;
+          s_dvsum = dvv;
+        }
+        s_dv[tid] = dvv;
+        const float t0 = wave_sum(ll), t1 = wave_sum(s_doutv), t2 = wave_sum(s_dvsum), t3 = wave_sum(s_par),
+                    t4 = wave_sum(s_infl);
+        if (lane == 0) {
+          float* q = s_sc + wave * 5;
+          q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; q[4] = t4;
+        }
+      }
+    }
+    __syncthreads();
+    BNF_MARK(ep, 4);
+    float* gr = ep.grad + (int64_t)e * ep.grad_stride;
+    if (tid == 0) {
+      float u[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w2 = 0; w2 < kBM / 64; ++w2)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) u[i] += s_sc[w2 * 5 + i];
+      const float step_loss = -ep.lik_c * u[0];
+      atomicAdd(&ep.loss[(int64_t)(e / ep.S) * ep.loss_stride], ep.loss_scale * step_loss);
+      if (ep.loss_raw) atomicAdd(&ep.loss_raw[e], step_loss);
+      atomicAdd(&gr[ep.off_os], sigmoidf(th[ep.off_os]) * u[1]);
+      atomicAdd(&gr[ep.off_bias_out], u[2]);
+      atomicAdd(&gr[ep.obs == BNF_OBS_NORMAL ? ep.off_lns : ep.off_shape], u[3]);
+      if (ep.obs == BNF_OBS_ZINB) atomicAdd(&gr[ep.off_infl], u[4]);
+    }
+    // running sums, kept per column half j and per element parity (folded after the loop):
+    //   sa = sum dv ediff, sg = sum p A, cp = sum p, ck = sum H dv   with p = dv act'(A)
+    // so that  d alpha ~ kvn sa,  d gamma ~ kvn sg,  d bias = gamma kvn cp,  d k_o = ck / sqrt W
+    f32x2 sa[2], sg[2], cp[2], ck[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) sa[j] = sg[j] = cp[j] = ck[j] = f32x2{0.f, 0.f};
+    const float kvn[2] = {th[ep.off_ko + nw] * inv_sw, th[ep.off_ko + nw + 32] * inv_sw};
+    const float gk[2] = {gamma * kvn[0], gamma * kvn[1]};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int lr = wr * 64 + 4 * kg + i * 32 + 8 * rg;
+        const f32x4 dv4 = *reinterpret_cast<const f32x4*>(s_dv + lr);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int lc = wc * 64 + j * 32 + frow;
+#pragma unroll
+          for (int q = 0; q < 4; q += 2) {
+            f32x2 av = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
+            // (volatile asm statements keep their order: this ties the group's arithmetic to its
+            // place between the fences; pure arithmetic would otherwise be emitted before them)
+            asm volatile("" : "+v"(av));
+            const f32x2 dv2 = {dv4[q], dv4[q + 1]};
+            ActOut2 o;
+            if constexpr (FAST) {
+              o = act_eval2(av, alpha);
+            } else {
+              const ActOut o0 = act_eval<FAST>(av.x, alpha), o1 = act_eval<FAST>(av.y, alpha);
+              o.h = f32x2{o0.h, o1.h}; o.dact = f32x2{o0.dact, o1.dact}; o.ediff = f32x2{o0.ediff, o1.ediff};
+            }
+            const f32x2 p = dv2 * o.dact;
+            sa[j] += dv2 * o.ediff;
+            sg[j] += p * av;
+            cp[j] += p;
+            ck[j] += o.h * dv2;
+            const f32x2 z = gk[j] * p;
+            Elem<T>::store(tile + (lr + q) * kPitch + lc, z.x);
+            Elem<T>::store(tile + (lr + q + 1) * kPitch + lc, z.y);
+          }
+        }
+        // pin the running sums here: otherwise the add chains (and everything feeding them)
+        // are sunk below the barrier to their first use and every term is spilled
+        asm volatile("" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sg[0]), "+v"(sg[1]), "+v"(cp[0]), "+v"(cp[1]),
+                     "+v"(ck[0]), "+v"(ck[1]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    const float s_alpha = kvn[0] * (sa[0].x + sa[0].y) + kvn[1] * (sa[1].x + sa[1].y);
+    const float s_gamma = kvn[0] * (sg[0].x + sg[0].y) + kvn[1] * (sg[1].x + sg[1].y);
+    const float cs_b[2] = {gk[0] * (cp[0].x + cp[0].y), gk[1] * (cp[1].x + cp[1].y)};
+    const float cs_k[2] = {ck[0].x + ck[0].y, ck[1].x + ck[1].y};
+    __syncthreads();
+    BNF_MARK(ep, 5);
+    tile_to_global(reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch, ep.ld);
+    BNF_MARK(ep, 6);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float b = cs_b[j] + __shfl_xor(cs_b[j], 32, 64);
+      const float k = cs_k[j] + __shfl_xor(cs_k[j], 32, 64);
+      if (lane < 32) {
+        s_col[wr * kBN + wc * 64 + j * 32 + lane] = b;
+        s_col[(WGM + wr) * kBN + wc * 64 + j * 32 + lane] = k;
+      }
+    }
+    const float wsa = wave_sum(s_alpha), wsg = wave_sum(s_gamma);
+    if (lane == 0) {
+      s_sc[16 + wave * 2] = wsa;
+      s_sc[17 + wave * 2] = wsg;
+    }
+    __syncthreads();
+    for (int c = tid; c < kBN; c += kThreads) {
+      float b = 0.f, k = 0.f;
+#pragma unroll
+      for (int r = 0; r < WGM; ++r) {
+        b += s_col[r * kBN + c];
+        k += s_col[(WGM + r) * kBN + c];
+      }
+      atomicAdd(&gr[ep.off_bias + n0 + c], b);
+      atomicAdd(&gr[ep.off_ko + n0 + c], k * inv_sw);
+    }
+    if (tid == 0) {
+      float ta = 0.f, tg = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < kWaves; ++w2) {
+        ta += s_sc[16 + w2 * 2];
+        tg += s_sc[17 + w2 * 2];
       }
       atomicAdd(&gr[ep.off_act_weight], alpha * (1.f - alpha) * ta);
       atomicAdd(&gr[ep.off_layer_scale], sigmoidf(th[ep.off_layer_scale]) * tg / gamma);
     }
   }
+  BNF_MARK(ep, 7);
 }
 
 // ===========================================================================

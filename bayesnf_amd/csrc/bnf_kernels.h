@@ -302,20 +302,6 @@ struct RowLossArgs {
   float* loss_raw;
 };
 
-// digamma for x > 0: shift to x >= 6 by the recurrence, then the asymptotic series
-// (|err| ~ 1e-7 relative in fp32 for the shifted argument).
-__device__ __forceinline__ float digammaf(float x) {
-  float acc = 0.f;
-#pragma unroll 1
-  while (x < 6.f) { acc -= 1.0f / x; x += 1.0f; }
-  const float r = 1.0f / x, r2 = r * r;
-  const float tail = r2 * (1.f / 12.f - r2 * (1.f / 120.f - r2 * (1.f / 252.f - r2 * (1.f / 240.f))));
-  return acc + logf(x) - 0.5f * r - tail;
-}
-
-// log(1 + e^x) / log sigmoid without overflow
-__device__ __forceinline__ float log_sigmoidf(float x) { return -softplusf(-x); }
-
 template <bool TRAIN>
 __global__ __launch_bounds__(256) void k_row_loss(NetDev nd, RowLossArgs a) {
   __shared__ float s_red[4][5];
@@ -333,54 +319,10 @@ __global__ __launch_bounds__(256) void k_row_loss(NetDev nd, RowLossArgs a) {
     const float out = gam_o * v;
     a.out[(int64_t)e * a.out_batch + r] = out;
     if constexpr (TRAIN) {
-      const float yv = a.ybat[vi];
-      float dout;   // d loss / d out
-      if (nd.obs == BNF_OBS_NORMAL) {
-        // NORMAL (models.py:157-164): sigma = 0.01 + exp(lns)
-        const float lns = th[nd.off_lns];
-        const float sigma = 0.01f + expf(lns);
-        const float res = yv - out;
-        const float z = res / sigma;
-        ll = -0.5f * z * z - logf(sigma) - 0.918938533204672742f;
-        dout = -a.c * res / (sigma * sigma);
-        s_par = -a.c * (res * res / (sigma * sigma * sigma) - 1.0f / sigma) * expf(lns);
-      } else {
-        // NB / ZINB (models.py:166-191): mean = softplus(out), shape = softplus(theta_shape),
-        // total_count = 1/shape, logits = -log shape - log mean;  TFP 0.24 log_prob:
-        //   tc logsig(-logits) + y logsig(logits) + lgamma(tc+y) - lgamma(1+y) - lgamma(tc)
-        const float ths = th[nd.off_shape];
-        const float shape = softplusf(ths);
-        const float tc = 1.0f / shape;
-        const float mean = softplusf(out);
-        const float logits = -logf(shape) - logf(mean);
-        const float sg = sigmoidf(logits);
-        const float lsn = log_sigmoidf(-logits);
-        float lp = tc * lsn + yv * log_sigmoidf(logits) + lgammaf(tc + yv) - lgammaf(1.0f + yv) -
-                   lgammaf(tc);
-        float dl_dlogits = yv * (1.0f - sg) - tc * sg;
-        float dl_dtc = lsn + digammaf(tc + yv) - digammaf(tc);
-        if (nd.obs == BNF_OBS_ZINB) {
-          // Mixture(cat = [1 - pi, pi], [NB, delta_0])
-          const float thp = th[nd.off_infl];
-          const float pi = sigmoidf(thp);
-          float dlp_dpi;
-          if (yv == 0.f) {
-            const float p0 = expf(lp);
-            const float den = (1.0f - pi) * p0 + pi;
-            const float w = (1.0f - pi) * p0 / den;
-            dlp_dpi = (1.0f - p0) / den;
-            lp = logf(den);
-            dl_dlogits *= w; dl_dtc *= w;
-          } else {
-            dlp_dpi = -1.0f / (1.0f - pi);
-            lp += log_sigmoidf(-thp);                 // log(1 - pi)
-          }
-          s_infl = -a.c * dlp_dpi * pi * (1.0f - pi);
-        }
-        ll = lp;
-        dout = -a.c * (-dl_dlogits / mean) * sigmoidf(out);
-        s_par = -a.c * (-dl_dlogits / shape - dl_dtc / (shape * shape)) * sigmoidf(ths);
-      }
+      const RowLoss rl = row_loss_eval(nd.obs, th, nd.off_lns, nd.off_shape, nd.off_infl, a.ybat[vi],
+                                       out, a.c);
+      ll = rl.ll; s_par = rl.d_par; s_infl = rl.d_infl;
+      const float dout = rl.dout;
       s_doutv = dout * v;
       const float dvv = gam_o * dout;
       a.dv[vi] = dvv;

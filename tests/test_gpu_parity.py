@@ -64,9 +64,13 @@ def test_weight_gradient_core(dtype, shape):
 # --------------------------------------------------------------------------- forward / grads
 @pytest.mark.parametrize('depth,width,n_rows,pipeline', [
     (2, 64, 300, 'layers'), (1, 128, 130, 'layers'), (3, 192, 257, 'layers'), (2, 256, 200, 'layers'),
+    (2, 64, 300, 'auto'), (1, 128, 130, 'auto'), (3, 256, 257, 'auto'), (2, 192, 140, 'auto'),
     (1, 128, 130, 'fused'), (2, 128, 300, 'fused'), (3, 256, 257, 'fused'), (2, 512, 100, 'fused')])
 def test_forward_and_grad_fp32(depth, width, n_rows, pipeline):
-  """Both train-step pipelines (layer-by-layer kernels / fused row-panel kernel)."""
+  """The train-step pipelines: 'layers' = one kernel per layer, every activation materialised;
+  'auto' (default) = the same with the last hidden layer, the output layer, the likelihood and
+  its backward fused into one kernel where the width allows (64/128/256, 512 in bf16; 192
+  falls back); 'fused' = the experimental row-panel kernel."""
   net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth)
   E = 3
   theta = util.random_theta(model, E)
@@ -79,7 +83,8 @@ def test_forward_and_grad_fp32(depth, width, n_rows, pipeline):
     H0 = eng.debug_activation(0)
     assert np.max(np.abs(H0 - ch['Hs'][0])) < 5e-5
     for l in range(depth):
-      if pipeline == 'layers':   # the fused kernel keeps pre-activations on chip
+      # the fused kernels keep (some) pre-activations on chip
+      if pipeline == 'layers' or (pipeline == 'auto' and (l < depth - 1 or width == 192)):
         assert util.rel_err(eng.debug_activation(100 + l), ch['As'][l]) < 2e-4, l
       if l < depth - 1:   # the last hidden output is consumed in registers, never stored
         assert util.rel_err(eng.debug_activation(1 + l), ch['Hs'][l + 1]) < 2e-4, l
@@ -91,7 +96,8 @@ def test_forward_and_grad_fp32(depth, width, n_rows, pipeline):
     eng.close()
 
 
-@pytest.mark.parametrize('width,pipeline', [(64, 'layers'), (128, 'fused'), (256, 'fused')])
+@pytest.mark.parametrize('width,pipeline', [(64, 'layers'), (64, 'auto'), (256, 'auto'), (128, 'fused'),
+                                            (256, 'fused')])
 def test_train_full_batch_fp32(width, pipeline):
   n_rows, E, steps = 200, 4, 30
   net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=2)
@@ -298,7 +304,7 @@ def test_count_models_forecast_means_and_quantiles(obs):
 
 
 # --------------------------------------------------------------------------- bf16
-@pytest.mark.parametrize('pipeline', ['layers', 'fused'])
+@pytest.mark.parametrize('pipeline', ['layers', 'auto', 'fused'])
 def test_bf16_tracks_fp32(pipeline):
   n_rows, E, steps = 512, 4, 40
   net, model, X, y = util.make_problem(n_rows=n_rows, width=128, depth=2)
