@@ -104,8 +104,12 @@ typedef struct bnf_config {
   int32_t vi_samples;       /* S = sample_size_divergence (VI), else 1 */
   int32_t forward_only;     /* 1: handle is used for bnf_forward / quantiles only
                                (no backward buffers are carved, bnf_train refuses) */
-  int32_t pipeline;         /* train-step kernels: 0 auto, 1 layer-by-layer kernels, 2 fused row-panel
-                               forward+backward (needs width 128/256/512, <= 128 features) */
+  int32_t pipeline;         /* train-step kernels.  0 auto: one kernel per layer, with the last hidden
+                               layer + output layer + likelihood + its backward in ONE kernel when
+                               the width is 64/128/256 (512: bf16 only).  1: one kernel per layer and
+                               every activation materialised (validation; bnf_debug_activation can
+                               read all of them).  2: experimental persistent row-panel kernel
+                               (NORMAL, width 128/256/512, <= 128 features; slower, opt-in) */
   float   learning_rate;
   float   prior_weight;     /* 1 MAP, 0 MLE (inference.py:561-569) */
   float   kl_weight;        /* VI (inference.py:689-702) */
