@@ -265,17 +265,22 @@ __device__ __forceinline__ ActOut act_eval(float a, float alpha) {
   ActOut o;
   float th, el, dexp;
   if constexpr (FAST) {
-    // one v_exp_f32 + one v_rcp_f32:  e1 = exp(-|a|), e2 = e1^2
+    // one v_exp_f32 + one v_rcp_f32:  e1 = exp(-|a|), r = 1 / (1 + e1^2)
+    //   tanh|a| = (1 - e1^2) r = 2 r - 1        1 - tanh^2 = 4 r (1 - r)
+    //   elu(a)  = max(a, e1 - 1)                 (a < 0: e^a - 1 >= a;  a > 0: e^-a - 1 < 0 < a)
+    // (bf16 pipeline only: 2 r - 1 loses relative accuracy for |a| << 1, far below bf16's 2^-8)
     const float e1 = BNF_EXP2(fabsf(a) * -1.44269504088896340736f);
-    const float e2 = e1 * e1;
-    float r = BNF_RCP(1.f + e2);
+    float r = BNF_RCP(__builtin_fmaf(e1, e1, 1.f));
     // Keep the reciprocal opaque: with both raw transcendental builtins visible, hipcc 7.2
     // mis-optimises the column reductions that consume this value inside the fused kernel
     // (wrong d bias / d k_o; every variant that hides either builtin is correct -- measured).
     asm volatile("" : "+v"(r));
-    th = copysignf((1.f - e2) * r, a);
-    el = a > 0.f ? a : e1 - 1.f;
-    dexp = a > 0.f ? 1.f : e1;
+    th = copysignf(__builtin_fmaf(2.f, r, -1.f), a);
+    el = fmaxf(a, e1 - 1.f);
+    o.ediff = el - th;
+    o.h = __builtin_fmaf(alpha, o.ediff, th);
+    o.dact = __builtin_fmaf(4.f * (1.f - alpha), __builtin_fmaf(-r, r, r), a > 0.f ? alpha : alpha * e1);
+    return o;
   } else {
     th = tanhf(a);
     el = a > 0.f ? a : expm1f(a);
@@ -292,11 +297,10 @@ __device__ __forceinline__ float act_fwd(float a, float alpha) {
   float th, el;
   if constexpr (FAST) {
     const float e1 = BNF_EXP2(fabsf(a) * -1.44269504088896340736f);
-    const float e2 = e1 * e1;
-    float r = BNF_RCP(1.f + e2);
+    float r = BNF_RCP(__builtin_fmaf(e1, e1, 1.f));
     asm volatile("" : "+v"(r));
-    th = copysignf((1.f - e2) * r, a);
-    el = a > 0.f ? a : e1 - 1.f;
+    th = copysignf(__builtin_fmaf(2.f, r, -1.f), a);
+    el = fmaxf(a, e1 - 1.f);
   } else {
     th = tanhf(a);
     el = a > 0.f ? a : expm1f(a);
@@ -310,33 +314,33 @@ __device__ __forceinline__ float act_fwd(float a, float alpha) {
 struct ActOut2 {
   f32x2 h, dact, ediff;
 };
-__device__ __forceinline__ f32x2 act_parts2(f32x2 a, f32x2& e1_out, f32x2& el_out) {
+__device__ __forceinline__ f32x2 act_parts2(f32x2 a, f32x2& e1_out, f32x2& r_out, f32x2& el_out) {
   const f32x2 t = __builtin_elementwise_abs(a) * -1.44269504088896340736f;
-  f32x2 e1 = {BNF_EXP2(t.x), BNF_EXP2(t.y)};
-  const f32x2 e2 = e1 * e1;
-  const f32x2 den = e2 + 1.f;
+  const f32x2 e1 = {BNF_EXP2(t.x), BNF_EXP2(t.y)};
+  const f32x2 den = e1 * e1 + 1.f;
   f32x2 r = {BNF_RCP(den.x), BNF_RCP(den.y)};
   asm volatile("" : "+v"(r));   // see act_eval
-  const f32x2 tha = (1.f - e2) * r;
-  const f32x2 th = {copysignf(tha.x, a.x), copysignf(tha.y, a.y)};
+  const f32x2 tha = 2.f * r - 1.f;
   const f32x2 em1 = e1 - 1.f;
-  el_out = f32x2{a.x > 0.f ? a.x : em1.x, a.y > 0.f ? a.y : em1.y};
+  el_out = f32x2{fmaxf(a.x, em1.x), fmaxf(a.y, em1.y)};
   e1_out = e1;
-  return th;
+  r_out = r;
+  return f32x2{copysignf(tha.x, a.x), copysignf(tha.y, a.y)};
 }
 __device__ __forceinline__ f32x2 act_fwd2(f32x2 a, float alpha) {
-  f32x2 e1, el;
-  const f32x2 th = act_parts2(a, e1, el);
+  f32x2 e1, r, el;
+  const f32x2 th = act_parts2(a, e1, r, el);
   return th + alpha * (el - th);
 }
 __device__ __forceinline__ ActOut2 act_eval2(f32x2 a, float alpha) {
   ActOut2 o;
-  f32x2 e1, el;
-  const f32x2 th = act_parts2(a, e1, el);
-  const f32x2 dexp = {a.x > 0.f ? 1.f : e1.x, a.y > 0.f ? 1.f : e1.y};
+  f32x2 e1, r, el;
+  const f32x2 th = act_parts2(a, e1, r, el);
+  const f32x2 ae1 = alpha * e1;
+  const f32x2 adexp = {a.x > 0.f ? alpha : ae1.x, a.y > 0.f ? alpha : ae1.y};
   o.ediff = el - th;
   o.h = th + alpha * o.ediff;
-  o.dact = alpha * dexp + (1.f - alpha) * (1.f - th * th);
+  o.dact = (4.f * (1.f - alpha)) * (r - r * r) + adexp;
   return o;
 }
 

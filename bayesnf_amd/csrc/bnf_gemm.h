@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     for (int j = 0; j < 2; ++j) {
       const int n = nw + j * 32;
       if (n >= g.N) continue;
-      const float bias = th[ep.off_bias + n];
+      const float gs = gamma * ep.scale, gb = gamma * th[ep.off_bias + n];   // A = acc gs + gb
       const float kov = vd ? th[ep.off_ko + n] : 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -448,11 +448,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
         for (int rg = 0; rg < 4; ++rg) {
           const int mb = mw + i * 32 + 8 * rg;
           float av[4], hv[4];
+          if constexpr (FAST) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            av[q] = gamma * (acc[i][j][rg * 4 + q] * ep.scale + bias);
-            hv[q] = BNF_ABL(ep, 4) ? av[q] : act_fwd<FAST>(av[q], alpha);
-            pdot[i][rg * 4 + q] += hv[q] * kov;
+            for (int q = 0; q < 4; q += 2) {
+              const f32x2 a2 = f32x2{acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]} * gs + gb;
+              const f32x2 h2 = BNF_ABL(ep, 4) ? a2 : act_fwd2(a2, alpha);
+              av[q] = a2.x; av[q + 1] = a2.y;
+              hv[q] = h2.x; hv[q + 1] = h2.y;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              av[q] = acc[i][j][rg * 4 + q] * gs + gb;
+              hv[q] = BNF_ABL(ep, 4) ? av[q] : act_fwd<FAST>(av[q], alpha);
+            }
+          }
+          if (vd) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pdot[i][rg * 4 + q] += hv[q] * kov;
           }
           if (oh && !BNF_ABL(ep, 2)) {
             const int lr = wr * 64 + 4 * kg + i * 32 + 8 * rg, lc = wc * 64 + j * 32 + frow;
@@ -490,7 +503,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     const float alpha = sigmoidf(th[ep.off_act_weight]);
     T* oz = reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch;
     T* tile = reinterpret_cast<T*>(smem);
-    float s_alpha = 0.f, s_gamma = 0.f, colsum[2] = {0.f, 0.f};
+    // running sums per element parity (folded after the loop)
+    f32x2 sa2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, cs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = nw + j * 32;
@@ -503,16 +517,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
           float av[4], zv[4];
           unpack(apre[j][i][rg], av);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float dh = (mb + q < g.M) ? acc[i][j][rg * 4 + q] * ep.scale : 0.f;
-            ActOut o;
-            if (BNF_ABL(ep, 4)) { o.h = av[q]; o.dact = 1.f; o.ediff = av[q]; }
-            else o = act_eval<FAST>(av[q], alpha);
-            s_alpha += dh * o.ediff;
-            const float da = dh * o.dact;
-            s_gamma += da * av[q];
-            zv[q] = gamma * da;
-            colsum[j] += zv[q];
+          for (int q = 0; q < 4; q += 2) {
+            // rows past M carry copies of the last row: masked through the scale
+            const f32x2 ms = {mb + q < g.M ? ep.scale : 0.f, mb + q + 1 < g.M ? ep.scale : 0.f};
+            const f32x2 dh = f32x2{acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]} * ms;
+            const f32x2 a2 = {av[q], av[q + 1]};
+            ActOut2 o;
+            if (BNF_ABL(ep, 4)) { o.h = a2; o.dact = f32x2{1.f, 1.f}; o.ediff = a2; }
+            else if constexpr (FAST) o = act_eval2(a2, alpha);
+            else {
+              const ActOut o0 = act_eval<FAST>(a2.x, alpha), o1 = act_eval<FAST>(a2.y, alpha);
+              o.h = f32x2{o0.h, o1.h}; o.dact = f32x2{o0.dact, o1.dact}; o.ediff = f32x2{o0.ediff, o1.ediff};
+            }
+            sa2 += dh * o.ediff;
+            const f32x2 da = dh * o.dact;
+            sg2 += da * a2;
+            const f32x2 z = gamma * da;
+            cs2[j] += z;
+            zv[q] = z.x; zv[q + 1] = z.y;
           }
           const int lr = wr * 64 + 4 * kg + i * 32 + 8 * rg, lc = wc * 64 + j * 32 + frow;
           if (!BNF_ABL(ep, 2)) {
@@ -520,10 +542,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
             for (int q = 0; q < 4; ++q) Elem<T>::store(tile + (lr + q) * kPitch + lc, zv[q]);
           }
           // pin the running sums (see EPI_LAST): keeps the add chains from sinking to their use
-          asm volatile("" : "+v"(s_alpha), "+v"(s_gamma), "+v"(colsum[0]), "+v"(colsum[1]));
+          asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(cs2[0]), "+v"(cs2[1]));
           __builtin_amdgcn_sched_barrier(0);
         }
     }
+    const float s_alpha = sa2.x + sa2.y, s_gamma = sg2.x + sg2.y;
+    const float colsum[2] = {cs2[0].x + cs2[0].y, cs2[1].x + cs2[1].y};
     __syncthreads();
     if (!BNF_ABL(ep, 2)) tile_to_global(oz, ep.ld);
     __syncthreads();
@@ -575,10 +599,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     float* s_col = s_dv + kBM;                // [2][WGM][kBN]
     float* s_sc = s_col + 2 * WGM * kBN;      // scalars
     {
-      float bias[2], kov[2];
+      const float gs = gamma * ep.scale;   // A = acc gs + gb
+      float gb[2], kov[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        bias[j] = th[ep.off_bias + nw + j * 32];
+        gb[j] = gamma * th[ep.off_bias + nw + j * 32];
         kov[j] = th[ep.off_ko + nw + j * 32];
       }
 #pragma unroll
@@ -592,7 +617,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
 #pragma unroll
               for (int q = 0; q < 4; q += 2) {
                 const f32x2 raw = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
-                const f32x2 av = gamma * (raw * ep.scale + bias[j]);
+                const f32x2 av = raw * gs + gb[j];
                 acc[i][j][rg * 4 + q] = av.x;
                 acc[i][j][rg * 4 + q + 1] = av.y;
                 const f32x2 hk = act_fwd2(av, alpha) * kov[j];
@@ -602,7 +627,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
             } else {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const float av = gamma * (acc[i][j][rg * 4 + q] * ep.scale + bias[j]);
+                const float av = acc[i][j][rg * 4 + q] * gs + gb[j];
                 acc[i][j][rg * 4 + q] = av;
                 pd[q] += act_fwd<FAST>(av, alpha) * kov[j];
               }
