@@ -1,0 +1,115 @@
+"""Size-independent properties at BASELINE.json's full configuration sizes (C2, and C3 / C4-shaped
+cases scaled to a few members), where the oracle is too slow: member-shard invariance, loss
+decrease, fp32-vs-bf16 agreement, finite VI / minibatch training at depth 4 and widths 768 / 1024."""
+import numpy as np
+import pytest
+import torch
+
+from bayesnf_amd.spec import NetSpec
+
+pytestmark = pytest.mark.gpu
+
+
+def _grid(T=522, S=20, seed=1234):
+  """The bench's C2 grid (bench.py:synthetic_grid), regenerated here so the test is self-contained."""
+  rng = np.random.default_rng(seed)
+  lat, lon = rng.uniform(-1, 1, S), rng.uniform(-1, 1, S)
+  lat, lon = (lat - lat.mean()) / lat.std(), (lon - lon.mean()) / lon.std()
+  tt, ss = np.meshgrid(np.arange(T, dtype=np.float64), np.arange(S), indexing='ij')
+  tt, ss = tt.ravel(), ss.ravel()
+  keep = ~((ss < 4) & (tt >= T - 52))
+  t, s = tt[keep], ss[keep]
+  X = np.stack([t, lat[s], lon[s]], axis=1)
+  y = (3 * np.sin(2 * np.pi * t / 4.0) + np.sin(2 * np.pi * t / 52.1775) + 2 * lat[s] * lon[s] +
+       0.5 * rng.standard_normal(t.size))
+  return X, y, [T - 1.0, 1.0, 1.0]
+
+
+def _net(scales, width=512, depth=2, obs='NORMAL'):
+  return NetSpec(width=width, depth=depth, input_scales=scales, fourier_degrees=[5, 5, 5],
+                 interactions=[], seasonality_periods=[4.0, 52.1775], num_seasonal_harmonics=[2, 10],
+                 observation_model=obs)
+
+
+def _engine(net, X, y, **kw):
+  from bayesnf_amd.engine import Engine
+  return Engine(net, X=X, y=y, **kw)
+
+
+def _fit(net, X, y, steps, **kw):
+  eng = _engine(net, X, y, **kw)
+  eng.init_params(float(np.log(np.nanstd(y) / 2)))
+  losses = eng.train(0, steps)
+  torch.cuda.synchronize()
+  out = eng.get_params().copy(), losses.cpu().numpy()
+  eng.close()
+  return out
+
+
+def test_c2_shard_invariance_and_loss_decrease_bf16():
+  """C2 (N=10,232, F=57, W=512, depth 2, bf16): 8 members on one handle == 2 x 4 members on two
+  handles with member offsets (what two ranks would run), and the loss falls for every member."""
+  X, y, scales = _grid()
+  assert X.shape[0] == 10232
+  net = _net(scales)
+  assert net.F == 57
+  kw = dict(seed=7, learning_rate=0.005, compute_dtype='bf16')
+  th_all, loss_all = _fit(net, X, y, 12, members=8, **kw)
+  th_a, loss_a = _fit(net, X, y, 12, members=4, member_offset=0, **kw)
+  th_b, loss_b = _fit(net, X, y, 12, members=4, member_offset=4, **kw)
+  # same random streams, same arithmetic; only the order of f32 atomics differs
+  np.testing.assert_allclose(np.concatenate([loss_a, loss_b]), loss_all, rtol=2e-4)
+  err = np.abs(np.concatenate([th_a, th_b]) - th_all).max()
+  assert err < 5e-3, err
+  assert np.all(np.isfinite(loss_all)) and np.all(loss_all[:, -1] < loss_all[:, 0])
+  assert np.all(np.diff(loss_all, axis=1)[:, :6] < 0)
+
+
+def test_c2_bf16_tracks_fp32_at_full_size():
+  X, y, scales = _grid()
+  net = _net(scales)
+  kw = dict(seed=3, learning_rate=0.005, members=4)
+  th32, l32 = _fit(net, X, y, 10, compute_dtype='fp32', **kw)
+  th16, l16 = _fit(net, X, y, 10, compute_dtype='bf16', **kw)
+  np.testing.assert_allclose(l16[:, 0], l32[:, 0], rtol=3e-3)     # same init, one forward
+  np.testing.assert_allclose(l16[:, -1], l32[:, -1], rtol=2e-2)
+  # the update direction agrees: parameters moved the same way
+  d32, d16 = th32 - th32.mean(0), th16 - th16.mean(0)
+  assert np.abs(th16 - th32).max() < 0.05
+
+
+@pytest.mark.parametrize('width,depth', [(512, 4), (768, 2), (1024, 2)])
+def test_deep_and_wide_minibatch_mle(width, depth):
+  """C4-shaped (minibatch MLE, depth 4 / widths the full-width last-layer kernel does not cover)."""
+  X, y, scales = _grid(T=1200, S=20, seed=5)        # 23k rows
+  net = _net(scales, width=width, depth=depth)
+  th, losses = _fit(net, X, y, 3, members=2, batch=4096, prior_weight=0.0, seed=11,
+                    learning_rate=0.005, compute_dtype='bf16')
+  assert losses.shape == (2, 3) and np.all(np.isfinite(losses)) and np.all(np.isfinite(th))
+  assert np.all(losses[:, -1] < losses[:, 0])
+
+
+def test_c3_shaped_vi_depth4():
+  """C3-shaped: mean-field VI, depth 4, W=512, B=3500, S=5."""
+  X, y, scales = _grid(T=1000, S=20, seed=9)
+  net = _net(scales, width=512, depth=4)
+  eng = _engine(net, X, y, mode='vi', members=2, batch=3500, vi_samples=5, kl_weight=0.2, seed=2,
+                learning_rate=0.01, compute_dtype='bf16')
+  eng.init_params(0.0)
+  losses = eng.train(0, 12)
+  torch.cuda.synchronize()
+  l = losses.cpu().numpy()
+  mu_rho = eng.get_params()
+  eng.close()
+  assert l.shape == (2, 12) and np.all(np.isfinite(l)) and np.all(np.isfinite(mu_rho))
+  # the ELBO estimate is stochastic (S = 5 draws per step): compare averages, not single epochs
+  assert l[:, -3:].mean() < l[:, :3].mean()
+
+
+@pytest.mark.parametrize('obs', ['NB', 'ZINB'])
+def test_c2_count_models_full_size(obs):
+  X, y, scales = _grid()
+  counts = np.random.default_rng(1).poisson(np.exp(0.5 * y)).astype(np.float64)
+  net = _net(scales, obs=obs)
+  th, losses = _fit(net, X, counts, 8, members=2, seed=1, learning_rate=0.005, compute_dtype='bf16')
+  assert np.all(np.isfinite(losses)) and np.all(losses[:, -1] < losses[:, 0])
