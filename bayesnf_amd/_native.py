@@ -70,6 +70,10 @@ class BnfConfig(C.Structure):
 
 
 def library_path() -> str:
+  """In-tree shared object; BNF_LIB=<path> selects another build (A/B perf experiments)."""
+  override = os.environ.get('BNF_LIB')
+  if override:
+    return override
   return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 

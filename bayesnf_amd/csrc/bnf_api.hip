@@ -116,6 +116,7 @@ struct bnf_handle {
   int prof_threads = 0;
   bool fuse_last = false;     // last layer + likelihood + its backward in one kernel (EPI_LAST)
   bool big_tiles = true;      // env BNF_BIG_TILES=0: 128 x 128 tiles everywhere (perf experiments)
+  float* scal = nullptr;      // (Ev, kScalStride) transformed scalar leaves (k_member_scalars)
   float* qscratch = nullptr;  // quantile partials: 2*1024*2 + 2 floats
   float* dbg_a = nullptr; float* dbg_b = nullptr;  // small debug staging (gmu/grho)
   uint8_t* is_matrix = nullptr;
@@ -174,6 +175,7 @@ static size_t carve(bnf_handle* h, char* base) {
   h->ybat = fo ? nullptr : (float*)take((size_t)Ev * Bp * 4);
   h->loss_raw = (float*)take((size_t)Ev * 4);
   h->qscratch = (float*)take((size_t)(4 * 1024 + 16) * 4);
+  h->scal = (float*)take((size_t)Ev * kScalStride * 4);
   h->dbg_a = (float*)take(256);
   h->is_matrix = (uint8_t*)take((size_t)P);
   return off;
@@ -349,6 +351,8 @@ static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1
 template <typename T>
 static void run_pack(bnf_handle* h, const float* theta, int nmem) {
   LaunchScope ls(h, KID_PACK);
+  hipLaunchKernelGGL(k_member_scalars, dim3(cdiv(nmem, 64)), dim3(64), 0, h->stream, h->nd, theta,
+                     (int64_t)h->P, (int32_t)nmem, h->scal);
   for (int l = 0; l < h->L; ++l) {
     const int n_in = (l == 0) ? h->F : h->W, n_pad = (l == 0) ? h->Fp : h->W;
     dim3 grid((unsigned)((n_pad / 32) * (h->W / 32)), (unsigned)nmem);
@@ -402,6 +406,7 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
     ep.off_bias = h->nd.off_bias[l];
     ep.off_layer_scale = h->nd.off_ls[l];
     ep.off_act_weight = h->nd.off_law;
+    ep.scal = h->scal; ep.scal_stride = kScalStride; ep.layer = l;
     ep.out_a = h->A[l];
     ep.out_h = last ? nullptr : h->H[l];
     ep.vdot = last ? h->vacc : nullptr;
@@ -495,6 +500,7 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
     ep.off_bias = h->nd.off_bias[l];
     ep.off_layer_scale = h->nd.off_ls[l];
     ep.off_act_weight = h->nd.off_law;
+    ep.scal = h->scal; ep.scal_stride = kScalStride; ep.layer = l;
     ep.off_ko = h->nd.off_kernel[L];
     ep.out_h = h->dZ[l];
     ep.act_batch = Bp * h->W; ep.ld = h->W;
@@ -553,6 +559,7 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
       ep.off_bias = h->nd.off_bias[l - 1];
       ep.off_layer_scale = h->nd.off_ls[l - 1];
       ep.off_act_weight = h->nd.off_law;
+      ep.scal = h->scal; ep.scal_stride = kScalStride; ep.layer = l - 1;
       ep.in_a = h->A[l - 1];
       ep.out_h = h->dZ[l - 1];
         ep.act_batch = Bp * h->W; ep.actt_batch = (int64_t)h->W * (Bp + kAtPad);

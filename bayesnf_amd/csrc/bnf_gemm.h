@@ -47,6 +47,8 @@ struct EpiArgs {
   int64_t theta_stride;
   float scale;  // 1/sqrt(fan_in) folded into the accumulator
   int32_t off_bias, off_layer_scale, off_act_weight;
+  const float* scal;   // (members, scal_stride): softplus(layer scales), [MAX_LAYERS] sigmoid(activation
+  int32_t scal_stride, layer;   // weight), [MAX_LAYERS + 1] softplus(output scale)  -- k_member_scalars
   // activations: row-major (rows, ld) and transposed (ld, ldt) copies
   void* out_a;         // FWD: pre-activation A_l^T (transposed only)
   void* out_h;         // FWD: H_{l+1} row-major (null for the last layer) ; DGRAD: dZ_l row-major
@@ -192,7 +194,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
   constexpr bool FAST = Elem<T>::kFast;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index is uniform: keeping it in an SGPR makes the stage bookkeeping scalar code
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WGN, wc = wave % WGN;
   BNF_MARK(ep, 0);
 
@@ -220,21 +224,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
   // kRowsPerInstr consecutive rows; instruction q of a stage belongs to wave q % kWaves.  The
   // XOR swizzle lives on the SOURCE side, so there are no staging VGPRs and no ds_write
   // traffic.  When kInstr is not a multiple of kWaves the first kRem waves issue one more.
-  const char* src[kPerWave];
-  int lds_base[kPerWave];
+  // Address of a piece = (operand base of this tile and K tile: 64-bit, SCALAR) + (row and
+  // swizzled chunk of this lane inside the tile: 32-bit, constant over the K loop).
+  const char* sbase[kPerWave];   // uniform
+  uint32_t voff[kPerWave];       // per lane
+  int lds_base[kPerWave];        // uniform
   const bool last_slot = (kRem == 0) || (wave < kRem);   // does slot kPerWave-1 exist for this wave
 #pragma unroll
   for (int i = 0; i < kPerWave; ++i) {
     const int q = min(wave + i * kWaves, kInstr - 1);
-    const int r0 = q * kRowsPerInstr;
+    const int r0 = q * kRowsPerInstr;                 // uniform; a piece never straddles A | B
     const int row = r0 + lane / kChunks, cp = lane % kChunks;
     const int c = cp ^ M_::swz(row);
-    if (row < kBM) {
-      const int am = min(m0 + row, g.M - 1);
-      src[i] = Ab + ((int64_t)am * g.a_ld) * Elem<T>::kBytes + c * 16;
+    if (r0 < kBM) {
+      const int lim = g.M - 1 - m0;                   // rows past M re-read the last valid row
+      sbase[i] = Ab + (int64_t)m0 * g.a_ld * Elem<T>::kBytes;
+      voff[i] = (uint32_t)(min(row, lim) * g.a_ld * Elem<T>::kBytes + c * 16);
     } else {
-      const int bn = min(n0 + row - kBM, g.N - 1);
-      src[i] = Bb + ((int64_t)bn * g.b_ld) * Elem<T>::kBytes + c * 16;
+      const int lim = g.N - 1 - n0;
+      sbase[i] = Bb + (int64_t)n0 * g.b_ld * Elem<T>::kBytes;
+      voff[i] = (uint32_t)(min(row - kBM, lim) * g.b_ld * Elem<T>::kBytes + c * 16);
     }
     lds_base[i] = r0 * kRowBytes;
   }
@@ -275,7 +284,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
 #pragma unroll
     for (int i = 0; i < kPerWave; ++i)
       if (i < kPerWave - 1 || last_slot)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(src[i] + koff), (lds_void_t*)(sS + lds_base[i]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(sbase[i] + koff + voff[i]), (lds_void_t*)(sS + lds_base[i]), 16,
+                                         0, 0);
   };
 
   // fragment rows of this lane
@@ -307,34 +317,34 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
 #pragma unroll
     for (int s = 0; s < kStages - 1; ++s)
       if (kt0 + s < kt1) stage(s, kt0 + s);
-    int buf = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-      if (kt + kStages - 2 >= kt1) __builtin_amdgcn_s_waitcnt(kWaitAll);
-      else if (last_slot) __builtin_amdgcn_s_waitcnt(kWaitHi);
-      else __builtin_amdgcn_s_waitcnt(kWaitLo);
-      __builtin_amdgcn_s_barrier();
-      {
-        const int pre = kt + kStages - 1;
-        int pbuf = buf + kStages - 1;
-        if (pbuf >= kStages) pbuf -= kStages;
-        if (pre < kt1) stage(pbuf, pre);
-      }
-      const char* sA = smem + buf * kStageBytes;
-      const char* sB = sA + kBM * kRowBytes;
+    // one trip = kStages K tiles, so every stage index below is a compile-time constant
+    // (LDS offsets become instruction immediates)
+    for (int ktb = kt0; ktb < kt1; ktb += kStages) {
 #pragma unroll
-      for (int ks = 0; ks < M_::kSteps; ++ks) {
-        typename M_::Frag fa[2], fb[2];
+      for (int sb = 0; sb < kStages; ++sb) {
+        const int kt = ktb + sb;
+        if (kt >= kt1) break;
+        if (kt + kStages - 2 >= kt1) __builtin_amdgcn_s_waitcnt(kWaitAll);
+        else if (last_slot) __builtin_amdgcn_s_waitcnt(kWaitHi);
+        else __builtin_amdgcn_s_waitcnt(kWaitLo);
+        __builtin_amdgcn_s_barrier();
+        if (kt + kStages - 1 < kt1) stage((sb + kStages - 1) % kStages, kt + kStages - 1);
+        const char* sA = smem + sb * kStageBytes;
+        const char* sB = sA + kBM * kRowBytes;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          fa[i] = M_::load(sA + a_row[i] * kRowBytes, a_swz[i], ks, kg);
-          fb[i] = M_::load(sB + b_row[i] * kRowBytes, b_swz[i], ks, kg);
+        for (int ks = 0; ks < M_::kSteps; ++ks) {
+          typename M_::Frag fa[2], fb[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            fa[i] = M_::load(sA + a_row[i] * kRowBytes, a_swz[i], ks, kg);
+            fb[i] = M_::load(sB + b_row[i] * kRowBytes, b_swz[i], ks, kg);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) M_::mma(acc[i][j], fa[i], fb[j]);
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) M_::mma(acc[i][j], fa[i], fb[j]);
       }
-      if (++buf == kStages) buf = 0;
     }
     __syncthreads();   // the epilogue reuses the stage buffers
   }
@@ -425,8 +435,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     }
   } else if constexpr (EPI == EPI_FWD) {
     const float* th = ep.theta + (int64_t)e * ep.theta_stride;
-    const float gamma = softplusf(th[ep.off_layer_scale]);
-    const float alpha = sigmoidf(th[ep.off_act_weight]);
+    // per-member transforms of the scalar leaves, precomputed by k_member_scalars (every lane
+    // would otherwise spend ~200 VALU instructions on two log1p / exp expansions)
+    const float gamma = ep.scal[(int64_t)e * ep.scal_stride + ep.layer];
+    const float alpha = ep.scal[(int64_t)e * ep.scal_stride + BNF_MAX_LAYERS];
     T* oat = reinterpret_cast<T*>(ep.out_a) + (int64_t)e * ep.actt_batch;   // A_l^T (W, ldt)
     T* oh = ep.out_h ? reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch : nullptr;
     float* vd = ep.vdot ? ep.vdot + (int64_t)e * ep.vdot_batch : nullptr;
@@ -499,8 +511,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     }
   } else if constexpr (EPI == EPI_DGRAD) {
     const float* th = ep.theta + (int64_t)e * ep.theta_stride;
-    const float gamma = softplusf(th[ep.off_layer_scale]);
-    const float alpha = sigmoidf(th[ep.off_act_weight]);
+    // per-member transforms of the scalar leaves, precomputed by k_member_scalars (every lane
+    // would otherwise spend ~200 VALU instructions on two log1p / exp expansions)
+    const float gamma = ep.scal[(int64_t)e * ep.scal_stride + ep.layer];
+    const float alpha = ep.scal[(int64_t)e * ep.scal_stride + BNF_MAX_LAYERS];
     T* oz = reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch;
     T* tile = reinterpret_cast<T*>(smem);
     // running sums per element parity (folded after the loop)
@@ -589,8 +603,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     //   3. dZ = gamma (dv k_o / sqrt W) act'(A) -> LDS tile -> coalesced rows; column sums
     // Rows past M carry copies of the last row (clamped operand loads) and dv = 0.
     const float* th = ep.theta + (int64_t)e * ep.theta_stride;
-    const float gamma = softplusf(th[ep.off_layer_scale]);
-    const float alpha = sigmoidf(th[ep.off_act_weight]);
+    // per-member transforms of the scalar leaves, precomputed by k_member_scalars (every lane
+    // would otherwise spend ~200 VALU instructions on two log1p / exp expansions)
+    const float gamma = ep.scal[(int64_t)e * ep.scal_stride + ep.layer];
+    const float alpha = ep.scal[(int64_t)e * ep.scal_stride + BNF_MAX_LAYERS];
     const float inv_sw = 1.0f / sqrtf((float)g.N);
     T* tile = reinterpret_cast<T*>(smem);
     float* xs = reinterpret_cast<float*>(smem + kBM * kPitch * (int)sizeof(T));
@@ -654,7 +670,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
         for (int c = 0; c < WGN; ++c) vsum += s_part[tid * WGN + c];
         float dvv = 0.f;
         if (m < g.M) {
-          const float gam_o = softplusf(th[ep.off_os]);
+          const float gam_o = ep.scal[(int64_t)e * ep.scal_stride + BNF_MAX_LAYERS + 1];
           const float v = vsum * inv_sw + th[ep.off_bias_out];
           const float outv = gam_o * v;
           ep.out[(int64_t)e * ep.out_batch + m] = outv;

@@ -274,6 +274,23 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
 }
 
 // ---------------------------------------------------------------------------
+// transforms of the scalar leaves, once per member and step (the contraction epilogues read
+// them instead of re-deriving them in every lane): softplus(layer scale_l), sigmoid(activation
+// weight), softplus(output scale)         models.py:256-273
+// ---------------------------------------------------------------------------
+constexpr int kScalStride = BNF_MAX_LAYERS + 2;
+__global__ void k_member_scalars(NetDev nd, const float* __restrict__ theta, int64_t stride, int32_t n,
+                                 float* __restrict__ scal) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const float* th = theta + (int64_t)e * stride;
+  float* o = scal + (int64_t)e * kScalStride;
+  for (int l = 0; l < nd.depth; ++l) o[l] = softplusf(th[nd.off_ls[l]]);
+  o[BNF_MAX_LAYERS] = sigmoidf(th[nd.off_law]);
+  o[BNF_MAX_LAYERS + 1] = softplusf(th[nd.off_os]);
+}
+
+// ---------------------------------------------------------------------------
 // output layer + likelihood, one thread per row.  The last forward contraction
 // has already accumulated vacc[row] = sum_j H_L[row][j] k_o[j] (EPI_FWD vdot).
 //   forward  (models.py:269-273, 157-164): v = vacc/sqrt W + b_o, out = gamma_o v
