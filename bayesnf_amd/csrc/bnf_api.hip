@@ -115,7 +115,8 @@ struct bnf_handle {
   double prof_blocks = 0;
   int prof_threads = 0;
   bool fuse_last = false;     // last layer + likelihood + its backward in one kernel (EPI_LAST)
-  bool big_tiles = true;      // env BNF_BIG_TILES=0: 128 x 128 tiles everywhere (perf experiments)
+  int big_tiles = 1;          // env BNF_BIG_TILES: 0 = 128 x 128 tiles everywhere, 1 = auto, 2 = 256 x 256
+                              // wherever the shape divides (tests of the large-tile kernels at small sizes)
   float* scal = nullptr;      // (Ev, kScalStride) transformed scalar leaves (k_member_scalars)
   float* qscratch = nullptr;  // quantile partials: 2*1024*2 + 2 floats
   float* dbg_a = nullptr; float* dbg_b = nullptr;  // small debug staging (gmu/grho)
@@ -327,20 +328,31 @@ static void launch_fwd_last(bnf_handle* h, GemmArgs g, const EpiArgs& ep) {
   else launch_fwd_last_obs<T, 4>(h, g, ep);
 }
 
-template <typename T, int TAG>
-static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep, hipStream_t st) {
-  g.tiles_m = (g.M + kBM - 1) / kBM;
-  g.tiles_n = (g.N + kBN - 1) / kBN;
+template <typename T, int TAG, int WG>
+static void launch_gemm_tn_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep, hipStream_t st) {
+  constexpr int kLds = gemm_tn_lds<T>(WG);
+  g.tiles_m = (g.M + 64 * WG - 1) / (64 * WG);
+  g.tiles_n = (g.N + 64 * WG - 1) / (64 * WG);
   if (g.splitk < 1) g.splitk = 1;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn<T, TAG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn<T, TAG, WG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     attr_set = true;
   }
   const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
   LaunchScope ls(h, kid, st, true);
-  hipLaunchKernelGGL((gemm_tn<T, TAG>), dim3(blocks), dim3(kThreads), kGemmLds, st, g, ep);
+  hipLaunchKernelGGL((gemm_tn<T, TAG, WG>), dim3(blocks), dim3(64 * WG * WG), kLds, st, g, ep);
+}
+template <typename T, int TAG>
+static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep, hipStream_t st) {
+  // 256 x 256 tiles when they still fill the chip (members x tiles >= half the CUs)
+  if (h->big_tiles && g.M % 256 == 0 && g.N % 256 == 0 &&
+      ((int64_t)g.members * (g.M / 256) * (g.N / 256) >= 128 || h->big_tiles == 2)) {
+    launch_gemm_tn_wg<T, TAG, 4>(h, kid, g, ep, st);
+    return;
+  }
+  launch_gemm_tn_wg<T, TAG, 2>(h, kid, g, ep, st);
 }
 
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
@@ -870,7 +882,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   }
   for (int k = 0; k < KID_COUNT; ++k) { h->acc_ms[k] = 0; h->acc_calls[k] = 0; }
   if (const char* ab = getenv("BNF_ABLATE")) h->ablate = atoi(ab);
-  if (const char* bt = getenv("BNF_BIG_TILES")) h->big_tiles = atoi(bt) != 0;
+  if (const char* bt = getenv("BNF_BIG_TILES")) h->big_tiles = atoi(bt);
   {
     // fused row-panel pipeline: training handles with W = 128 / 256 / 512 and F <= 128
     int want = cfg->pipeline;  // 0 auto, 1 unfused, 2 fused

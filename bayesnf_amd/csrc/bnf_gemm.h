@@ -824,25 +824,33 @@ struct TnCfg;
 template <>
 struct TnCfg<bf16_t> {
   static constexpr int kRows = 64;        // batch rows per K tile
-  static constexpr int kRowBytes = 256;   // 128 columns x 2 B
 };
 template <>
 struct TnCfg<float> {
   static constexpr int kRows = 32;
-  static constexpr int kRowBytes = 512;
 };
+// LDS of a (64 WG)^2 tile: two stages of two operands, kRows rows of 64 WG columns each
+template <typename T>
+__host__ __device__ constexpr int gemm_tn_lds(int wg) {
+  return 2 * 2 * TnCfg<T>::kRows * 64 * wg * (int)sizeof(T);
+}
 
-template <typename T, int TAG>
-__global__ __launch_bounds__(kThreads, 2) void gemm_tn(const GemmArgs g, const EpiArgs ep) {
+// WG x WG waves, each a 64 x 64 sub-tile: WG = 2 -> 128 x 128 (default), WG = 4 -> 256 x 256
+// with 16 waves for the W x W weight gradients (W a multiple of 256, >= 512): this kernel is
+// almost pure K loop and bound by the operand stream into LDS, which the large tile halves.
+template <typename T, int TAG, int WG>
+__global__ __launch_bounds__(64 * WG * WG, WG == 2 ? 2 : 4) void gemm_tn(const GemmArgs g, const EpiArgs ep) {
   using C_ = TnCfg<T>;
-  constexpr int kRows = C_::kRows, kRB = C_::kRowBytes;
-  constexpr int kOpBytes = kRows * kRB;       // 16 KiB per operand per stage
-  constexpr int kStage = 2 * kOpBytes;        // 32 KiB
-  constexpr int kChunksPerRow = kRB / 16;     // 16 (bf16) / 32 (f32)
+  constexpr int kBM = 64 * WG, kBN = 64 * WG, kWaves = WG * WG;
+  constexpr int kRows = C_::kRows, kRB = kBM * (int)sizeof(T);   // row bytes of one operand tile
+  constexpr int kOpBytes = kRows * kRB;       // per operand per stage
+  constexpr int kStage = 2 * kOpBytes;
+  constexpr int kChunksPerRow = kRB / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WG, wc = wave % WG;
 
   const uint32_t per_member = (uint32_t)(g.tiles_m * g.tiles_n * g.splitk);
   uint32_t w = xcd_remap(blockIdx.x, gridDim.x);
@@ -863,16 +871,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn(const GemmArgs g, const E
   const char* Bb = reinterpret_cast<const char*>(g.B) + (int64_t)e * g.b_batch * Elem<T>::kBytes;
 
   // ---- LDS-DMA staging: one wave instruction = 1 KiB = 1024/kRB rows ---------------
-  constexpr int kInstrPerOp = kOpBytes / 1024;          // 16 per operand per tile
-  constexpr int kPerWave = kInstrPerOp / 4;             // 4
-  constexpr int kRowsPerInstr = 1024 / kRB;             // 4 (bf16) / 2 (f32)
+  constexpr int kInstrPerOp = kOpBytes / 1024;          // per operand per tile
+  constexpr int kPerWave = kInstrPerOp / kWaves;
+  constexpr int kRowsPerInstr = 1024 / kRB;
+  static_assert(kPerWave >= 1 && kPerWave * kWaves == kInstrPerOp && kRowsPerInstr >= 1, "staging map");
   int src_off_a[kPerWave], src_off_b[kPerWave], lds_base[kPerWave];
   // valid bytes of a tile row, from the (16-byte aligned, zero padded) leading dimensions
   const int a_cols_bytes = min(g.a_ld - m0, kBM) * Elem<T>::kBytes;
   const int b_cols_bytes = min(g.b_ld - n0, kBN) * Elem<T>::kBytes;
 #pragma unroll
   for (int i = 0; i < kPerWave; ++i) {
-    const int q = wave * kPerWave + i;                  // instruction index 0..15
+    const int q = wave * kPerWave + i;                  // instruction index
     const int row = q * kRowsPerInstr + lane / kChunksPerRow;
     const int cp = lane % kChunksPerRow;                // physical 16-byte chunk
     const int c = cp ^ ((row & 3) << 2);                // logical chunk: 64-byte segment ^= row & 3

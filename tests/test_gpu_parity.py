@@ -61,6 +61,40 @@ def test_weight_gradient_core(dtype, shape):
   eng.close()
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_large_tile_kernels_forced(dtype, monkeypatch):
+  """256 x 256 tiles (16 waves) of the contraction cores, forced at sizes the oracle can check
+  (production picks them only when they fill the chip): weight-gradient core + a train step."""
+  monkeypatch.setenv('BNF_BIG_TILES', '2')
+  net, model, X, y = util.make_problem(n_rows=64, width=64, depth=1)
+  eng = _engine(net, X, y, members=1, compute_dtype=dtype)
+  rng = np.random.default_rng(3)
+  R, M, N = 640, 512, 256
+  A = rng.standard_normal((R, M)).astype(np.float32)
+  B = rng.standard_normal((R, N)).astype(np.float32)
+  if dtype == 'bf16':
+    A = torch.tensor(A).bfloat16().float().numpy()
+    B = torch.tensor(B).bfloat16().float().numpy()
+  Cd = eng.debug_gemm_tn(A, B)
+  ref = A.astype(np.float64).T @ B.astype(np.float64)
+  assert util.rel_err(Cd, ref) < 2e-6, util.rel_err(Cd, ref)
+  eng.close()
+  # whole step at W = 256: forward 4 x 4 tiles (bf16), W x W weight gradient 4 x 4 tiles
+  n_rows, E = 300, 2
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=256, depth=2)
+  theta = util.random_theta(model, E)
+  eng = _engine(net, X, y, members=E, compute_dtype=dtype, pipeline='layers')
+  eng.set_params(theta)
+  loss_d, g_d = eng.debug_loss_and_grad()
+  loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
+  tol_l, tol_g = (2e-5, 5e-4) if dtype == 'fp32' else (5e-3, 6e-2)
+  np.testing.assert_allclose(loss_d, loss_o, rtol=tol_l)
+  errs = util.per_leaf_rel_err(model, g_d, g_o)
+  bad = {k: v for k, v in errs.items() if v > tol_g}
+  assert not bad, bad
+  eng.close()
+
+
 # --------------------------------------------------------------------------- forward / grads
 @pytest.mark.parametrize('depth,width,n_rows,pipeline', [
     (2, 64, 300, 'layers'), (1, 128, 130, 'layers'), (3, 192, 257, 'layers'), (2, 256, 200, 'layers'),
