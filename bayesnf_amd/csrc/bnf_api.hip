@@ -114,6 +114,7 @@ struct bnf_handle {
   double prof_gap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double prof_blocks = 0;
   int prof_threads = 0;
+  bool recompute_a0 = false;  // layer-0 pre-activation recomputed in the backward pass (DGRAD TAG 2)
   bool fuse_last = false;     // last layer + likelihood + its backward in one kernel (EPI_LAST)
   int big_tiles = 1;          // env BNF_BIG_TILES: 0 = 128 x 128 tiles everywhere, 1 = auto, 2 = 256 x 256
                               // wherever the shape divides (tests of the large-tile kernels at small sizes)
@@ -152,7 +153,7 @@ static size_t carve(bnf_handle* h, char* base) {
   h->H0 = take((size_t)Ev * Bp * Fp * es);
   h->H0t = nullptr;   // no transposed copies: the weight-gradient contraction reads row-major (gemm_tn)
   for (int l = 0; l < h->L; ++l) {
-    h->A[l] = (h->fused || (h->fuse_last && l == h->L - 1)) ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
+    h->A[l] = (h->fused || (h->fuse_last && l == h->L - 1) || (h->recompute_a0 && l == 0)) ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
     h->H[l] = (l < h->L - 1) ? take((size_t)Ev * Bp * W * es) : nullptr;       // H_{l+1} (Bp, W)
     h->Ht[l] = nullptr;
     h->dZ[l] = fo ? nullptr : take((size_t)Ev * Bp * W * es);
@@ -419,7 +420,7 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
     ep.off_layer_scale = h->nd.off_ls[l];
     ep.off_act_weight = h->nd.off_law;
     ep.scal = h->scal; ep.scal_stride = kScalStride; ep.layer = l;
-    ep.out_a = h->A[l];
+    ep.out_a = h->A[l];   // null: not materialised in this pipeline
     ep.out_h = last ? nullptr : h->H[l];
     ep.vdot = last ? h->vacc : nullptr;
     ep.vdot_batch = Bp;
@@ -574,9 +575,16 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
       ep.scal = h->scal; ep.scal_stride = kScalStride; ep.layer = l - 1;
       ep.in_a = h->A[l - 1];
       ep.out_h = h->dZ[l - 1];
-        ep.act_batch = Bp * h->W; ep.actt_batch = (int64_t)h->W * (Bp + kAtPad);
+      ep.act_batch = Bp * h->W; ep.actt_batch = (int64_t)h->W * (Bp + kAtPad);
       ep.ld = h->W; ep.ldt = (int32_t)(Bp + kAtPad);
-      launch_gemm<T, EPI_DGRAD, 1>(h, KID_DGRAD, g, ep);
+      if (l == 1 && h->recompute_a0) {
+        ep.aux_a = h->H0; ep.aux_a_batch = Bp * h->Fp;
+        ep.aux_b = h->Kt[0]; ep.aux_b_batch = h->pack_batch[0];
+        ep.aux_ld = h->Fp; ep.aux_scale = 1.0f / sqrtf((float)h->F);
+        launch_gemm<T, EPI_DGRAD, 2>(h, KID_DGRAD, g, ep);
+      } else {
+        launch_gemm<T, EPI_DGRAD, 1>(h, KID_DGRAD, g, ep);
+      }
       wgrad_after_dz<T>(h, nmem, l - 1);
     } else {
       g.N = h->Fp;
@@ -898,6 +906,8 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
     // pipeline 1: every layer kernel separate and every activation materialised (validation)
     const bool fl_ok = h->bf16 ? fused_last_supported<bf16_t>(h->W) : fused_last_supported<float>(h->W);
     h->fuse_last = !cfg->forward_only && !h->fused && want == 0 && fl_ok;
+    // its contraction depth is Fp <= 128: cheaper to redo than to write + gather A_0^T
+    h->recompute_a0 = !cfg->forward_only && !h->fused && want == 0 && h->L >= 2 && h->Fp <= 128;
     if (h->fused) {
       h->fused_lds = fused_lds_bytes(h->W, h->Fp, h->es);
       const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / h->fused_lds)));

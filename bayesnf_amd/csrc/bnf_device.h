@@ -132,6 +132,10 @@ __device__ __forceinline__ RawF8 load_raw8(const float* p) {
   return {*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)};
 }
 __device__ __forceinline__ RawB8 load_raw8(const bf16_t* p) { return {*reinterpret_cast<const u32x4*>(p)}; }
+__device__ __forceinline__ RawF4 pack_raw4(const float*, float a, float b, float c, float d) { return {f32x4{a, b, c, d}}; }
+__device__ __forceinline__ RawB4 pack_raw4(const bf16_t*, float a, float b, float c, float d) {
+  return {uint2{pack_bf16x2(a, b), pack_bf16x2(c, d)}};   // same rounding as store4
+}
 __device__ __forceinline__ void unpack(const RawF4& r, float (&o)[4]) {
   o[0] = r.v[0]; o[1] = r.v[1]; o[2] = r.v[2]; o[3] = r.v[3];
 }

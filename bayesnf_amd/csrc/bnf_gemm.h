@@ -52,7 +52,13 @@ struct EpiArgs {
   // activations: row-major (rows, ld) and transposed (ld, ldt) copies
   void* out_a;         // FWD: pre-activation A_l^T (transposed only)
   void* out_h;         // FWD: H_{l+1} row-major (null for the last layer) ; DGRAD: dZ_l row-major
-  const void* in_a;    // DGRAD: A_l^T
+  const void* in_a;    // DGRAD: A_l^T  (TAG 1)
+  // DGRAD TAG 2 (layer below = layer 0): A_0 is recomputed from the layer-0 operands instead
+  const void* aux_a;   //   H0 (rows, aux_ld)
+  const void* aux_b;   //   packed K_0^T (W, aux_ld)
+  int64_t aux_a_batch, aux_b_batch;
+  int32_t aux_ld;      //   Fp
+  float aux_scale;     //   1/sqrt(F)
   float* vdot;         // FWD (last layer): (members, vdot_batch) += H . k_o (un-normalised)
   int64_t vdot_batch;
   int32_t off_ko;      // offset of the output-layer kernel
@@ -226,27 +232,34 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
   // traffic.  When kInstr is not a multiple of kWaves the first kRem waves issue one more.
   // Address of a piece = (operand base of this tile and K tile: 64-bit, SCALAR) + (row and
   // swizzled chunk of this lane inside the tile: 32-bit, constant over the K loop).
-  const char* sbase[kPerWave];   // uniform
-  uint32_t voff[kPerWave];       // per lane
-  int lds_base[kPerWave];        // uniform
+  struct StageMap {
+    const char* sbase[kPerWave];   // uniform
+    uint32_t voff[kPerWave];       // per lane
+  };
+  int lds_base[kPerWave];          // uniform
   const bool last_slot = (kRem == 0) || (wave < kRem);   // does slot kPerWave-1 exist for this wave
+  auto make_map = [&](const char* a_base, int a_ld, const char* b_base, int b_ld) {
+    StageMap sm;
 #pragma unroll
-  for (int i = 0; i < kPerWave; ++i) {
-    const int q = min(wave + i * kWaves, kInstr - 1);
-    const int r0 = q * kRowsPerInstr;                 // uniform; a piece never straddles A | B
-    const int row = r0 + lane / kChunks, cp = lane % kChunks;
-    const int c = cp ^ M_::swz(row);
-    if (r0 < kBM) {
-      const int lim = g.M - 1 - m0;                   // rows past M re-read the last valid row
-      sbase[i] = Ab + (int64_t)m0 * g.a_ld * Elem<T>::kBytes;
-      voff[i] = (uint32_t)(min(row, lim) * g.a_ld * Elem<T>::kBytes + c * 16);
-    } else {
-      const int lim = g.N - 1 - n0;
-      sbase[i] = Bb + (int64_t)n0 * g.b_ld * Elem<T>::kBytes;
-      voff[i] = (uint32_t)(min(row - kBM, lim) * g.b_ld * Elem<T>::kBytes + c * 16);
+    for (int i = 0; i < kPerWave; ++i) {
+      const int q = min(wave + i * kWaves, kInstr - 1);
+      const int r0 = q * kRowsPerInstr;                 // uniform; a piece never straddles A | B
+      const int row = r0 + lane / kChunks, cp = lane % kChunks;
+      const int c = cp ^ M_::swz(row);
+      if (r0 < kBM) {
+        const int lim = g.M - 1 - m0;                   // rows past M re-read the last valid row
+        sm.sbase[i] = a_base + (int64_t)m0 * a_ld * Elem<T>::kBytes;
+        sm.voff[i] = (uint32_t)(min(row, lim) * a_ld * Elem<T>::kBytes + c * 16);
+      } else {
+        const int lim = g.N - 1 - n0;
+        sm.sbase[i] = b_base + (int64_t)n0 * b_ld * Elem<T>::kBytes;
+        sm.voff[i] = (uint32_t)(min(row - kBM, lim) * b_ld * Elem<T>::kBytes + c * 16);
+      }
+      lds_base[i] = r0 * kRowBytes;
     }
-    lds_base[i] = r0 * kRowBytes;
-  }
+    return sm;
+  };
+  const StageMap smain = make_map(Ab, g.a_ld, Bb, g.b_ld);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
   // the MFMAs.  A_l^T has ldt >= tiles_m * 128 zero-padded columns, so the
   // 4-row vector is always in bounds.
   typename Raw<T>::R4 apre[(EPI == EPI_DGRAD) ? 2 : 1][(EPI == EPI_DGRAD) ? 2 : 1][(EPI == EPI_DGRAD) ? 4 : 1];
-  if constexpr (EPI == EPI_DGRAD) {
+  if constexpr (EPI == EPI_DGRAD && TAG != 2) {
     const T* iat = reinterpret_cast<const T*>(ep.in_a) + (int64_t)e * ep.actt_batch;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -278,14 +291,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
 
   typedef __attribute__((address_space(3))) void lds_void_t;
   typedef __attribute__((address_space(1))) const void glb_void_t;
-  auto stage = [&](int buf, int kt) {
+  auto stage = [&](const StageMap& sm, int buf, int kt) {
     const int64_t koff = (int64_t)kt * kRowBytes;
     char* sS = smem + buf * kStageBytes;
 #pragma unroll
     for (int i = 0; i < kPerWave; ++i)
       if (i < kPerWave - 1 || last_slot)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(sbase[i] + koff + voff[i]), (lds_void_t*)(sS + lds_base[i]), 16,
-                                         0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(sm.sbase[i] + koff + sm.voff[i]),
+                                         (lds_void_t*)(sS + lds_base[i]), 16, 0, 0);
   };
 
   // fragment rows of this lane
@@ -312,23 +325,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
   constexpr int kWaitHi = (kAheadHi & 15) | ((kAheadHi >> 4) << 14) | 0x0F70;
   constexpr int kWaitLo = (kAheadLo & 15) | ((kAheadLo >> 4) << 14) | 0x0F70;
   constexpr int kWaitAll = 0x0F70;
-  BNF_MARK(ep, 1);
-  if (kt0 < kt1 && !BNF_ABL(ep, 16)) {
+  // acc += A[:, k0..k1) . B[:, k0..k1)^T over K tiles [k0, k1) of the operands behind `sm`
+  auto k_loop = [&](const StageMap& sm, int k0, int k1) {
 #pragma unroll
     for (int s = 0; s < kStages - 1; ++s)
-      if (kt0 + s < kt1) stage(s, kt0 + s);
+      if (k0 + s < k1) stage(sm, s, k0 + s);
     // one trip = kStages K tiles, so every stage index below is a compile-time constant
     // (LDS offsets become instruction immediates)
-    for (int ktb = kt0; ktb < kt1; ktb += kStages) {
+    for (int ktb = k0; ktb < k1; ktb += kStages) {
 #pragma unroll
       for (int sb = 0; sb < kStages; ++sb) {
         const int kt = ktb + sb;
-        if (kt >= kt1) break;
-        if (kt + kStages - 2 >= kt1) __builtin_amdgcn_s_waitcnt(kWaitAll);
+        if (kt >= k1) break;
+        if (kt + kStages - 2 >= k1) __builtin_amdgcn_s_waitcnt(kWaitAll);
         else if (last_slot) __builtin_amdgcn_s_waitcnt(kWaitHi);
         else __builtin_amdgcn_s_waitcnt(kWaitLo);
         __builtin_amdgcn_s_barrier();
-        if (kt + kStages - 1 < kt1) stage((sb + kStages - 1) % kStages, kt + kStages - 1);
+        if (kt + kStages - 1 < k1) stage(sm, (sb + kStages - 1) % kStages, kt + kStages - 1);
         const char* sA = smem + sb * kStageBytes;
         const char* sB = sA + kBM * kRowBytes;
 #pragma unroll
@@ -346,8 +359,37 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
         }
       }
     }
-    __syncthreads();   // the epilogue reuses the stage buffers
+    __syncthreads();   // the next user of the stage buffers (K loop or epilogue) may overwrite them
+  };
+  if constexpr (EPI == EPI_DGRAD && TAG == 2) {
+    // The layer below is layer 0, whose contraction depth is only Fp: recompute its
+    // pre-activation A_0 = gamma_0 (H0 K_0 / sqrt F + b_0) for this tile (the same MFMA sequence
+    // and the same rounding as the forward kernel -> bit-identical to what it would have
+    // stored) instead of writing A_0^T in the forward pass and gathering it here.
+    const char* Xa = reinterpret_cast<const char*>(ep.aux_a) + (int64_t)e * ep.aux_a_batch * Elem<T>::kBytes;
+    const char* Xb = reinterpret_cast<const char*>(ep.aux_b) + (int64_t)e * ep.aux_b_batch * Elem<T>::kBytes;
+    const StageMap saux = make_map(Xa, ep.aux_ld, Xb, ep.aux_ld);
+    k_loop(saux, 0, ep.aux_ld / M_::kTileK);
+    const float* th0 = ep.theta + (int64_t)e * ep.theta_stride;
+    const float gs0 = ep.scal[(int64_t)e * ep.scal_stride + ep.layer] * ep.aux_scale;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = min(n0 + wc * 64 + j * 32 + (lane & 31), g.N - 1);
+      const float gb0 = ep.scal[(int64_t)e * ep.scal_stride + ep.layer] * th0[ep.off_bias + n];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          apre[j][i][rg] = pack_raw4((const T*)nullptr, acc[i][j][rg * 4] * gs0 + gb0,
+                                     acc[i][j][rg * 4 + 1] * gs0 + gb0, acc[i][j][rg * 4 + 2] * gs0 + gb0,
+                                     acc[i][j][rg * 4 + 3] * gs0 + gb0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[i][j][rg * 4 + q] = 0.f;
+        }
+    }
   }
+  BNF_MARK(ep, 1);
+  if (kt0 < kt1 && !BNF_ABL(ep, 16)) k_loop(smain, kt0, kt1);
   BNF_MARK(ep, 2);
 
   // ---- epilogues --------------------------------------------------------------
@@ -439,7 +481,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     // would otherwise spend ~200 VALU instructions on two log1p / exp expansions)
     const float gamma = ep.scal[(int64_t)e * ep.scal_stride + ep.layer];
     const float alpha = ep.scal[(int64_t)e * ep.scal_stride + BNF_MAX_LAYERS];
-    T* oat = reinterpret_cast<T*>(ep.out_a) + (int64_t)e * ep.actt_batch;   // A_l^T (W, ldt)
+    // A_l^T (W, ldt); null when the backward pass recomputes it (layer 0, DGRAD TAG 2)
+    T* oat = ep.out_a ? reinterpret_cast<T*>(ep.out_a) + (int64_t)e * ep.actt_batch : nullptr;
     T* oh = ep.out_h ? reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch : nullptr;
     float* vd = ep.vdot ? ep.vdot + (int64_t)e * ep.vdot_batch : nullptr;
     T* tile = reinterpret_cast<T*>(smem);
@@ -487,7 +530,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
           // A_l^T has ldt >= tiles_m * 128 columns: the four-row vector is always in bounds
           // (rows past M hold copies of the last row -- the operand loader clamps -- which
           // the backward pass masks out)
-          if (!BNF_ABL(ep, 1)) store4(oat + (int64_t)n * ep.ldt + mb, av[0], av[1], av[2], av[3]);
+          if (oat && !BNF_ABL(ep, 1)) store4(oat + (int64_t)n * ep.ldt + mb, av[0], av[1], av[2], av[3]);
           // keep the 32 four-row groups sequential: without the fence the scheduler
           // interleaves all of them and the live ranges spill
           __builtin_amdgcn_sched_barrier(0);
