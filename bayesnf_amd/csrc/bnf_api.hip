@@ -393,7 +393,7 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
       attr_set = true;
     }
     hipLaunchKernelGGL((k_featurize<T>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, X, stab,
-                       y, theta, (int64_t)h->P, rows, (T*)h->H0, Bp * h->Fp,
+                       y, h->scal, rows, (T*)h->H0, Bp * h->Fp,
                        (T*)nullptr, (int64_t)h->Fp * Bp, (int32_t)Bp,
                        train ? h->ybat : (float*)nullptr, Bp);
   }
@@ -598,7 +598,7 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
     dim3 grid(cdiv(rows, 256), (unsigned)nmem);
     const float* X = h->X;
     hipLaunchKernelGGL(k_feat_bwd, grid, dim3(256), 0, h->stream, h->nd, rs, X, h->stab, theta,
-                       (int64_t)h->P, rows, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->grad,
+                       (int64_t)h->P, h->scal, rows, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->grad,
                        (int64_t)h->P);
   }
   wgrad_join(h);
@@ -610,6 +610,8 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
 template <typename T>
 static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
   LaunchScope ls(h, KID_PACK);
+  hipLaunchKernelGGL(k_member_scalars, dim3(cdiv(nmem, 64)), dim3(64), 0, h->stream, h->nd, theta,
+                     (int64_t)h->P, (int32_t)nmem, h->scal);
   for (int l = 0; l < h->L; ++l) {
     const int n_in = (l == 0) ? h->F : h->W, n_pad = (l == 0) ? h->Fp : h->W;
     const int64_t threads = (int64_t)n_pad * h->W / 8;
@@ -649,7 +651,7 @@ static void run_fused(bnf_handle* h, const float* theta, int nmem, const RowSrc&
       attr_set = true;
     }
     hipLaunchKernelGGL((k_featurize<T>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, h->X, h->stab,
-                       h->y, theta, (int64_t)h->P, h->B, (T*)h->H0, Bp * h->Fp, (T*)nullptr,
+                       h->y, h->scal, h->B, (T*)h->H0, Bp * h->Fp, (T*)nullptr,
                        (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp);
   }
   FusedArgs fa{};
@@ -684,7 +686,7 @@ static void run_fused(bnf_handle* h, const float* theta, int nmem, const RowSrc&
     LaunchScope ls(h, KID_FEATBWD);
     dim3 grid(cdiv(h->B, 256), (unsigned)nmem);
     hipLaunchKernelGGL(k_feat_bwd, grid, dim3(256), 0, h->stream, h->nd, rs, h->X, h->stab, theta,
-                       (int64_t)h->P, h->B, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->grad,
+                       (int64_t)h->P, h->scal, h->B, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->grad,
                        (int64_t)h->P);
   }
   run_wgrad<T>(h, nmem);

@@ -11,6 +11,22 @@
 namespace bnf {
 
 // Device copy of the static network description (passed by value, ~700 B).
+// Per-member table of transformed scalar leaves (k_member_scalars, once per step):
+//   [l]                 softplus(layer scale l)          [BNF_MAX_LAYERS]     sigmoid(activation weight)
+//   [BNF_MAX_LAYERS+1]  softplus(output scale)
+//   [kScalGroup + g]    softplus(feature-group scale g)  [kScalInput + d]     in_scale[d] * exp(log_scale_adjustment[d])
+constexpr int kScalGroup = BNF_MAX_LAYERS + 2;
+constexpr int kScalInput = kScalGroup + BNF_MAX_GROUPS;
+constexpr int kScalStride = kScalInput + BNF_MAX_INPUTS;
+
+// sin / cos of 2 pi x (x in revolutions), evaluated like the reference: ocml sincosf of the
+// float32 product float32(2 pi) * x.  (The hardware v_sin_f32 / v_cos_f32 were tried for the
+// bf16 pipeline: no measurable gain -- the feature kernels are not VALU-bound -- so the
+// accurate path is used everywhere.)
+__device__ __forceinline__ void sincos_rev(float x, float* s, float* c) {
+  sincosf(6.28318530717958647692f * x, s, c);
+}
+
 struct NetDev {
   int32_t D, F, Fp, W, depth, P, n_groups, n_freqs, n_interact, obs;
   int32_t group_kind[BNF_MAX_GROUPS], group_arg[BNF_MAX_GROUPS], group_ncols[BNF_MAX_GROUPS],
@@ -85,7 +101,7 @@ constexpr int kFeatRows = 128;
 template <typename T>
 __global__ __launch_bounds__(kFeatRows) void k_featurize(
     NetDev nd, RowSrc rs, const float* __restrict__ X, const float* __restrict__ Stab,
-    const float* __restrict__ y, const float* __restrict__ theta, int64_t theta_stride, int64_t B,
+    const float* __restrict__ y, const float* __restrict__ scal, int64_t B,
     T* __restrict__ H0, int64_t h0_batch, T* __restrict__ H0t, int64_t h0t_batch, int32_t ldt,
     float* __restrict__ ybat, int64_t ybat_batch) {
   extern __shared__ __attribute__((aligned(16))) char fsm[];
@@ -95,14 +111,14 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
   const int e = blockIdx.y;
   const int64_t r0 = (int64_t)blockIdx.x * kFeatRows;
   const int64_t r = r0 + threadIdx.x;
-  const float* th = theta + (int64_t)e * theta_stride;
+  const float* sc = scal + (int64_t)e * kScalStride;   // transformed scalar leaves of this member
   if (r < B) {
     const int64_t row = row_of(rs, e, r);
     const float* x = X + row * nd.D;
     float u[BNF_MAX_INPUTS];
 #pragma unroll
     for (int d = 0; d < BNF_MAX_INPUTS; ++d)
-      if (d < nd.D) u[d] = x[d] / (nd.in_scale[d] * expf(th[nd.off_lsa + d]));
+      if (d < nd.D) u[d] = x[d] / sc[kScalInput + d];
     T* trow = tile + threadIdx.x * pitch;
     T* hcol = H0t ? H0t + (int64_t)e * h0t_batch + r : nullptr;
     auto put = [&](int col, float v) {
@@ -110,7 +126,7 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
       if (hcol) Elem<T>::store(hcol + (int64_t)col * ldt, v);
     };
     for (int g = 0; g < nd.n_groups; ++g) {
-      const float sp = softplusf(th[nd.group_scale_off[g]]);
+      const float sp = sc[kScalGroup + g];
       const int c0 = nd.group_col0[g], nc = nd.group_ncols[g];
       const int kind = nd.group_kind[g];
       if (kind == BNF_GROUP_INPUT) {
@@ -121,10 +137,9 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
 #pragma unroll
         for (int d = 0; d < BNF_MAX_INPUTS; ++d)
           if (d == nd.group_arg[g]) ud = u[d];
-        const float y0 = kTwoPiF * ud;
         for (int k = 0; k < deg; ++k) {
           float sn, cs;
-          sincosf(y0 * (float)(1u << k), &sn, &cs);
+          sincos_rev(ud * (float)(1u << k), &sn, &cs);
           const float den = (float)(k + 1);
           put(c0 + k, (cs / den) * sp);
           put(c0 + deg + k, (sn / den) * sp);
@@ -165,13 +180,14 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_feat_bwd(
     NetDev nd, RowSrc rs, const float* __restrict__ X, const float* __restrict__ Stab,
-    const float* __restrict__ theta, int64_t theta_stride, int64_t B,
+    const float* __restrict__ theta, int64_t theta_stride, const float* __restrict__ scal, int64_t B,
     const float* __restrict__ dH0t, int64_t dh0_batch, int32_t ldt, float* __restrict__ grad,
     int64_t grad_stride) {
   __shared__ float red[4][BNF_MAX_GROUPS + BNF_MAX_INPUTS];
   const int e = blockIdx.y;
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const float* th = theta + (int64_t)e * theta_stride;
+  const float* sc = scal + (int64_t)e * kScalStride;
   float dfs[BNF_MAX_GROUPS], dlsa[BNF_MAX_INPUTS];
 #pragma unroll
   for (int g = 0; g < BNF_MAX_GROUPS; ++g) dfs[g] = 0.f;
@@ -185,14 +201,14 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
     for (int d = 0; d < BNF_MAX_INPUTS; ++d) {
       du[d] = 0.f;
       u[d] = 0.f;
-      if (d < nd.D) u[d] = x[d] / (nd.in_scale[d] * expf(th[nd.off_lsa + d]));
+      if (d < nd.D) u[d] = x[d] / sc[kScalInput + d];
     }
     const float* dhp = dH0t + (int64_t)e * dh0_batch + r;
     auto dh = [&](int col) { return dhp[(int64_t)col * ldt]; };
 #pragma unroll
     for (int g = 0; g < BNF_MAX_GROUPS; ++g) {
       if (g >= nd.n_groups) continue;
-      const float sp = softplusf(th[nd.group_scale_off[g]]);
+      const float sp = sc[kScalGroup + g];
       const int c0 = nd.group_col0[g], nc = nd.group_ncols[g];
       const int kind = nd.group_kind[g];
       float acc = 0.f;
@@ -210,16 +226,15 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
 #pragma unroll
         for (int d = 0; d < BNF_MAX_INPUTS; ++d)
           if (d == nd.group_arg[g]) ud = u[d];
-        const float y0 = kTwoPiF * ud;
         float dud = 0.f;
         for (int k = 0; k < deg; ++k) {
           float s, c;
-          const float sc = (float)(1u << k);
-          sincosf(y0 * sc, &s, &c);
+          const float p2 = (float)(1u << k);
+          sincos_rev(ud * p2, &s, &c);
           const float den = (float)(k + 1);
           const float dc = dh(c0 + k), ds = dh(c0 + deg + k);
           acc += dc * (c / den) + ds * (s / den);
-          dud += (kTwoPiF * sc) * (-s * dc + c * ds) / den;
+          dud += (kTwoPiF * p2) * (-s * dc + c * ds) / den;
         }
 #pragma unroll
         for (int d = 0; d < BNF_MAX_INPUTS; ++d)
@@ -278,7 +293,6 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
 // them instead of re-deriving them in every lane): softplus(layer scale_l), sigmoid(activation
 // weight), softplus(output scale)         models.py:256-273
 // ---------------------------------------------------------------------------
-constexpr int kScalStride = BNF_MAX_LAYERS + 2;
 __global__ void k_member_scalars(NetDev nd, const float* __restrict__ theta, int64_t stride, int32_t n,
                                  float* __restrict__ scal) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,6 +302,8 @@ __global__ void k_member_scalars(NetDev nd, const float* __restrict__ theta, int
   for (int l = 0; l < nd.depth; ++l) o[l] = softplusf(th[nd.off_ls[l]]);
   o[BNF_MAX_LAYERS] = sigmoidf(th[nd.off_law]);
   o[BNF_MAX_LAYERS + 1] = softplusf(th[nd.off_os]);
+  for (int g = 0; g < nd.n_groups; ++g) o[kScalGroup + g] = softplusf(th[nd.group_scale_off[g]]);
+  for (int d = 0; d < nd.D; ++d) o[kScalInput + d] = nd.in_scale[d] * expf(th[nd.off_lsa + d]);
 }
 
 // ---------------------------------------------------------------------------
