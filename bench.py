@@ -92,8 +92,9 @@ MODEL_KW = dict(width=512, depth=2, fourier_degrees=[5, 5, 5], interactions=[],
                 seasonality_periods=[4.0, 52.1775], num_seasonal_harmonics=[2, 10])
 
 
-def cpu_baseline(X, y, input_scales, members=2, steps=2):
-  """Oracle train steps on the host: float32 numpy (BLAS threads = all cores)."""
+def cpu_baseline(X, y, input_scales, members=4, steps=6):
+  """Oracle train steps on the host: float32 numpy (BLAS threads = all cores); a bounded sample
+  of the bench workload (about 10 s of CPU work at the default 4 members x 6 steps)."""
   from oracle import bnf_oracle as O
   model = O.Model(input_scales=input_scales, **MODEL_KW)
   rng = np.random.default_rng(0)
