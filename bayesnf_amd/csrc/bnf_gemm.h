@@ -259,8 +259,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     }
     return sm;
   };
-  const StageMap smain = make_map(Ab, g.a_ld, Bb, g.b_ld);
-
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -389,7 +387,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     }
   }
   BNF_MARK(ep, 1);
-  if (kt0 < kt1 && !BNF_ABL(ep, 16)) k_loop(smain, kt0, kt1);
+  if (kt0 < kt1 && !BNF_ABL(ep, 16)) {
+    const StageMap smain = make_map(Ab, g.a_ld, Bb, g.b_ld);
+    k_loop(smain, kt0, kt1);
+  }
   BNF_MARK(ep, 2);
 
   // ---- epilogues --------------------------------------------------------------

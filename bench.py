@@ -43,7 +43,7 @@ KERNEL_SYMBOL = {   # gemm_nt<T, epilogue, tag, wave rows, wave cols>
     'gemm_fwd_l0': 'void bnf::gemm_nt<{T}, 0, 0, 4, 4>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_fwd': 'void bnf::gemm_nt<{T}, 0, 1, 4, 4>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_fwd_last': 'void bnf::gemm_nt<{T}, 5, 3, 1, 8>(bnf::GemmArgs, bnf::EpiArgs)',
-    'gemm_dgrad': 'void bnf::gemm_nt<{T}, 1, 1, 2, 2>(bnf::GemmArgs, bnf::EpiArgs)',
+    'gemm_dgrad': 'void bnf::gemm_nt<{T}, 1, 2, 2, 2>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_dgrad0': 'void bnf::gemm_nt<{T}, 2, 0, 2, 2>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_wgrad_l0': 'void bnf::gemm_tn<{T}, 0, 2>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_wgrad': 'void bnf::gemm_tn<{T}, 1, 4>(bnf::GemmArgs, bnf::EpiArgs)',
