@@ -294,9 +294,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     char* sS = smem + buf * kStageBytes;
 #pragma unroll
     for (int i = 0; i < kPerWave; ++i)
-      if (i < kPerWave - 1 || last_slot)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(sm.sbase[i] + koff + sm.voff[i]),
-                                         (lds_void_t*)(sS + lds_base[i]), 16, 0, 0);
+      if (i < kPerWave - 1 || last_slot) {
+        // pin (tile base + K offset) in SGPRs: left alone the compiler re-associates the sum into
+        // a loop-invariant 64-bit per-lane pointer per piece (two VGPRs each, spilled in DGRAD)
+        const uint64_t b = (uint64_t)(sm.sbase[i] + koff);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+        const char* sp = reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(sp + sm.voff[i]), (lds_void_t*)(sS + lds_base[i]), 16, 0, 0);
+      }
   };
 
   // fragment rows of this lane
