@@ -950,10 +950,19 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 2 ? 2 : 4) void gemm_tn(const G
     const int64_t rb = (int64_t)kt * kRows * g.b_ld * Elem<T>::kBytes;
     char* sA = smem + buf * kStage;
     char* sB = sA + kOpBytes;
+    // scalar base (pinned in SGPRs, see gemm_nt) + 32-bit lane offset
+    auto pin = [](const char* p) {
+      const uint64_t b = (uint64_t)p;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+      return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+    const char* pa = pin(Ab + ra);
+    const char* pb = pin(Bb + rb);
 #pragma unroll
     for (int i = 0; i < kPerWave; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(Ab + ra + src_off_a[i]), (lds_void_t*)(sA + lds_base[i]), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(Bb + rb + src_off_b[i]), (lds_void_t*)(sB + lds_base[i]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + (uint32_t)src_off_a[i]), (lds_void_t*)(sA + lds_base[i]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + (uint32_t)src_off_b[i]), (lds_void_t*)(sB + lds_base[i]), 16, 0, 0);
     }
   };
 
