@@ -113,3 +113,26 @@ def test_c2_count_models_full_size(obs):
   net = _net(scales, obs=obs)
   th, losses = _fit(net, X, counts, 8, members=2, seed=1, learning_rate=0.005, compute_dtype='bf16')
   assert np.all(np.isfinite(losses)) and np.all(losses[:, -1] < losses[:, 0])
+
+
+def test_forward_only_bf16_matches_fp32_at_width_512():
+  """Predict path (forward-only handle, 256 x 256 forward tiles + fused output row dot in bf16) against
+  the fp32 path on the same parameters, in member and row chunks."""
+  from bayesnf_amd.engine import Engine
+  X, y, scales = _grid(T=300, S=20, seed=4)
+  net = _net(scales, width=512, depth=2)
+  rng = np.random.default_rng(0)
+  M = 6
+  theta = (0.3 * rng.standard_normal((M, net.P))).astype(np.float32)
+  outs = {}
+  for dt in ('fp32', 'bf16'):
+    eng = Engine(net, members=4, forward_only=True, row_capacity=2048, compute_dtype=dt)
+    loc, aux = eng.forward(torch.tensor(theta, device=eng.device), torch.tensor(X, dtype=torch.float32,
+                                                                                device=eng.device))
+    torch.cuda.synchronize()
+    outs[dt] = (loc.cpu().numpy(), aux.cpu().numpy())
+    eng.close()
+  assert outs['bf16'][0].shape == (M, X.shape[0])
+  np.testing.assert_allclose(outs['bf16'][1], outs['fp32'][1], rtol=1e-6)
+  scale = np.abs(outs['fp32'][0]).max()
+  assert np.abs(outs['bf16'][0] - outs['fp32'][0]).max() < 2e-2 * scale
