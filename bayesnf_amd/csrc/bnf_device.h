@@ -430,13 +430,39 @@ __device__ __forceinline__ float std_normal(uint32_t a, uint32_t b) {
   return sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
 }
 
-// reparameterisation noise eps[member_global][sample][p] of VI step `step`
+// reparameterisation noise eps[member_global][sample][p] of VI step `step`.  One Philox call
+// yields the four normals of samples 4g .. 4g+3 (two Box-Muller pairs, both branches); the
+// hardware log2 / sqrt / sin / cos are plenty for noise (the tests read eps back from the device).
+struct Normal4 {
+  float v[4];
+};
+__device__ __forceinline__ void box_muller_pair(uint32_t a, uint32_t b, float* n0, float* n1) {
+  const float u1 = u01_open(a), u2 = u01_open(b);
+  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // -2 ln u1
+  *n0 = rad * __builtin_amdgcn_cosf(u2);    // v_cos / v_sin take revolutions
+  *n1 = rad * __builtin_amdgcn_sinf(u2);
+}
+__device__ __forceinline__ Philox vi_eps_words(uint64_t seed, uint32_t member_global, uint32_t group,
+                                               uint32_t p, uint64_t step, uint32_t stream) {
+  return philox4x32(p, member_global, (uint32_t)step,
+                    (stream & 0xffu) | (group << 8) | ((uint32_t)(step >> 32) << 20), (uint32_t)seed,
+                    (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ Normal4 vi_eps4(uint64_t seed, uint32_t member_global, uint32_t group,
+                                           uint32_t p, uint64_t step, uint32_t stream) {
+  const Philox r = vi_eps_words(seed, member_global, group, p, step, stream);
+  Normal4 n;
+  box_muller_pair(r.v[0], r.v[1], &n.v[0], &n.v[1]);
+  box_muller_pair(r.v[2], r.v[3], &n.v[2], &n.v[3]);
+  return n;
+}
 __device__ __forceinline__ float vi_eps(uint64_t seed, uint32_t member_global, uint32_t sample,
                                         uint32_t p, uint64_t step, uint32_t stream) {
-  Philox r = philox4x32(p, member_global, (uint32_t)step,
-                        (stream & 0xffu) | (sample << 8) | ((uint32_t)(step >> 32) << 20),
-                        (uint32_t)seed, (uint32_t)(seed >> 32));
-  return std_normal(r.v[0], r.v[1]);
+  const Philox r = vi_eps_words(seed, member_global, sample >> 2, p, step, stream);
+  float n0, n1;
+  if (sample & 2u) box_muller_pair(r.v[2], r.v[3], &n0, &n1);
+  else box_muller_pair(r.v[0], r.v[1], &n0, &n1);
+  return (sample & 1u) ? n1 : n0;
 }
 
 // ---------------------------------------------------------------------------
