@@ -131,6 +131,26 @@ def test_forward_and_grad_fp32(depth, width, n_rows, pipeline):
     eng.close()
 
 
+@pytest.mark.parametrize('harmonics', [(40,), (90,)])
+def test_many_seasonal_frequencies(harmonics):
+  """Feature kernels with a wide seasonal block (up to 90 of the 96 supported frequencies)."""
+  n_rows, E = 333, 2
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=2, periods=(400.0,),
+                                       harmonics=harmonics, T=1000)
+  theta = util.random_theta(model, E)
+  eng = _engine(net, X, y, members=E, compute_dtype='fp32')
+  eng.set_params(theta)
+  loss_d, g_d = eng.debug_loss_and_grad()
+  out_o, ch = O.forward(model, theta, X, keep=True)
+  loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
+  assert np.max(np.abs(eng.debug_activation(0) - ch['Hs'][0])) < 5e-5
+  np.testing.assert_allclose(loss_d, loss_o, rtol=2e-5)
+  errs = util.per_leaf_rel_err(model, g_d, g_o)
+  bad = {k: v for k, v in errs.items() if v > 5e-4}
+  assert not bad, bad
+  eng.close()
+
+
 @pytest.mark.parametrize('width,pipeline', [(64, 'layers'), (64, 'auto'), (256, 'auto'), (128, 'fused'),
                                             (256, 'fused')])
 def test_train_full_batch_fp32(width, pipeline):
