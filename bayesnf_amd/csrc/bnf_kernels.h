@@ -115,10 +115,13 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
   if (r < B) {
     const int64_t row = row_of(rs, e, r);
     const float* x = X + row * nd.D;
-    float u[BNF_MAX_INPUTS];
+    // all inputs in flight together (clamped index instead of a branch per input: a load under
+    // a branch is followed by its own s_waitcnt, i.e. one full memory latency per input)
+    float xr[BNF_MAX_INPUTS], u[BNF_MAX_INPUTS];
 #pragma unroll
-    for (int d = 0; d < BNF_MAX_INPUTS; ++d)
-      if (d < nd.D) u[d] = x[d] / sc[kScalInput + d];
+    for (int d = 0; d < BNF_MAX_INPUTS; ++d) xr[d] = x[min(d, nd.D - 1)];
+#pragma unroll
+    for (int d = 0; d < BNF_MAX_INPUTS; ++d) u[d] = xr[d] / sc[kScalInput + min(d, nd.D - 1)];
     T* trow = tile + threadIdx.x * pitch;
     T* hcol = H0t ? H0t + (int64_t)e * h0t_batch + r : nullptr;
     auto put = [&](int col, float v) {
@@ -146,7 +149,15 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
         }
       } else if (kind == BNF_GROUP_SEASONAL) {
         const float* srow = Stab + row * nc;
-        for (int j = 0; j < nc; ++j) put(c0 + j, srow[j] * sp);
+        int j = 0;
+        for (; j + 8 <= nc; j += 8) {   // eight table entries in flight per wait
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = srow[j + q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) put(c0 + j + q, v[q] * sp);
+        }
+        for (; j < nc; ++j) put(c0 + j, srow[j] * sp);
       } else {
         for (int k = 0; k < nc; ++k) {
           float up = 0.f, uq = 0.f;
@@ -196,12 +207,13 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
   if (r < B) {
     const int64_t row = row_of(rs, e, r);
     const float* x = X + row * nd.D;
-    float u[BNF_MAX_INPUTS], du[BNF_MAX_INPUTS];
+    float xr[BNF_MAX_INPUTS], u[BNF_MAX_INPUTS], du[BNF_MAX_INPUTS];
+#pragma unroll
+    for (int d = 0; d < BNF_MAX_INPUTS; ++d) xr[d] = x[min(d, nd.D - 1)];   // all in flight (see k_featurize)
 #pragma unroll
     for (int d = 0; d < BNF_MAX_INPUTS; ++d) {
       du[d] = 0.f;
-      u[d] = 0.f;
-      if (d < nd.D) u[d] = x[d] / sc[kScalInput + d];
+      u[d] = d < nd.D ? xr[d] / sc[kScalInput + min(d, nd.D - 1)] : 0.f;
     }
     const float* dhp = dH0t + (int64_t)e * dh0_batch + r;
     auto dh = [&](int col) { return dhp[(int64_t)col * ldt]; };
@@ -227,21 +239,41 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
         for (int d = 0; d < BNF_MAX_INPUTS; ++d)
           if (d == nd.group_arg[g]) ud = u[d];
         float dud = 0.f;
-        for (int k = 0; k < deg; ++k) {
-          float s, c;
-          const float p2 = (float)(1u << k);
-          sincos_rev(ud * p2, &s, &c);
-          const float den = (float)(k + 1);
-          const float dc = dh(c0 + k), ds = dh(c0 + deg + k);
-          acc += dc * (c / den) + ds * (s / den);
-          dud += (kTwoPiF * p2) * (-s * dc + c * ds) / den;
+        for (int k0 = 0; k0 < deg; k0 += 4) {
+          float dcv[4], dsv[4];   // the gradient entries of four degrees in flight together
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int k = min(k0 + q, deg - 1);
+            dcv[q] = dh(c0 + k);
+            dsv[q] = dh(c0 + deg + k);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int k = k0 + q;
+            if (k < deg) {
+              float s, c;
+              const float p2 = (float)(1u << k);
+              sincos_rev(ud * p2, &s, &c);
+              const float den = (float)(k + 1);
+              acc += dcv[q] * (c / den) + dsv[q] * (s / den);
+              dud += (kTwoPiF * p2) * (-s * dcv[q] + c * dsv[q]) / den;
+            }
+          }
         }
 #pragma unroll
         for (int d = 0; d < BNF_MAX_INPUTS; ++d)
           if (d == nd.group_arg[g]) du[d] += sp * dud;
       } else if (kind == BNF_GROUP_SEASONAL) {
         const float* srow = Stab + row * nc;
-        for (int j = 0; j < nc; ++j) acc += dh(c0 + j) * srow[j];
+        int j = 0;
+        for (; j + 8 <= nc; j += 8) {   // sixteen loads in flight per wait
+          float v[8], w[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { v[q] = srow[j + q]; w[q] = dh(c0 + j + q); }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc += w[q] * v[q];
+        }
+        for (; j < nc; ++j) acc += dh(c0 + j) * srow[j];
       } else {
         for (int k = 0; k < nc; ++k) {
           const int p = nd.interact[k][0], q = nd.interact[k][1];
