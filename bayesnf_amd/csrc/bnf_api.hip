@@ -758,7 +758,7 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   float* rho = h->params + (int64_t)E * h->P;
   {
     LaunchScope ls(h, KID_VISAMPLE);
-    dim3 grid(cdiv(h->P, 256), (unsigned)E, (unsigned)S);
+    dim3 grid(cdiv(h->P, 256), (unsigned)E, (unsigned)((S + 3) / 4));
     hipLaunchKernelGGL(k_vi_sample, grid, dim3(256), 0, h->stream, mu, rho, h->P, S, h->cfg.seed,
                        h->cfg.member_offset, (uint64_t)step, (uint32_t)STREAM_VI_EPS, h->theta_c,
                        (int64_t)S * h->P, (int64_t)h->P);
@@ -1042,7 +1042,7 @@ int bnf_vi_posterior_draws(bnf_handle* h, int32_t n_draws, float* out) {
   if (n_draws < 1 || n_draws > 65535 || !out) return fail(BNF_ERR_INVALID, "n_draws/out");
   HIPCHK(hipSetDevice(h->cfg.device));
   const int E = h->cfg.members;
-  dim3 grid(cdiv(h->P, 256), (unsigned)E, (unsigned)n_draws);
+  dim3 grid(cdiv(h->P, 256), (unsigned)E, (unsigned)((n_draws + 3) / 4));
   // out[d][e][p]: member stride P, sample stride E*P
   hipLaunchKernelGGL(k_vi_sample, grid, dim3(256), 0, h->stream, h->params,
                      h->params + (int64_t)E * h->P, h->P, n_draws, h->cfg.seed,

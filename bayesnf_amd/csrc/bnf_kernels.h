@@ -638,13 +638,17 @@ __global__ __launch_bounds__(256) void k_vi_sample(const float* __restrict__ mu,
                                                    uint64_t step, uint32_t stream,
                                                    float* __restrict__ z, int64_t z_member_stride,
                                                    int64_t z_sample_stride) {
-  // grid: (ceil(P/256), members, S)
-  const int e = blockIdx.y, s = blockIdx.z;
+  // grid: (ceil(P/256), members, ceil(S/4)): one Philox call serves the four samples of a group
+  const int e = blockIdx.y, s0 = blockIdx.z * 4;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const int64_t i = (int64_t)e * P + p;
-  const float eps = vi_eps(seed, (uint32_t)(member_offset + e), (uint32_t)s, (uint32_t)p, step, stream);
-  z[(int64_t)e * z_member_stride + (int64_t)s * z_sample_stride + p] = mu[i] + vi_sigma(rho[i]) * eps;
+  const float m = mu[i], sg = vi_sigma(rho[i]);
+  const Normal4 n4 = vi_eps4(seed, (uint32_t)(member_offset + e), (uint32_t)blockIdx.z, (uint32_t)p, step, stream);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (s0 + k < S)
+      z[(int64_t)e * z_member_stride + (int64_t)(s0 + k) * z_sample_stride + p] = m + sg * n4.v[k];
 }
 
 struct ViAdamArgs {
@@ -672,6 +676,10 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
     for (int s0 = 0; s0 < a.S; s0 += 4) {
       const Normal4 n4 = vi_eps4(a.seed, (uint32_t)(a.member_offset + e), (uint32_t)(s0 >> 2), (uint32_t)p,
                                  a.step, STREAM_VI_EPS);
+      float gl[4];   // the four likelihood gradients in flight together
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        gl[k] = a.grad[((int64_t)e * a.S + min(s0 + k, a.S - 1)) * a.P + p];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int s = s0 + k;
@@ -682,7 +690,7 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
         // Logistic(loc, 1) prior: d(-log p)/dz = tanh(z/2), log p = -z - 2 softplus(-z);
         // both from u = exp(-|z|)
         const float u = expf(-fabsf(z));
-        const float g = a.grad[gi] + copysignf((1.f - u) / (1.f + u), z);
+        const float g = gl[k] + copysignf((1.f - u) / (1.f + u), z);
         if (a.apply) a.grad[gi] = 0.f;
         gmu += g;
         grho += g * eps;
