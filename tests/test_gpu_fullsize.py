@@ -136,3 +136,19 @@ def test_forward_only_bf16_matches_fp32_at_width_512():
   np.testing.assert_allclose(outs['bf16'][1], outs['fp32'][1], rtol=1e-6)
   scale = np.abs(outs['fp32'][0]).max()
   assert np.abs(outs['bf16'][0] - outs['fp32'][0]).max() < 2e-2 * scale
+
+
+def test_repeated_step_is_reproducible_at_c2():
+  """Race screen for the ring-buffered K loops (counted vmcnt + raw barriers, LDS-DMA): the same
+  forward + backward at the benchmark size must reproduce itself up to the order of f32 atomics."""
+  X, y, scales = _grid()
+  net = _net(scales)
+  eng = _engine(net, X, y, members=8, seed=1, compute_dtype='bf16')
+  eng.init_params(float(np.log(np.nanstd(y) / 2)))
+  loss0, g0 = eng.debug_loss_and_grad()
+  scale = np.abs(g0).max(axis=1, keepdims=True)
+  for _ in range(12):
+    loss, g = eng.debug_loss_and_grad()
+    assert np.abs(loss - loss0).max() <= 1e-5 * np.abs(loss0).max()
+    assert (np.abs(g - g0) / scale).max() < 1e-4
+  eng.close()
