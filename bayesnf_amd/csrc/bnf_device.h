@@ -283,7 +283,8 @@ __device__ __forceinline__ ActOut act_eval(float a, float alpha) {
     el = fmaxf(a, e1 - 1.f);
     o.ediff = el - th;
     o.h = __builtin_fmaf(alpha, o.ediff, th);
-    o.dact = __builtin_fmaf(4.f * (1.f - alpha), __builtin_fmaf(-r, r, r), a > 0.f ? alpha : alpha * e1);
+    o.dact = __builtin_fmaf(4.f * (1.f - alpha), __builtin_fmaf(-r, r, r),
+                            __builtin_fmaf(alpha, fminf(el, 0.f), alpha));   // alpha (1 + min(elu, 0))
     return o;
   } else {
     th = tanhf(a);
@@ -318,33 +319,33 @@ __device__ __forceinline__ float act_fwd(float a, float alpha) {
 struct ActOut2 {
   f32x2 h, dact, ediff;
 };
-__device__ __forceinline__ f32x2 act_parts2(f32x2 a, f32x2& e1_out, f32x2& r_out, f32x2& el_out) {
-  const f32x2 t = __builtin_elementwise_abs(a) * -1.44269504088896340736f;
-  const f32x2 e1 = {BNF_EXP2(t.x), BNF_EXP2(t.y)};
+__device__ __forceinline__ f32x2 act_parts2(f32x2 a, f32x2& r_out, f32x2& el_out) {
+  // exp(-|a|) as exp2(-|a log2 e|): the |.| and the sign are source modifiers of v_exp_f32
+  const f32x2 t = a * 1.44269504088896340736f;
+  const f32x2 e1 = {BNF_EXP2(-fabsf(t.x)), BNF_EXP2(-fabsf(t.y))};
   const f32x2 den = e1 * e1 + 1.f;
   f32x2 r = {BNF_RCP(den.x), BNF_RCP(den.y)};
   asm volatile("" : "+v"(r));   // see act_eval
   const f32x2 tha = 2.f * r - 1.f;
   const f32x2 em1 = e1 - 1.f;
   el_out = f32x2{fmaxf(a.x, em1.x), fmaxf(a.y, em1.y)};
-  e1_out = e1;
   r_out = r;
   return f32x2{copysignf(tha.x, a.x), copysignf(tha.y, a.y)};
 }
 __device__ __forceinline__ f32x2 act_fwd2(f32x2 a, float alpha) {
-  f32x2 e1, r, el;
-  const f32x2 th = act_parts2(a, e1, r, el);
+  f32x2 r, el;
+  const f32x2 th = act_parts2(a, r, el);
   return th + alpha * (el - th);
 }
 __device__ __forceinline__ ActOut2 act_eval2(f32x2 a, float alpha) {
   ActOut2 o;
-  f32x2 e1, r, el;
-  const f32x2 th = act_parts2(a, e1, r, el);
-  const f32x2 ae1 = alpha * e1;
-  const f32x2 adexp = {a.x > 0.f ? alpha : ae1.x, a.y > 0.f ? alpha : ae1.y};
+  f32x2 r, el;
+  const f32x2 th = act_parts2(a, r, el);
+  // d elu / da = (a > 0 ? 1 : e^a) = 1 + min(elu(a), 0): no compare / select
+  const f32x2 mn = {fminf(el.x, 0.f), fminf(el.y, 0.f)};
   o.ediff = el - th;
   o.h = th + alpha * o.ediff;
-  o.dact = (4.f * (1.f - alpha)) * (r - r * r) + adexp;
+  o.dact = (4.f * (1.f - alpha)) * (r - r * r) + (alpha * mn + alpha);
   return o;
 }
 
