@@ -70,6 +70,15 @@ struct Elem<bf16_t> {
   __device__ static __forceinline__ float round(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
 };
 
+// store two values to two (unrelated) addresses with ONE conversion instruction for bf16
+// (v_cvt_pk_bf16_f32 rounds both; the halves leave as ds_write_b16 / ds_write_b16_d16_hi)
+__device__ __forceinline__ void store_pair(float* p0, float* p1, float a, float b) { *p0 = a; *p1 = b; }
+__device__ __forceinline__ void store_pair(bf16_t* p0, bf16_t* p1, float a, float b) {
+  const uint32_t pk = pack_bf16x2(a, b);
+  p0->bits = (uint16_t)(pk & 0xffffu);
+  p1->bits = (uint16_t)(pk >> 16);
+}
+
 // store 4 consecutive elements (used for the transposed copies: 4 consecutive
 // rows of one column).  p must be aligned to 4 elements.
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {

@@ -23,6 +23,8 @@
 // in one L2.
 #pragma once
 
+#include <type_traits>
+
 #include "bnf_device.h"
 
 namespace bnf {
@@ -532,7 +534,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
           if (oh && !BNF_ABL(ep, 2)) {
             const int lr = wr * 64 + 4 * kg + i * 32 + 8 * rg, lc = wc * 64 + j * 32 + frow;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Elem<T>::store(tile + (lr + q) * kPitch + lc, hv[q]);
+            for (int q = 0; q < 4; q += 2)
+              store_pair(tile + (lr + q) * kPitch + lc, tile + (lr + q + 1) * kPitch + lc, hv[q], hv[q + 1]);
           }
           // A_l^T has ldt >= tiles_m * 128 columns: the four-row vector is always in bounds
           // (rows past M hold copies of the last row -- the operand loader clamps -- which
@@ -567,49 +570,58 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     const float alpha = ep.scal[(int64_t)e * ep.scal_stride + BNF_MAX_LAYERS];
     T* oz = reinterpret_cast<T*>(ep.out_h) + (int64_t)e * ep.act_batch;
     T* tile = reinterpret_cast<T*>(smem);
+    const bool full_tile = m0 + kBM <= g.M;
     // running sums per element parity (folded after the loop)
     f32x2 sa2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, cs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    // two instances of the element loop: only the last row tile needs the row masks
+    auto dgrad_tile = [&](auto full_c) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = nw + j * 32;
-      if (n >= g.N) continue;
+      for (int j = 0; j < 2; ++j) {
+        const int n = nw + j * 32;
+        if (n >= g.N) continue;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int mb = mw + i * 32 + 8 * rg;
-          float av[4], zv[4];
-          unpack(apre[j][i][rg], av);
+          for (int rg = 0; rg < 4; ++rg) {
+            const int mb = mw + i * 32 + 8 * rg;
+            float av[4], zv[4];
+            unpack(apre[j][i][rg], av);
 #pragma unroll
-          for (int q = 0; q < 4; q += 2) {
-            // rows past M carry copies of the last row: masked through the scale
-            const f32x2 ms = {mb + q < g.M ? ep.scale : 0.f, mb + q + 1 < g.M ? ep.scale : 0.f};
-            const f32x2 dh = f32x2{acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]} * ms;
-            const f32x2 a2 = {av[q], av[q + 1]};
-            ActOut2 o;
-            if (BNF_ABL(ep, 4)) { o.h = a2; o.dact = f32x2{1.f, 1.f}; o.ediff = a2; }
-            else if constexpr (FAST) o = act_eval2(a2, alpha);
-            else {
-              const ActOut o0 = act_eval<FAST>(a2.x, alpha), o1 = act_eval<FAST>(a2.y, alpha);
-              o.h = f32x2{o0.h, o1.h}; o.dact = f32x2{o0.dact, o1.dact}; o.ediff = f32x2{o0.ediff, o1.ediff};
+            for (int q = 0; q < 4; q += 2) {
+              // rows past M carry copies of the last row: masked through the scale
+              f32x2 ms = {ep.scale, ep.scale};
+              if constexpr (!decltype(full_c)::value)
+                ms = f32x2{mb + q < g.M ? ep.scale : 0.f, mb + q + 1 < g.M ? ep.scale : 0.f};
+              const f32x2 dh = f32x2{acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]} * ms;
+              const f32x2 a2 = {av[q], av[q + 1]};
+              ActOut2 o;
+              if (BNF_ABL(ep, 4)) { o.h = a2; o.dact = f32x2{1.f, 1.f}; o.ediff = a2; }
+              else if constexpr (FAST) o = act_eval2(a2, alpha);
+              else {
+                const ActOut o0 = act_eval<FAST>(a2.x, alpha), o1 = act_eval<FAST>(a2.y, alpha);
+                o.h = f32x2{o0.h, o1.h}; o.dact = f32x2{o0.dact, o1.dact}; o.ediff = f32x2{o0.ediff, o1.ediff};
+              }
+              sa2 += dh * o.ediff;
+              const f32x2 da = dh * o.dact;
+              sg2 += da * a2;
+              const f32x2 z = gamma * da;
+              cs2[j] += z;
+              zv[q] = z.x; zv[q + 1] = z.y;
             }
-            sa2 += dh * o.ediff;
-            const f32x2 da = dh * o.dact;
-            sg2 += da * a2;
-            const f32x2 z = gamma * da;
-            cs2[j] += z;
-            zv[q] = z.x; zv[q + 1] = z.y;
-          }
-          const int lr = wr * 64 + 4 * kg + i * 32 + 8 * rg, lc = wc * 64 + j * 32 + frow;
-          if (!BNF_ABL(ep, 2)) {
+            const int lr = wr * 64 + 4 * kg + i * 32 + 8 * rg, lc = wc * 64 + j * 32 + frow;
+            if (!BNF_ABL(ep, 2)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Elem<T>::store(tile + (lr + q) * kPitch + lc, zv[q]);
+              for (int q = 0; q < 4; q += 2)
+                store_pair(tile + (lr + q) * kPitch + lc, tile + (lr + q + 1) * kPitch + lc, zv[q], zv[q + 1]);
+            }
+            // pin the running sums (see EPI_LAST): keeps the add chains from sinking to their use
+            asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(cs2[0]), "+v"(cs2[1]));
+            __builtin_amdgcn_sched_barrier(0);
           }
-          // pin the running sums (see EPI_LAST): keeps the add chains from sinking to their use
-          asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(cs2[0]), "+v"(cs2[1]));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+      }
+    };
+    if (full_tile) dgrad_tile(std::true_type{});
+    else dgrad_tile(std::false_type{});
     const float s_alpha = sa2.x + sa2.y, s_gamma = sg2.x + sg2.y;
     const float colsum[2] = {cs2[0].x + cs2[0].y, cs2[1].x + cs2[1].y};
     __syncthreads();
@@ -795,8 +807,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
             cp[j] += p;
             ck[j] += o.h * dv2;
             const f32x2 z = gk[j] * p;
-            Elem<T>::store(tile + (lr + q) * kPitch + lc, z.x);
-            Elem<T>::store(tile + (lr + q + 1) * kPitch + lc, z.y);
+            store_pair(tile + (lr + q) * kPitch + lc, tile + (lr + q + 1) * kPitch + lc, z.x, z.y);
           }
         }
         // pin the running sums here: otherwise the add chains (and everything feeding them)
