@@ -268,7 +268,7 @@ static void phase_prof_end(bnf_handle* h, int kid, unsigned blocks, int threads)
 
 template <typename T, int EPI, int TAG, int WGM, int WGN>
 static void launch_gemm_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep) {
-  constexpr int kLds = Mma<T>::lds_bytes(WGM, WGN, epi_extra_lds(EPI, WGM, WGN));
+  constexpr int kLds = Mma<T>::lds_bytes(WGM, WGN, epi_extra_lds(EPI, WGM, WGN, (int)sizeof(T)));
   static_assert(kLds <= 160 * 1024, "LDS per workgroup");
   g.tiles_m = (g.M + 64 * WGM - 1) / (64 * WGM);
   g.tiles_n = (g.N + 64 * WGN - 1) / (64 * WGN);

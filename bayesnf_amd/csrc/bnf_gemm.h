@@ -173,10 +173,16 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total) {
   return first + slot;
 }
 
-// Bytes of LDS an epilogue needs beyond the (rows x cols) output tile.
-__host__ __device__ constexpr int epi_extra_lds(int epi, int wgm, int wgn) {
-  // EPI_LAST: row-dot partials (rows x wgn), dv (rows), column sums 2 x (wgm x cols), scalars
-  return epi == EPI_LAST ? (64 * wgm * wgn + 64 * wgm + 2 * wgm * 64 * wgn + 16 + 2 * wgm * wgn) * 4 : 0;
+// Bytes of LDS an epilogue needs beyond the (rows x cols) output tile of `esz`-byte elements.
+// EPI_LAST: row-dot partials (rows x wgn), dv (rows), column sums 2 x (wgm x cols), scalars;
+// they sit behind max(output tile, row-dot scratch = 64 rows x 36 floats per wave).
+constexpr int kRowDotPitch = 36;   // floats: 16 lanes x ds_read_b128 at this pitch hit 64 distinct banks
+__host__ __device__ constexpr int epi_extra_lds(int epi, int wgm, int wgn, int esz) {
+  if (epi != EPI_LAST) return 0;
+  const int xs = (64 * wgm * wgn + 64 * wgm + 2 * wgm * 64 * wgn + 16 + 2 * wgm * wgn) * 4;
+  const int tile = 64 * wgm * (64 * wgn + 16 / esz) * esz;
+  const int scratch = wgm * wgn * 64 * kRowDotPitch * 4;
+  return xs + (scratch > tile ? scratch - tile : 0);
 }
 
 // WGM x WGN waves per workgroup, each wave a 64 x 64 sub-tile:
@@ -671,7 +677,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     const float alpha = ep.scal[(int64_t)e * ep.scal_stride + BNF_MAX_LAYERS];
     const float inv_sw = 1.0f / sqrtf((float)g.N);
     T* tile = reinterpret_cast<T*>(smem);
-    float* xs = reinterpret_cast<float*>(smem + kBM * kPitch * (int)sizeof(T));
+    constexpr int kTileBytes = kBM * kPitch * (int)sizeof(T), kDotBytes = kWaves * 64 * kRowDotPitch * 4;
+    float* xs = reinterpret_cast<float*>(smem + (kTileBytes > kDotBytes ? kTileBytes : kDotBytes));
+    float* s_dot = reinterpret_cast<float*>(smem) + wave * (64 * kRowDotPitch);   // this wave's [64 rows][32 lanes]
     float* s_part = xs;                       // [kBM][WGN]
     float* s_dv = s_part + kBM * WGN;         // [kBM]
     float* s_col = s_dv + kBM;                // [2][WGM][kBN]
@@ -711,14 +719,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
               }
             }
           }
-          const int lr = wr * 64 + i * 32 + 8 * rg + 4 * kg;
+          // row (i, rg, kg, q) of this wave's 64 x 32 partial-dot image (summed below by the
+          // lane that owns the row: 4 ds_write_b32 here instead of 20 DPP adds + hazard nops)
+          float* dst = s_dot + (i * 32 + 8 * rg + 4 * kg) * kRowDotPitch + frow;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float sacc = half_wave_sum_dpp(pd[q]);
-            if (frow == 16) s_part[(lr + q) * WGN + wc] = sacc;
-          }
+          for (int q = 0; q < 4; ++q) dst[q * kRowDotPitch] = pd[q];
           __builtin_amdgcn_sched_barrier(0);
         }
+      // lane = row: sum its 32 partials (8 x ds_read_b128; the wave's own writes are in order)
+      __builtin_amdgcn_wave_barrier();
+      const f32x4* rp = reinterpret_cast<const f32x4*>(s_dot + lane * kRowDotPitch);
+      f32x4 t4 = rp[0];
+#pragma unroll
+      for (int c = 1; c < 8; ++c) t4 += rp[c];
+      s_part[(wr * 64 + lane) * WGN + wc] = (t4.x + t4.y) + (t4.z + t4.w);
     }
     __syncthreads();
     BNF_MARK(ep, 3);
