@@ -296,7 +296,9 @@ static void launch_gemm(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep) {
   // (measured on C2: forward 916 -> 811 us, forward layer 0 497 -> 445 us; the backward-data
   // epilogue needs more registers than 16 waves leave it and got slower, 864 -> 1172 us)
   if constexpr (sizeof(T) == 2 && EPI == EPI_FWD) {
-    if (g.N % 256 == 0 && g.M >= 256 && h->big_tiles) {
+    // (layer 0 has a short K loop and, since A_0 is recomputed, writes only H_1: 316 us with
+    // 128 x 128 tiles vs 362 us with 256 x 256 at C2)
+    if (g.N % 256 == 0 && g.M >= 256 && h->big_tiles && (g.K >= 256 || h->big_tiles == 2)) {
       launch_gemm_wg<T, EPI, TAG, 4, 4>(h, kid, g, ep);
       return;
     }

@@ -40,7 +40,7 @@ PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense MFMA peaks, MI355X_MICRO
 
 # engine kernel name (bnf_profile_read) -> device symbol (rocprofv3 Kernel_Name), {T} = element type
 KERNEL_SYMBOL = {   # gemm_nt<T, epilogue, tag, wave rows, wave cols>
-    'gemm_fwd_l0': 'void bnf::gemm_nt<{T}, 0, 0, 4, 4>(bnf::GemmArgs, bnf::EpiArgs)',
+    'gemm_fwd_l0': 'void bnf::gemm_nt<{T}, 0, 0, 2, 2>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_fwd': 'void bnf::gemm_nt<{T}, 0, 1, 4, 4>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_fwd_last': 'void bnf::gemm_nt<{T}, 5, 3, 1, 8>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_dgrad': 'void bnf::gemm_nt<{T}, 1, 2, 2, 2>(bnf::GemmArgs, bnf::EpiArgs)',
