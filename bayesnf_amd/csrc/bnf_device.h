@@ -258,6 +258,20 @@ __device__ __forceinline__ RowLoss row_loss_eval(int obs, const float* __restric
   return o;
 }
 
+// max / min without the canonicalising self-max the compiler adds in IEEE mode when it cannot
+// prove an operand is already quiet (values unpacked from bf16 bits, MFMA results made opaque):
+// the operands here are ordinary finite numbers.
+__device__ __forceinline__ float vmaxf(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vminf(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 struct ActOut {
   float h, dact, ediff;
 };
@@ -337,7 +351,7 @@ __device__ __forceinline__ f32x2 act_parts2(f32x2 a, f32x2& r_out, f32x2& el_out
   asm volatile("" : "+v"(r));   // see act_eval
   const f32x2 tha = 2.f * r - 1.f;
   const f32x2 em1 = e1 - 1.f;
-  el_out = f32x2{fmaxf(a.x, em1.x), fmaxf(a.y, em1.y)};
+  el_out = f32x2{vmaxf(a.x, em1.x), vmaxf(a.y, em1.y)};
   r_out = r;
   return f32x2{copysignf(tha.x, a.x), copysignf(tha.y, a.y)};
 }
@@ -351,7 +365,7 @@ __device__ __forceinline__ ActOut2 act_eval2(f32x2 a, float alpha) {
   f32x2 r, el;
   const f32x2 th = act_parts2(a, r, el);
   // d elu / da = (a > 0 ? 1 : e^a) = 1 + min(elu(a), 0): no compare / select
-  const f32x2 mn = {fminf(el.x, 0.f), fminf(el.y, 0.f)};
+  const f32x2 mn = {vminf(el.x, 0.f), vminf(el.y, 0.f)};
   o.ediff = el - th;
   o.h = th + alpha * o.ediff;
   o.dact = (4.f * (1.f - alpha)) * (r - r * r) + (alpha * mn + alpha);
