@@ -57,3 +57,23 @@ def test_random_model_shapes_fp32(seed):
   bad = {k: v for k, v in errs.items() if v > 1e-3}
   assert not bad, (bad, kw)
   eng.close()
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_random_model_shapes_bf16(seed):
+  """Same sweep through the bf16 kernels (different K-tile geometry, fast activation formulas,
+  fused last layer, large tiles): statistical agreement with the float64 oracle."""
+  from bayesnf_amd.engine import Engine
+  kw, X, y, pw = _case(seed)
+  net, model = NetSpec(**kw), O.Model(**kw)
+  E = 2
+  theta = util.random_theta(model, E, seed=seed, scale=0.4)
+  eng = Engine(net, X=X, y=y, members=E, prior_weight=pw, compute_dtype='bf16')
+  eng.set_params(theta)
+  loss_d, g_d = eng.debug_loss_and_grad()
+  loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=X.shape[0], prior_weight=pw)
+  np.testing.assert_allclose(loss_d, loss_o, rtol=3e-2, err_msg=str(kw))
+  errs = util.per_leaf_rel_err(model, g_d, g_o)
+  bad = {k: v for k, v in errs.items() if v > 0.12}
+  assert not bad, (bad, kw)
+  eng.close()
