@@ -379,3 +379,32 @@ def test_bf16_tracks_fp32(pipeline):
   assert util.rel_err(res['bf16'][1], res['fp32'][1]) < 0.05
   np.testing.assert_allclose(res['bf16'][2][:, -1], res['fp32'][2][:, -1], rtol=1e-2)
   assert np.all(res['bf16'][2][:, -1] < res['bf16'][2][:, 0])
+
+
+def test_extreme_quantiles_normal_and_counts():
+  """Tail quantiles: the mixture CDF at the returned point must hit q within the root finder's
+  value tolerance (Normal), and the integer count quantile must be the smallest k with CDF >= q."""
+  from bayesnf_amd.engine import Engine
+  for obs in ('NORMAL', 'NB'):
+    net, model, X, y = util.make_problem(n_rows=150, width=64, depth=1, observation_model=obs)
+    M = 5
+    theta = util.random_theta(model, M, scale=0.4)
+    eng = Engine(net, members=M, forward_only=True, row_capacity=150, compute_dtype='fp32')
+    loc, aux = eng.forward(torch.tensor(theta, dtype=torch.float32, device=eng.device),
+                           torch.tensor(X, dtype=torch.float32, device=eng.device))
+    qs = (0.001, 0.01, 0.99, 0.999)
+    if obs == 'NORMAL':
+      mu_o, sd_o = O.predict_normal(model, theta, X)
+      q_d = eng.normal_mixture_quantiles(loc, aux[:, 0], qs).cpu().numpy()
+      for i, q in enumerate(qs):
+        np.testing.assert_allclose(O.mixture_cdf(mu_o, sd_o, q_d[i]), q, atol=2e-5)
+    else:
+      fc = O.count_forecast(model, theta, O.forward(model, theta, X))
+      _, q_d = eng.count_mixture_quantiles(loc, aux, qs)
+      q_d = q_d.cpu().numpy()
+      for i, q in enumerate(qs):
+        k = q_d[i]
+        assert np.all(O.count_cdf(fc, k[None, :]).mean(axis=0) >= q - 3e-5)
+        lo = np.maximum(k - 1, 0)
+        assert np.all((O.count_cdf(fc, lo[None, :]).mean(axis=0) <= q + 3e-5) | (k == 0))
+    eng.close()
