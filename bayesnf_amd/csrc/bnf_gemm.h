@@ -1,26 +1,21 @@
-// bnf_gemm.h -- the dense-contraction core:  C[m][n] = sum_k A[m][k] * Bt[n][k]
+// bnf_gemm.h -- the dense-contraction cores of a BayesNF layer (reference models.py:263-268
+// forward and its autodiff, inference.py:602), batched over ensemble members.
 //
-// One MFMA kernel serves the three contractions of a BayesNF layer (reference
-// models.py:263-268 forward and its autodiff, inference.py:602), batched over
-// ensemble members:
+//   gemm_nt   C[m][n] = sum_k A[m][k] Bt[n][k]        both operands K-contiguous
+//     forward   Z  = H_l (rows x n_l) . K_l^T stored (W x n_l)          EPI_FWD / EPI_LAST
+//     dgrad     dH = dZ_{l+1} (rows x W) . K_{l+1} stored (n x W)       EPI_DGRAD / EPI_DGRAD0
+//   gemm_tn   C[i][j] = sum_r A[r][i] B[r][j]          both operands row-major (r slow)
+//     wgrad     dK = H_l^T dZ_l                        (transpose reads in LDS; no transposed
+//                                                       copy of any activation exists in HBM)
 //
-//   forward   Z   = H_l      (rows x n_l) . K_l^T  stored (W x n_l)   -> EPI_FWD
-//   dgrad     dH  = dZ_{l+1} (rows x W)   . K_{l+1} stored (n x W)    -> EPI_DGRAD / EPI_DGRAD0
-//   wgrad     dK  = H_l^T    (n_l x rows) . dZ_l^T stored (W x rows)  -> EPI_WGRAD
-//
-// Both operands are K-contiguous ("NT"), which is why every activation is kept
-// in HBM twice (row-major and transposed) and the weights in both layouts.
-//
-// Tiling (gfx950): 128x128 block tile, 256 threads = 4 waves (2x2), each wave a
-// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 f32 VGPRs).  K advances in
-// 128-byte rows (64 bf16 / 32 f32) through a double-buffered, XOR-swizzled LDS
-// image (row pitch 128 B, 16-byte chunk index ^= (row >> 1) & 7, which makes
-// every 16-lane ds_read_b128 group hit 16 distinct 16-byte slots), filled by
-// LDS-DMA (global_load_lds_dwordx4) with the swizzle applied to the source address.  bf16 uses
-// v_mfma_f32_32x32x16_bf16, f32 uses the exact v_mfma_f32_32x32x2_f32.
-// Workgroup ids are remapped so each XCD (private 4 MiB L2) owns a contiguous
-// range of (member, tile) work: a member's weights and activation panels stay
-// in one L2.
+// Tiling (gfx950): a workgroup is a WGM x WGN grid of waves, each wave a 64x64 sub-tile =
+// 2x2 MFMA 32x32 accumulators (64 f32 VGPRs); 2x2 waves (128x128) by default, 4x4 (256x256) and
+// 1xN / 2xN full-width panels where they pay (table in DESIGN.md section 4).  K advances through a
+// ring of XOR-swizzled LDS stages filled by LDS-DMA (global_load_lds_dwordx4, swizzle on the
+// source address, scalar base + 32-bit lane offset): bf16 64-byte rows (32 k), 3 stages, counted
+// s_waitcnt vmcnt + one raw s_barrier per K tile; f32 128-byte rows, 2 stages.  bf16 multiplies
+// with v_mfma_f32_32x32x16_bf16, f32 with the exact v_mfma_f32_32x32x2_f32.  Workgroup ids are
+// remapped so that each XCD (private 4 MiB L2) owns a contiguous range of (member, tile) work.
 #pragma once
 
 #include <type_traits>

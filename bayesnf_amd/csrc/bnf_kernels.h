@@ -93,8 +93,9 @@ __global__ void k_seasonal_table(const float* __restrict__ X, int64_t n_rows, in
 // ---------------------------------------------------------------------------
 // featurise forward (models.py:218-252): one thread per batch row, 128 rows per
 // block.  The row-major tile (rows, Fp) is staged in LDS and leaves as coalesced
-// 16-byte stores; the transposed copy H0^T (Fp, ldt) is written directly (lanes
-// are consecutive rows).  Also gathers the target of the row.
+// 16-byte stores (H0t is a legacy optional transposed copy, null in every pipeline).
+// Loads are issued in batches: a load under a per-group branch costs a full memory latency.
+// Also gathers the target of the row.
 // ---------------------------------------------------------------------------
 constexpr int kFeatRows = 128;
 
