@@ -1,0 +1,159 @@
+"""Bit-level restatement of the random streams the reference's goldens are a function of.
+
+THIS IS TEST INFRASTRUCTURE (see oracle/bnf_oracle.py).  The reference draws its initial
+parameters through jax.random (threefry2x32) and TensorFlow Probability's seed plumbing:
+
+  jax.random.PRNGKey / split / fold_in / bits / uniform / normal / permutation
+                                          reference call sites: src/bayesnf/inference.py:38,400,
+                                          434,571-575,593,622,706,722-725,747-753
+  tfd.JointDistributionCoroutine.sample   inference.py:425-427 (MAP / MLE init), :203-231 (VI init)
+  tfd.TruncatedNormal(0, 1, -2, 2).sample inference.py:416-423
+
+Neither library is under /root/reference nor installable here (jax==0.4.26, jaxlib==0.4.26,
+tensorflow-probability==0.24.0: requirements.Python3.10.14.txt:19,20,51), so their published
+algorithms are restated:
+
+  * Threefry-2x32, 20 rounds (Salmon et al., SC'11), as jax/_src/prng.py applies it:
+    counts are split in two halves (first half -> word 0, second half -> word 1), an odd count is
+    padded with one zero; `jax_threefry_partitionable` is False (the 0.4.26 default).
+  * split(key, n)   = threefry(key, iota(2 n)) reshaped (n, 2)
+  * fold_in(key, d) = threefry(key, [0, d])
+  * bits(key, shape)= threefry(key, iota(size))
+  * uniform(key, shape, lo, hi) = max(lo, f * (hi - lo) + lo), f = bitcast(bits >> 9 | 0x3f800000) - 1
+  * normal          = sqrt(2) erfinv(uniform(nextafter(-1, 0), 1))
+  * truncated_normal(lo, hi) = clip(sqrt(2) erfinv(uniform(erf(lo / sqrt 2), erf(hi / sqrt 2))), open interval)
+  * permutation(key, n): one round (n < 2^32 / ...) of sort-by-random-bits: key, sub = split(key);
+    stable sort of arange(n) by bits(sub, (n,))
+  * TFP: sanitize_seed(seed, salt) = fold_in(seed, int(sha512(salt).hexdigest(), 16) & (2^31 - 1));
+    JointDistributionCoroutine._execute_model salts with 'JointDistributionCoroutine', then before
+    EVERY yielded distribution (Deterministic ones included) does `sample_seed, seed = split(seed)`;
+    TruncatedNormal._sample_n draws a standard truncated normal on the standardised bounds with the
+    backend's parameterised sampler (= jax.random.truncated_normal) in (flat batch, n) layout.
+
+Known answers checked in tests/test_jax_rng.py: split(PRNGKey(0)) and normal(PRNGKey(0), (10,)) as
+printed in the JAX documentation, and -- the pin that matters -- the reference's own golden files
+tests/test_data/bnf-{map,mle}.chickenpox.8.mini.pred.csv, which only this exact chain reproduces.
+"""
+
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+from scipy import special as _sp
+
+_ROT = ((13, 15, 26, 6), (17, 29, 16, 24))
+U32 = np.uint32
+
+
+def _rotl(x, r):
+  return (x << U32(r)) | (x >> U32(32 - r))
+
+
+def threefry2x32(key, x0, x1):
+  """key (2,) uint32; x0, x1 uint32 arrays of one shape -> (y0, y1)."""
+  with np.errstate(over='ignore'):
+    k0, k1 = U32(key[0]), U32(key[1])
+    ks = (k0, k1, U32(k0 ^ k1 ^ U32(0x1BD11BDA)))
+    x0 = np.asarray(x0, dtype=U32) + ks[0]
+    x1 = np.asarray(x1, dtype=U32) + ks[1]
+    for i in range(5):
+      for r in _ROT[i % 2]:
+        x0 = x0 + x1
+        x1 = _rotl(x1, r)
+        x1 = x0 ^ x1
+      x0 = x0 + ks[(i + 1) % 3]
+      x1 = x1 + ks[(i + 2) % 3] + U32(i + 1)
+  return x0, x1
+
+
+def threefry_2x32(key, count):
+  """jax/_src/prng.py threefry_2x32: flat counts, halves -> the two words, odd sizes padded."""
+  count = np.asarray(count, dtype=U32).ravel()
+  odd = count.size % 2
+  if odd:
+    count = np.concatenate([count, np.zeros(1, U32)])
+  h = count.size // 2
+  y0, y1 = threefry2x32(key, count[:h], count[h:])
+  out = np.concatenate([y0, y1])
+  return out[:-1] if odd else out
+
+
+def prng_key(seed: int):
+  return np.array([(seed >> 32) & 0xFFFFFFFF, seed & 0xFFFFFFFF], dtype=U32)
+
+
+def split(key, num=2):
+  shape = (num,) if np.isscalar(num) else tuple(num)
+  n = int(np.prod(shape))
+  return threefry_2x32(key, np.arange(2 * n, dtype=U32)).reshape(shape + (2,))
+
+
+def fold_in(key, data: int):
+  return threefry_2x32(key, np.array([0, data & 0xFFFFFFFF], dtype=U32))
+
+
+def random_bits(key, shape):
+  n = int(np.prod(shape)) if len(shape) else 1
+  return threefry_2x32(key, np.arange(n, dtype=U32)).reshape(shape)
+
+
+def uniform(key, shape, minval=0.0, maxval=1.0):
+  """float32, as jax.random.uniform."""
+  bits = random_bits(key, shape)
+  f = ((bits >> U32(9)) | U32(0x3F800000)).view(np.float32) - np.float32(1.0)
+  lo, hi = np.float32(minval), np.float32(maxval)
+  return np.maximum(lo, f * (hi - lo) + lo).astype(np.float32)
+
+
+def normal(key, shape):
+  lo = np.nextafter(np.float32(-1.0), np.float32(0.0))
+  u = uniform(key, shape, lo, 1.0)
+  return (np.float32(np.sqrt(2)) * _sp.erfinv(u.astype(np.float64)).astype(np.float32)).astype(np.float32)
+
+
+def truncated_normal(key, lower, upper, shape):
+  sqrt2 = np.float32(np.sqrt(2))
+  a = np.float32(_sp.erf(np.float64(np.float32(lower) / sqrt2)))
+  b = np.float32(_sp.erf(np.float64(np.float32(upper) / sqrt2)))
+  u = uniform(key, shape, a, b)
+  out = sqrt2 * _sp.erfinv(u.astype(np.float64)).astype(np.float32)
+  return np.clip(out, np.nextafter(np.float32(lower), np.float32(np.inf)),
+                 np.nextafter(np.float32(upper), np.float32(-np.inf))).astype(np.float32)
+
+
+def permutation(key, n: int):
+  """jax.random.permutation(key, n) for n where one sort round suffices (n^3 < 2^32 - 1 ... the
+  reference's formula: rounds = ceil(3 ln n / ln(2^32 - 1)))."""
+  rounds = int(np.ceil(3 * np.log(max(1, n)) / np.log(np.iinfo(np.uint32).max)))
+  x = np.arange(n)
+  for _ in range(rounds):
+    key, sub = split(key, 2)
+    sort_keys = random_bits(sub, (n,))
+    x = x[np.argsort(sort_keys, kind='stable')]
+  return x
+
+
+# --------------------------------------------------------------------------- TFP seed plumbing
+def tfp_salt(salt: str) -> int:
+  return int(hashlib.sha512(str(salt).encode("utf-8")).hexdigest(), 16) & 0xFFFFFFFF
+
+
+def sanitize_seed(seed, salt=None):
+  return fold_in(seed, tfp_salt(salt)) if salt is not None else seed
+
+
+def jdc_sample_seeds(seed, n_dists: int, salt='JointDistributionCoroutine'):
+  """Seeds JointDistributionCoroutine.sample(seed=seed) hands to its n_dists yielded distributions."""
+  seed = sanitize_seed(seed, salt)
+  out = []
+  for _ in range(n_dists):
+    sample_seed, seed = split(seed, 2)
+    out.append(sample_seed)
+  return out
+
+
+def tfd_truncated_normal_std(seed, shape):
+  """tfd.TruncatedNormal(0, ones(shape), -2, 2).sample(seed=seed): (flat batch, n = 1) layout."""
+  flat = int(np.prod(shape))
+  return truncated_normal(seed, -2.0, 2.0, (flat, 1)).reshape(shape)

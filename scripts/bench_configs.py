@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from bayesnf_amd.engine import Engine   # noqa: E402
 from bayesnf_amd.spec import NetSpec    # noqa: E402
 
@@ -35,12 +35,12 @@ CONFIGS = {
                                       num_seasonal_harmonics=[4, 4]),
                                  dict(mode='vi', members=16, batch=3500, vi_samples=5, kl_weight=0.2,
                                       learning_rate=0.01), 40),
-    # (0.8M rows instead of 10M: the cost of a step is set by the batch, not by N)
-    'C4/8 synthetic minibatch MLE': (dict(T=800, S=1000, periods=[7, 365.25]),
+    # the full 10^7-row grid, resident once per GPU (X 120 MB, seasonal table 1 GB)
+    'C4/8 synthetic minibatch MLE': (dict(T=10000, S=1000, periods=[7, 365.25]),
                                    dict(width=1024, depth=4, seasonality_periods=[7, 365.25],
                                         num_seasonal_harmonics=[3, 10]),
                                    dict(mode='map', members=32, batch=65536, prior_weight=0.0,
-                                        learning_rate=0.005), 1),
+                                        learning_rate=0.005), 0),
     'C5/8 wind-like MAP (bf16)': (dict(T=6574, S=12, periods=[7, 30.4375, 365.25], keep=71000),
                                   dict(width=256, depth=2, seasonality_periods=[7, 30.4375, 365.25],
                                        num_seasonal_harmonics=[3, 10, 10]),
@@ -49,7 +49,10 @@ CONFIGS = {
 
 
 def main():
+  only = sys.argv[1] if len(sys.argv) > 1 else None       # 'C3' | 'C4' | 'C5'
   for name, (gk, nk, ek, epochs) in CONFIGS.items():
+    if only and not name.startswith(only):
+      continue
     X, y, scales = grid(**gk)
     net = NetSpec(input_scales=scales, fourier_degrees=[5, 5, 5], interactions=[], **nk)
     eng = Engine(net, X=X, y=y, seed=0, compute_dtype='bf16', **ek)
@@ -57,13 +60,32 @@ def main():
     B = ek.get('batch') or len(y)
     # (the VI engine, like tfp.vi.fit_surrogate_posterior, counts single steps, not passes)
     steps_per_epoch = 1 if ek['mode'] == 'vi' else len(y) // B
-    eng.train(0, 1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    losses = eng.train(1, epochs)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    steps = epochs * steps_per_epoch
+    if epochs == 0:
+      # C4: an epoch is 152 steps; time 12 of them through the step entry point (same kernels;
+      # debug_loss_and_grad runs forward + backward + the optimiser kernel with apply = 0)
+      n_timed = 12
+      eng.debug_loss_and_grad(0, 0)
+      torch.cuda.synchronize()
+      import ctypes as C
+      from bayesnf_amd import _native
+      grads = torch.empty((ek['members'], net.P), dtype=torch.float32, device=eng.device)
+      loss1 = torch.empty((ek['members'],), dtype=torch.float32, device=eng.device)
+      t0 = time.perf_counter()
+      for s_ in range(n_timed):
+        _native.check(eng.lib.bnf_debug_loss_and_grad(eng.handle, 0, s_, C.c_void_p(grads.data_ptr()),
+                                                      C.c_void_p(loss1.data_ptr())), 'step')
+      torch.cuda.synchronize()
+      dt = time.perf_counter() - t0
+      steps = n_timed
+      losses = loss1[:, None]
+    else:
+      eng.train(0, 1)
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      losses = eng.train(1, epochs)
+      torch.cuda.synchronize()
+      dt = time.perf_counter() - t0
+      steps = epochs * steps_per_epoch
     S = ek.get('vi_samples', 1)
     flops = net.flops_per_member_step(B, S) * ek['members'] * steps
     print(json.dumps({'config': name, 'rows': len(y), 'F': net.F, 'members_on_this_gpu': ek['members'],

@@ -1,0 +1,229 @@
+"""BASELINE.json configs C3, C4, C5 on their REAL per-GPU workloads (one GPU's 1/8 share of the
+8-GPU job; reference scripts/evaluate.py:205-212, scripts/dataset_config.py:81-108), plus oracle
+parity on exactly those feature layouts / depths at sizes the oracle finishes in seconds.
+
+  C3/8  air_quality VI   T=2160 x S=36 -> 76,192 rows, periods [24,168] / [4,4] => F = 49,
+        W=512, depth 4, B=3,500, S=5, kl_weight 0.2, 16 members
+  C4/8  synthetic MLE    N = 10^7 rows resident once (T=10,000 x S=1,000), periods [7,365.25] /
+        [3,10] => F = 59, W=1024, depth 4, B=65,536, per-member shuffles, >= 4 members
+  C5/8  wind MAP         71,000 rows, periods [7,30.4375,365.25] / [3,10,10] => F = 79,
+        W=256, depth 2, full batch, 64 members
+
+Full-size checks are size-independent properties (finite, loss decreasing, invariance under how
+the members are sharded, distinct per-member shuffles); the arithmetic itself is checked against
+the oracle on the same layouts below.
+"""
+import numpy as np
+import pytest
+import torch
+
+from bayesnf_amd.spec import NetSpec
+from oracle import bnf_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+LAYOUTS = {
+    # name: (periods, harmonics, width, depth, F)
+    'C3': ([24.0, 168.0], [4, 4], 512, 4, 49),
+    'C4': ([7.0, 365.25], [3, 10], 1024, 4, 59),
+    'C5': ([7.0, 30.4375, 365.25], [3, 10, 10], 256, 2, 79),
+}
+
+
+def grid(T, S, periods, keep=None, seed=1234):
+  """SURVEY 8(d) synthetic grid: x = (t, lat, lon), standardised site coordinates."""
+  rng = np.random.default_rng(seed)
+  lat, lon = rng.uniform(-1, 1, S), rng.uniform(-1, 1, S)
+  lat, lon = (lat - lat.mean()) / lat.std(), (lon - lon.mean()) / lon.std()
+  t = np.repeat(np.arange(T, dtype=np.float64), S)
+  s = np.tile(np.arange(S), T)
+  if keep is not None:
+    t, s = t[:keep], s[:keep]
+  X = np.stack([t, lat[s], lon[s]], axis=1)
+  y = (3 * np.sin(2 * np.pi * t / periods[0]) + np.sin(2 * np.pi * t / periods[-1]) + 2 * lat[s] * lon[s] +
+       0.5 * rng.standard_normal(t.size))
+  return X, y, [T - 1.0, 1.0, 1.0]
+
+
+def net_for(name, scales):
+  periods, harmonics, width, depth, F = LAYOUTS[name]
+  net = NetSpec(width=width, depth=depth, input_scales=scales, fourier_degrees=[5, 5, 5], interactions=[],
+                seasonality_periods=periods, num_seasonal_harmonics=harmonics)
+  assert net.F == F, (name, net.F)
+  return net
+
+
+def _engine(net, X, y, **kw):
+  from bayesnf_amd.engine import Engine
+  return Engine(net, X=X, y=y, **kw)
+
+
+# ----------------------------------------------------------------------------- full workloads
+def test_c3_air_quality_vi_full_workload():
+  X, y, scales = grid(2160, 36, [24, 168], keep=76192)
+  assert X.shape[0] == 76192
+  net = net_for('C3', scales)
+  kw = dict(mode='vi', batch=3500, vi_samples=5, kl_weight=0.2, seed=2, learning_rate=0.01, compute_dtype='bf16')
+  steps = 24
+  eng = _engine(net, X, y, members=16, **kw)
+  eng.init_params(0.0)
+  rows0 = eng.debug_row_index(0, 0)
+  rows1 = eng.debug_row_index(0, 1)
+  l16 = eng.train(0, steps)
+  torch.cuda.synchronize()
+  l16 = l16.cpu().numpy()
+  p16 = eng.get_params()
+  eng.close()
+  assert l16.shape == (16, steps) and np.all(np.isfinite(l16)) and np.all(np.isfinite(p16))
+  # one shared random batch per step (inference.py:704-709), a fresh one every step
+  assert all(np.array_equal(rows0[0], rows0[e]) for e in range(16))
+  assert len(set(rows0[0].tolist())) == 3500 and not np.array_equal(rows0[0], rows1[0])
+  # the ELBO estimate is stochastic (5 draws / step): compare block means
+  assert np.all(l16[:, -6:].mean(axis=1) < l16[:, :6].mean(axis=1))
+  # shard invariance: global members 8..15 on their own handle (what a second rank would run)
+  eng = _engine(net, X, y, members=8, member_offset=8, **kw)
+  eng.init_params(0.0)
+  l8 = eng.train(0, steps)
+  torch.cuda.synchronize()
+  l8 = l8.cpu().numpy()
+  p8 = eng.get_params()
+  eng.close()
+  np.testing.assert_allclose(l8[:, :3], l16[8:, :3], rtol=2e-3)
+  # (bf16 + atomics: trajectories diverge slowly; the early steps pin that the streams are the same)
+  assert np.abs(p8[0] - p16[0][8:]).max() < 0.1
+
+
+def test_c4_ten_million_rows_minibatch_mle_full_workload():
+  T, S = 10_000, 1_000
+  X, y, scales = grid(T, S, [7, 365.25])
+  assert X.shape[0] == 10_000_000
+  net = net_for('C4', scales)
+  kw = dict(batch=65536, prior_weight=0.0, seed=11, learning_rate=0.005, compute_dtype='bf16')
+  eng = _engine(net, X, y, members=4, **kw)
+  eng.init_params(float(np.log(np.nanstd(y) / 2)))
+  assert eng.n_rows // eng.batch == 152          # steps per epoch (ragged tail dropped)
+  rows = [eng.debug_row_index(0, s) for s in range(3)]
+  for r in rows:
+    assert r.shape == (4, 65536) and r.min() >= 0 and r.max() < 10_000_000
+    assert not np.array_equal(r[0], r[1]) and not np.array_equal(r[2], r[3])   # per-member shuffles
+    assert len(np.unique(r[0])) == 65536
+  # the three batches of member 0 are disjoint pieces of ONE permutation
+  assert len(np.unique(np.concatenate([r[0] for r in rows]))) == 3 * 65536
+  # a few steps (an epoch is 152 steps): run them through the debug entry (same kernels, no update)
+  # and one real epoch for the optimiser path
+  loss_a, g_a = eng.debug_loss_and_grad(0, 0)
+  assert np.all(np.isfinite(loss_a)) and np.all(np.isfinite(g_a))
+  losses = eng.train(0, 1)
+  torch.cuda.synchronize()
+  losses = losses.cpu().numpy()
+  th = eng.get_params()
+  loss_b, _ = eng.debug_loss_and_grad(1, 0)
+  assert losses.shape == (4, 1) and np.all(np.isfinite(losses)) and np.all(np.isfinite(th))
+  assert np.all(loss_b < loss_a)                 # 152 Adam steps later the batch loss is lower
+  # shard invariance at full size: global members 2, 3 alone reproduce the first batch loss
+  eng2 = _engine(net, X, y, members=2, member_offset=2, **kw)
+  eng2.init_params(float(np.log(np.nanstd(y) / 2)))
+  np.testing.assert_array_equal(eng2.debug_row_index(0, 1), rows[1][2:])
+  loss_c, _ = eng2.debug_loss_and_grad(0, 0)
+  np.testing.assert_allclose(loss_c, loss_a[2:], rtol=2e-3)
+  eng.close(); eng2.close()
+
+
+def test_c5_wind_map_full_workload():
+  X, y, scales = grid(6574, 12, [7, 30.4375, 365.25], keep=71000)
+  assert X.shape[0] == 71000
+  net = net_for('C5', scales)
+  kw = dict(seed=5, learning_rate=0.005, compute_dtype='bf16')
+  lns = float(np.log(np.nanstd(y) / 2))
+  steps = 10
+  eng = _engine(net, X, y, members=64, **kw)
+  eng.init_params(lns)
+  l64 = eng.train(0, steps)
+  torch.cuda.synchronize()
+  l64 = l64.cpu().numpy()
+  p64 = eng.get_params()
+  eng.close()
+  assert l64.shape == (64, steps) and np.all(np.isfinite(l64)) and np.all(np.isfinite(p64))
+  assert np.all(np.diff(l64, axis=1) < 0)        # full batch, Adam lr 0.005: monotone at the start
+  eng = _engine(net, X, y, members=8, member_offset=40, **kw)
+  eng.init_params(lns)
+  l8 = eng.train(0, steps)
+  torch.cuda.synchronize()
+  np.testing.assert_allclose(l8.cpu().numpy(), l64[40:48], rtol=5e-4)
+  assert np.abs(eng.get_params() - p64[40:48]).max() < 5e-3
+  eng.close()
+
+
+# ----------------------------------------------------------------------------- oracle parity on the layouts
+def _small_problem(name, n_rows, seed=0):
+  periods, harmonics, width, depth, F = LAYOUTS[name]
+  T = 400
+  rng = np.random.default_rng(seed)
+  t = rng.integers(0, T, n_rows).astype(np.float64)
+  lat, lon = rng.standard_normal(n_rows), rng.standard_normal(n_rows)
+  X = np.stack([t, lat, lon], axis=1).astype(np.float32).astype(np.float64)
+  y = (3 * np.sin(2 * np.pi * t / periods[0]) + 2 * lat * lon + 0.5 * rng.standard_normal(n_rows))
+  y = y.astype(np.float32).astype(np.float64)
+  kw = dict(observation_model='NORMAL', width=width, depth=depth, input_scales=[T - 1.0, 1.0, 1.0],
+            fourier_degrees=[5, 5, 5], interactions=[], seasonality_periods=periods,
+            num_seasonal_harmonics=harmonics)
+  net, model = NetSpec(**kw), O.Model(**kw)
+  assert net.F == F
+  return net, model, X, y
+
+
+@pytest.mark.parametrize('name,pw', [('C4', 0.0), ('C5', 1.0)])
+def test_layout_parity_map_mle_fp32(name, pw):
+  """fp32 engine vs float64 oracle: loss 2e-5, every gradient leaf 5e-4, on the C4 / C5 layouts."""
+  n_rows, E = 260, 2
+  net, model, X, y = _small_problem(name, n_rows)
+  theta = util.random_theta(model, E, scale=0.3)
+  eng = _engine(net, X, y, members=E, prior_weight=pw, compute_dtype='fp32')
+  eng.set_params(theta)
+  loss_d, g_d = eng.debug_loss_and_grad()
+  loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows, prior_weight=pw)
+  np.testing.assert_allclose(loss_d, loss_o, rtol=2e-5)
+  bad = {k: v for k, v in util.per_leaf_rel_err(model, g_d, g_o).items() if v > 5e-4}
+  assert not bad, bad
+  H0 = eng.debug_activation(0)
+  _, ch = O.forward(model, theta, X, keep=True)
+  assert np.max(np.abs(H0 - ch['Hs'][0])) < 5e-5
+  eng.close()
+
+
+def test_layout_parity_c4_minibatch_fp32():
+  """C4 layout, minibatch MLE with the device's own shuffles fed to the oracle: 2 epochs."""
+  n_rows, B, E = 300, 128, 2
+  net, model, X, y = _small_problem('C4', n_rows, seed=3)
+  eng = _engine(net, X, y, members=E, batch=B, prior_weight=0.0, seed=4, compute_dtype='fp32')
+  eng.init_params(0.2)
+  theta0 = eng.get_params().astype(np.float64)
+  steps = n_rows // B
+  idx = {ep: np.concatenate([eng.debug_row_index(ep, s) for s in range(steps)], axis=1) for ep in range(2)}
+  losses = eng.train(0, 2)
+  torch.cuda.synchronize()
+  theta_o, losses_o = O.train_map(model, theta0, X, y, lr=0.005, num_epochs=2, batch_size=B, prior_weight=0.0,
+                                  row_index_fn=lambda ep: idx[ep])
+  np.testing.assert_allclose(losses.cpu().numpy(), losses_o, rtol=1e-4)
+  assert util.rel_err(eng.get_params(), theta_o) < 1e-3
+  eng.close()
+
+
+def test_layout_parity_c3_vi_fp32():
+  """C3 layout (F = 49, W = 512, depth 4), ELBO step with S = 5 and the reference's kl_weight 0.2."""
+  n_rows, E, S = 200, 2, 5
+  net, model, X, y = _small_problem('C3', n_rows, seed=1)
+  eng = _engine(net, X, y, mode='vi', members=E, vi_samples=S, kl_weight=0.2, seed=3, learning_rate=0.01,
+                compute_dtype='fp32')
+  eng.init_params(0.0)
+  p0 = eng.get_params().astype(np.float64)
+  eps0 = eng.debug_vi_eps(0)
+  loss_d, g_d = eng.debug_loss_and_grad(0, 0)
+  loss_o, gmu_o, grho_o = O.vi_loss_and_grad(model, p0[0], p0[1], eps0, X, y, n_rows, 0.2)
+  np.testing.assert_allclose(loss_d, loss_o * 0.2, rtol=5e-5)
+  bad = {k: v for k, v in util.per_leaf_rel_err(model, g_d[0], gmu_o).items() if v > 5e-4}
+  assert not bad, ('gmu', bad)
+  bad = {k: v for k, v in util.per_leaf_rel_err(model, g_d[1], grho_o).items() if v > 5e-4}
+  assert not bad, ('grho', bad)
+  eng.close()
