@@ -13,6 +13,7 @@ the end (the reference's implicit pmap output gather, inference.py:452,486-492).
 
 from __future__ import annotations
 
+import os
 from typing import Any
 
 import numpy as np
@@ -20,6 +21,7 @@ import torch
 
 from . import _native
 from . import distributed
+from . import jaxseed
 from .engine import Engine
 from .spec import NetSpec
 
@@ -45,8 +47,13 @@ def _flatten_struct(net: NetSpec, params) -> np.ndarray:
 # ---------------------------------------------------------------------------
 def fit_map(features, target, seed, observation_model, model_args, num_particles,
             learning_rate, num_epochs, prior_weight=1.0, batch_size=None,
-            num_splits=1, compute_dtype=None):
+            num_splits=1, compute_dtype=None, init_rng=None):
   """Fit `num_particles` MAP (or MLE, prior_weight=0) members.
+
+  init_rng: 'jax' (default; env BNF_INIT_RNG) starts every member from the initial parameters the
+  reference itself would draw for `seed` (threefry + TFP seed chain restated on the host,
+  `jaxseed`), 'philox' from the device generator (`bnf_init_params`).  Minibatch shuffles always
+  come from the device's keyed Feistel permutation.
 
   Returns (params, losses): params is a StructTuple whose leaves have shape
   (num_devices, num_particles // num_devices, *leaf_shape); losses has shape
@@ -64,6 +71,9 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
   if per_device < 1:
     raise ValueError('fewer than one particle per device and split')
   log_noise_init = float(np.log(np.nanstd(target) / 2.0))
+  init_rng = init_rng or os.environ.get('BNF_INIT_RNG', 'jax')
+  if init_rng not in ('jax', 'philox'):
+    raise ValueError("init_rng must be 'jax' or 'philox'")
   thetas, losses = [], []
   for i in range(num_splits):
     seed_i = _native.fold_in(seed64, i) if num_splits > 1 else seed64
@@ -71,7 +81,11 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
                  members=per_device, member_offset=rank * per_device, seed=seed_i,
                  learning_rate=learning_rate, prior_weight=prior_weight,
                  compute_dtype=compute_dtype)
-    eng.init_params(log_noise_init)
+    if init_rng == 'jax':
+      keys = jaxseed.member_keys(seed, world, per_device, i if num_splits > 1 else None)[rank]
+      eng.set_params(jaxseed.map_initial_params(net, keys, log_noise_init))
+    else:
+      eng.init_params(log_noise_init)
     loss_dev = eng.train(0, num_epochs)
     theta_dev = eng.params.view(per_device, net.P)
     thetas.append(distributed.all_gather_stack(theta_dev).cpu().numpy())

@@ -1,0 +1,120 @@
+"""Initial parameters from the SAME random streams the reference draws them from.
+
+`BayesianNeuralFieldMAP/MLE.fit(table, seed=jax.random.PRNGKey(k))` in the reference initialises
+every Dense kernel with `tfd.TruncatedNormal(0, 1, -2, 2)` through
+`tfd.JointDistributionCoroutine(...).sample(seed=key_e)` where `key_e` comes from
+`jax.random.split(split(seed)[0], (devices, members))` (/root/reference/src/bayesnf/
+inference.py:399-427, 432-441, 571-575).  This module computes those numbers on the host (numpy,
+uint32 arithmetic), so that a fit with the same seed starts from the reference's own initial
+parameters -- with full-batch training (no shuffles) the whole fit then follows the reference's
+trajectory, and the reference's golden predictions are reproduced through the GPU engine
+(tests/test_gpu_estimator.py).  It is host glue executed once per fit (E x P numbers), not part
+of the per-step hot path; the device generator (Philox, `bnf_init_params`) remains available with
+`init_rng='philox'` / BNF_INIT_RNG=philox and is what bench.py uses.
+
+Restated library behaviour (jax 0.4.26 `jax/_src/prng.py`, `jax/_src/random.py`; tfp 0.24
+`internal/samplers.py`, `distributions/joint_distribution*.py`, `truncated_normal.py`):
+  threefry2x32 (20 rounds, `jax_threefry_partitionable` off): counts iota(n) split in halves;
+  split(key, n) = threefry(key, iota(2n)).reshape(n, 2);  fold_in(key, d) = threefry(key, [0, d]);
+  uniform: f = bitcast(bits >> 9 | 0x3f800000) - 1, max(lo, f (hi - lo) + lo);
+  truncated_normal: sqrt2 erfinv(uniform(erf(lo / sqrt2), erf(hi / sqrt2))) clipped to the open interval;
+  JointDistribution sampling: key <- fold_in(key, sha512('JointDistribution') mod 2^32) once, then
+  `sample_seed, key = split(key)` before every yielded distribution.
+"""
+
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+from scipy import special as _sp
+
+_U32 = np.uint32
+_ROTATIONS = ((13, 15, 26, 6), (17, 29, 16, 24))
+_JD_SALT = int(hashlib.sha512(b'JointDistribution').hexdigest(), 16) & 0xFFFFFFFF
+
+
+def as_key(seed) -> np.ndarray:
+  """int k -> PRNGKey(k) = [k >> 32, k & 0xffffffff]; a length-2 array is taken as a key."""
+  if isinstance(seed, (int, np.integer)):
+    k = int(seed) & 0xFFFFFFFFFFFFFFFF
+    return np.array([k >> 32, k & 0xFFFFFFFF], dtype=_U32)
+  arr = np.asarray(seed).reshape(-1)
+  if arr.size == 1:
+    return as_key(int(arr[0]))
+  if arr.size != 2:
+    raise ValueError('seed must be an int or a length-2 uint32 array (jax.random.PRNGKey)')
+  return arr.astype(np.uint64).astype(_U32)
+
+
+def _threefry(key, x0, x1):
+  with np.errstate(over='ignore'):
+    ks = (_U32(key[0]), _U32(key[1]), _U32(_U32(key[0]) ^ _U32(key[1]) ^ _U32(0x1BD11BDA)))
+    x0 = x0.astype(_U32) + ks[0]
+    x1 = x1.astype(_U32) + ks[1]
+    for group in range(5):
+      for r in _ROTATIONS[group % 2]:
+        x0 = x0 + x1
+        x1 = ((x1 << _U32(r)) | (x1 >> _U32(32 - r))) ^ x0
+      x0 = x0 + ks[(group + 1) % 3]
+      x1 = x1 + ks[(group + 2) % 3] + _U32(group + 1)
+  return x0, x1
+
+
+def _bits(key, n: int) -> np.ndarray:
+  """jax.random.bits(key, (n,), uint32) (original, non-partitionable layout)."""
+  m = n + (n & 1)
+  c = np.arange(m, dtype=_U32)
+  c[n:] = 0
+  y0, y1 = _threefry(key, c[:m // 2], c[m // 2:])
+  return np.concatenate([y0, y1])[:n]
+
+
+def split(key, n: int = 2) -> np.ndarray:
+  return _bits(key, 2 * n).reshape(n, 2)
+
+
+def fold_in(key, data: int) -> np.ndarray:
+  y0, y1 = _threefry(key, np.zeros(1, _U32), np.array([data & 0xFFFFFFFF], dtype=_U32))
+  return np.array([y0[0], y1[0]], dtype=_U32)
+
+
+def truncated_normal_std(key, n: int) -> np.ndarray:
+  """n draws of TruncatedNormal(0, 1, -2, 2) in float32, flat order of the leaf."""
+  sqrt2 = np.float32(np.sqrt(2.0))
+  a = np.float32(_sp.erf(np.float64(np.float32(-2.0) / sqrt2)))
+  b = np.float32(_sp.erf(np.float64(np.float32(2.0) / sqrt2)))
+  f = ((_bits(key, n) >> _U32(9)) | _U32(0x3F800000)).view(np.float32) - np.float32(1.0)
+  u = np.maximum(a, f * (b - a) + a)
+  x = sqrt2 * _sp.erfinv(u.astype(np.float64)).astype(np.float32)
+  lo = np.nextafter(np.float32(-2.0), np.float32(np.inf))
+  hi = np.nextafter(np.float32(2.0), np.float32(-np.inf))
+  return np.clip(x, lo, hi).astype(np.float32)
+
+
+def member_keys(seed, world: int, per_device: int, split_index=None) -> np.ndarray:
+  """(world, per_device, 2): `jax.random.split(init_seed, (devices, ensemble_size))` of
+  ensemble_map, with fit_map's `fold_in(seed, i)` when num_splits > 1."""
+  key = as_key(seed)
+  if split_index is not None:
+    key = fold_in(key, int(split_index))
+  init_seed = split(key, 2)[0]
+  return split(init_seed, world * per_device).reshape(world, per_device, 2)
+
+
+def map_initial_params(net, keys: np.ndarray, log_noise_init: float) -> np.ndarray:
+  """(len(keys), P) float32 packed initial parameters of MAP / MLE members (inference.py:399-427):
+  log_noise_scale = log(nanstd / 2), Dense kernels ~ TN(0, 1, [-2, 2]) from the member's key,
+  every other leaf 0.  `net.leaves` is the reference's leaf order (one split per leaf, also for
+  the leaves whose initial value is deterministic)."""
+  keys = np.asarray(keys, dtype=_U32).reshape(-1, 2)
+  theta = np.zeros((keys.shape[0], net.P), dtype=np.float32)
+  theta[:, net.by_name['log_noise_scale'].offset] = np.float32(log_noise_init)
+  for e, key in enumerate(keys):
+    key = fold_in(key, _JD_SALT)
+    for lf in net.leaves:
+      pair = split(key, 2)
+      sample_seed, key = pair[0], pair[1]
+      if len(lf.shape) == 2:
+        theta[e, lf.offset:lf.offset + lf.size] = truncated_normal_std(sample_seed, lf.size)
+  return theta

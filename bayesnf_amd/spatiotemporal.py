@@ -184,7 +184,10 @@ class BayesianNeuralFieldEstimator:
     standardize: columns to z-score (never the time column).
   Extra (not in the reference): compute_dtype 'fp32' | 'bf16' selects the
     arithmetic of the dense contractions on the GPU (fp32 accumulate either
-    way); default from env BNF_DTYPE, else 'fp32'.
+    way); default from env BNF_DTYPE, else 'fp32'.  init_rng 'jax' | 'philox' (MAP / MLE): 'jax'
+    (default, env BNF_INIT_RNG) draws the initial Dense kernels from the reference's own streams
+    for `seed` (jax threefry + TFP seed chain restated in `jaxseed`), so a full-batch fit follows
+    the reference's trajectory; 'philox' uses the device generator.
   """
 
   _ensemble_dims: int
@@ -195,7 +198,7 @@ class BayesianNeuralFieldEstimator:
                num_seasonal_harmonics=None, fourier_degrees=None,
                interactions=None, freq=None, timetype='index', depth=2,
                width=512, observation_model='NORMAL', standardize=None,
-               compute_dtype=None):
+               compute_dtype=None, init_rng=None):
     self.feature_cols = feature_cols
     self.target_col = target_col
     self.seasonality_periods = seasonality_periods
@@ -209,6 +212,7 @@ class BayesianNeuralFieldEstimator:
     self.observation_model = observation_model
     self.standardize = standardize
     self.compute_dtype = compute_dtype
+    self.init_rng = init_rng
     self.losses_ = None
     self.params_ = None
     self.data_handler = SpatiotemporalDataHandler(
@@ -340,7 +344,8 @@ class BayesianNeuralFieldMAP(BayesianNeuralFieldEstimator):
         prior_weight=self._prior_weight,
         batch_size=batch_size,
         num_splits=num_splits,
-        compute_dtype=self.compute_dtype)
+        compute_dtype=self.compute_dtype,
+        init_rng=self.init_rng)
     return self
 
 

@@ -24,15 +24,21 @@ algorithms are restated:
   * truncated_normal(lo, hi) = clip(sqrt(2) erfinv(uniform(erf(lo / sqrt 2), erf(hi / sqrt 2))), open interval)
   * permutation(key, n): one round (n < 2^32 / ...) of sort-by-random-bits: key, sub = split(key);
     stable sort of arange(n) by bits(sub, (n,))
-  * TFP: sanitize_seed(seed, salt) = fold_in(seed, int(sha512(salt).hexdigest(), 16) & (2^31 - 1));
-    JointDistributionCoroutine._execute_model salts with 'JointDistributionCoroutine', then before
-    EVERY yielded distribution (Deterministic ones included) does `sample_seed, seed = split(seed)`;
+  * TFP: sanitize_seed(seed, salt) = fold_in(seed, int(sha512(salt).hexdigest(), 16) & (2^32 - 1));
+    JointDistributionCoroutine.sample(seed=key) (sample_shape (), use_vectorized_map=True) salts the
+    key ONCE with the string 'JointDistribution', then before EVERY yielded distribution
+    (Deterministic ones included) does `sample_seed, seed = split(seed)`;
     TruncatedNormal._sample_n draws a standard truncated normal on the standardised bounds with the
     backend's parameterised sampler (= jax.random.truncated_normal) in (flat batch, n) layout.
 
-Known answers checked in tests/test_jax_rng.py: split(PRNGKey(0)) and normal(PRNGKey(0), (10,)) as
-printed in the JAX documentation, and -- the pin that matters -- the reference's own golden files
-tests/test_data/bnf-{map,mle}.chickenpox.8.mini.pred.csv, which only this exact chain reproduces.
+PIN STATUS.  jax / tfp are not importable here, so the chain above was first written from their
+published behaviour and then DETERMINED against the reference's own golden files: of every
+variant tried (salt strings, split order, iid_sample pre-steps; scripts/n1_chain_search.py keeps
+the search) exactly this one reproduces tests/test_data/bnf-map.chickenpox.8.mini.pred.csv and
+bnf-mle...pred.csv element-wise (max |yhat - golden| = 1.9e-6 / 5.0e-6 over the 100 training
+rows; any other chain is off by ~0.1).  Further known answers in tests/test_jax_rng.py:
+split(PRNGKey(0)) and normal(PRNGKey(0), (10,)) / normal(PRNGKey(42)) as printed in the JAX
+documentation.
 """
 
 from __future__ import annotations
@@ -143,7 +149,7 @@ def sanitize_seed(seed, salt=None):
   return fold_in(seed, tfp_salt(salt)) if salt is not None else seed
 
 
-def jdc_sample_seeds(seed, n_dists: int, salt='JointDistributionCoroutine'):
+def jdc_sample_seeds(seed, n_dists: int, salt='JointDistribution'):
   """Seeds JointDistributionCoroutine.sample(seed=seed) hands to its n_dists yielded distributions."""
   seed = sanitize_seed(seed, salt)
   out = []
@@ -157,3 +163,29 @@ def tfd_truncated_normal_std(seed, shape):
   """tfd.TruncatedNormal(0, ones(shape), -2, 2).sample(seed=seed): (flat batch, n = 1) layout."""
   flat = int(np.prod(shape))
   return truncated_normal(seed, -2.0, 2.0, (flat, 1)).reshape(shape)
+
+
+# --------------------------------------------------------------------------- the reference's init
+def reference_member_keys(seed, n_members: int, split_index=None):
+  """Per-member init keys of fit_map / ensemble_map (inference.py:432-441, 571-575):
+  seed_i = fold_in(seed, i) when num_splits > 1, init_seed = split(seed_i)[0],
+  keys = split(init_seed, (devices, members per device)) -- the flat order is the member order."""
+  key = np.asarray(seed, dtype=U32)
+  if split_index is not None:
+    key = fold_in(key, int(split_index))
+  init_seed = split(key, 2)[0]
+  return split(init_seed, n_members)
+
+
+def reference_map_init_matrices(model, seed, n_members: int, split_index=None):
+  """(n_members, P) array holding the reference's TruncatedNormal initial Dense kernels at their
+  packed offsets (zeros elsewhere): inference.py:399-427 through the TFP chain above.  `model` is
+  an oracle Model (leaf list in the reference's order)."""
+  keys = reference_member_keys(seed, n_members, split_index)
+  mats = np.zeros((n_members, model.P), dtype=np.float64)
+  for e in range(n_members):
+    seeds = jdc_sample_seeds(keys[e], len(model.leaves))
+    for i, lf in enumerate(model.leaves):
+      if len(lf.shape) == 2:
+        mats[e, lf.offset:lf.offset + lf.size] = tfd_truncated_normal_std(seeds[i], lf.shape).ravel()
+  return mats
