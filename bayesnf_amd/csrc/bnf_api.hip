@@ -25,6 +25,7 @@
 #include "bnf_gemm.h"
 #include "bnf_kernels.h"
 #include "bnf_fused.h"
+#include "bnf_panel.h"
 
 using namespace bnf;
 
@@ -52,12 +53,12 @@ static int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 enum KernelId {
   KID_PACK = 0, KID_FEAT, KID_FWD0, KID_FWD, KID_ROWLOSS, KID_LASTBWD, KID_DGRAD, KID_DGRAD0,
-  KID_FEATBWD, KID_WGRAD0, KID_WGRAD, KID_ADAM, KID_VISAMPLE, KID_VIADAM, KID_FUSED, KID_FWDLAST, KID_COUNT
+  KID_FEATBWD, KID_WGRAD0, KID_WGRAD, KID_ADAM, KID_VISAMPLE, KID_VIADAM, KID_FUSED, KID_FWDLAST, KID_PANEL, KID_COUNT
 };
 static const char* kKernelNames[KID_COUNT] = {
     "pack_weights", "featurize", "gemm_fwd_l0", "gemm_fwd", "row_loss", "last_bwd", "gemm_dgrad",
     "gemm_dgrad0", "feat_bwd", "gemm_wgrad_l0", "gemm_wgrad", "adam_map", "vi_sample", "vi_adam",
-    "fused_fwd_bwd", "gemm_fwd_last"};
+    "fused_fwd_bwd", "gemm_fwd_last", "panel_fwd_bwd"};
 
 struct TimedLaunch {
   int kid;
@@ -105,13 +106,14 @@ struct bnf_handle {
   float* dH0 = nullptr; float* out = nullptr; float* ybat = nullptr; float* loss_raw = nullptr;
   float* vacc = nullptr; float* dv = nullptr;   // output-layer dot accumulator, d loss / d v
   // fused row-panel pipeline
+  bool panel = false;         // row-panel forward + backward kernel (bnf_panel.h): bf16, depth 2, W = 256 / 512
   bool fused = false;
   int fused_grid = 0;
   size_t fused_lds = 0;
   void* Wf[BNF_MAX_LAYERS]; void* Wb[BNF_MAX_LAYERS];   // fragment-major packed weights
   void* spill = nullptr;
   unsigned long long* prof_buf = nullptr;   // phase clocks (ABLATE builds)
-  double prof_gap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double prof_gap[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   double prof_blocks = 0;
   int prof_threads = 0;
   bool recompute_a0 = false;  // layer-0 pre-activation recomputed in the backward pass (DGRAD TAG 2)
@@ -151,22 +153,24 @@ static size_t carve(bnf_handle* h, char* base) {
   h->stab = (float*)take((size_t)std::max<int64_t>(1, h->N * nf2) * 4);
   h->stab_pred = (float*)take((size_t)std::max<int64_t>(1, Bp * nf2) * 4);
   h->H0 = take((size_t)Ev * Bp * Fp * es);
-  h->H0t = nullptr;   // no transposed copies: the weight-gradient contraction reads row-major (gemm_tn)
+  // no transposed copies (the weight-gradient contraction reads row-major, gemm_tn); the row-panel
+  // kernel reads the features as MFMA A fragments from a second, fragment-major copy (H0t slot)
+  h->H0t = h->panel ? take((size_t)Ev * Bp * Fp * es) : nullptr;
   for (int l = 0; l < h->L; ++l) {
-    h->A[l] = (h->fused || (h->fuse_last && l == h->L - 1) || (h->recompute_a0 && l == 0)) ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
+    h->A[l] = (h->fused || h->panel || (h->fuse_last && l == h->L - 1) || (h->recompute_a0 && l == 0)) ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
     h->H[l] = (l < h->L - 1) ? take((size_t)Ev * Bp * W * es) : nullptr;       // H_{l+1} (Bp, W)
     h->Ht[l] = nullptr;
     h->dZ[l] = fo ? nullptr : take((size_t)Ev * Bp * W * es);
     h->dZt[l] = nullptr;
     const int64_t npad = (l == 0) ? Fp : W;
     h->pack_batch[l] = npad * W;
-    h->Kn[l] = h->fused ? nullptr : take((size_t)Ev * npad * W * es);
-    h->Kt[l] = h->fused ? nullptr : take((size_t)Ev * npad * W * es);
+    h->Kn[l] = (h->fused || h->panel) ? nullptr : take((size_t)Ev * npad * W * es);
+    h->Kt[l] = (h->fused || h->panel) ? nullptr : take((size_t)Ev * npad * W * es);
   }
   for (int l = 0; l < h->L; ++l) {
     const int64_t npad = (l == 0) ? Fp : W;
-    h->Wf[l] = h->fused ? take((size_t)Ev * npad * W * es) : nullptr;
-    h->Wb[l] = h->fused ? take((size_t)Ev * npad * W * es) : nullptr;
+    h->Wf[l] = (h->fused || h->panel) ? take((size_t)Ev * npad * W * es) : nullptr;
+    h->Wb[l] = (h->fused || h->panel) ? take((size_t)Ev * npad * W * es) : nullptr;
   }
   h->spill = (h->fused && h->L > 1)
                  ? take((size_t)h->fused_grid * (h->L - 1) * kFusedBM * W * es) : nullptr;
@@ -238,9 +242,9 @@ static void phase_prof_begin(bnf_handle* h, int kid, unsigned blocks, EpiArgs* e
 #ifdef BNF_ENABLE_ABLATE
   const char* want = getenv("BNF_PHASE_PROF");
   if (!want || strcmp(want, kKernelNames[kid]) != 0) return;
-  if (!h->prof_buf) (void)hipMalloc(&h->prof_buf, (size_t)(1 << 20) * 8 * sizeof(unsigned long long));
+  if (!h->prof_buf) (void)hipMalloc(&h->prof_buf, (size_t)(1 << 20) * 16 * sizeof(unsigned long long));
   if (blocks > (1u << 20)) return;
-  (void)hipMemsetAsync(h->prof_buf, 0, (size_t)blocks * 64, h->stream);
+  (void)hipMemsetAsync(h->prof_buf, 0, (size_t)blocks * 128, h->stream);
   ep->prof = h->prof_buf;
 #endif
 }
@@ -248,18 +252,18 @@ static void phase_prof_end(bnf_handle* h, int kid, unsigned blocks, int threads)
 #ifdef BNF_ENABLE_ABLATE
   const char* want = getenv("BNF_PHASE_PROF");
   if (!want || strcmp(want, kKernelNames[kid]) != 0 || !h->prof_buf || blocks > (1u << 20)) return;
-  std::vector<unsigned long long> host((size_t)blocks * 8);
+  std::vector<unsigned long long> host((size_t)blocks * 16);
   (void)hipStreamSynchronize(h->stream);
   (void)hipMemcpy(host.data(), h->prof_buf, host.size() * 8, hipMemcpyDeviceToHost);
   for (unsigned b = 0; b < blocks; ++b) {
-    unsigned long long prev = host[(size_t)b * 8];
-    for (int k = 1; k < 8; ++k) {
-      const unsigned long long t = host[(size_t)b * 8 + k];
+    unsigned long long prev = host[(size_t)b * 16];
+    for (int k = 1; k < 16; ++k) {
+      const unsigned long long t = host[(size_t)b * 16 + k];
       if (!t) continue;
       h->prof_gap[k] += (double)(t - prev);
       prev = t;
     }
-    h->prof_gap[0] += (double)(prev - host[(size_t)b * 8]);
+    h->prof_gap[0] += (double)(prev - host[(size_t)b * 16]);
   }
   h->prof_blocks += blocks;
   h->prof_threads = threads;
@@ -694,6 +698,81 @@ static void run_fused(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   run_wgrad<T>(h, nmem);
 }
 
+// ---------------------------------------------------------------------------
+// row-panel pipeline (bf16, depth 2): pack fragments -> featurise -> k_panel_fwd_bwd ->
+// featurise backward -> gemm_tn weight gradients
+// ---------------------------------------------------------------------------
+template <int WN, int RT, bool H0L>
+static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
+  constexpr int kLds = panel_lds_bytes(WN, RT, H0L);
+  static_assert(kLds <= 160 * 1024, "LDS per workgroup");
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel_fwd_bwd<WN, RT, H0L>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+  const unsigned blocks = (unsigned)(pa.members * pa.panels);
+  PanelArgs pa2 = pa;
+  pa2.ablate = h->ablate;
+  {
+    EpiArgs tmp{};
+    phase_prof_begin(h, KID_PANEL, blocks, &tmp);
+    pa2.prof = tmp.prof;
+  }
+  {
+    LaunchScope ls(h, KID_PANEL);
+    hipLaunchKernelGGL((k_panel_fwd_bwd<WN, RT, H0L>), dim3(blocks), dim3(512), kLds, h->stream, pa2);
+  }
+  phase_prof_end(h, KID_PANEL, blocks, 512);
+}
+
+static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs, float c,
+                      const LossSink& sink) {
+  const int64_t Bp = h->Bp;
+  run_pack_fragments<bf16_t>(h, theta, nmem);
+  {
+    LaunchScope ls(h, KID_FEAT);
+    dim3 grid(cdiv(h->B, kFeatRows), (unsigned)nmem);
+    const size_t lds = (size_t)kFeatRows * (h->Fp + 8) * 2;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_featurize<bf16_t>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((k_featurize<bf16_t>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, h->X, h->stab,
+                       h->y, h->scal, h->B, (bf16_t*)h->H0, Bp * h->Fp, (bf16_t*)h->H0t,
+                       (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp);
+  }
+  PanelArgs pa{};
+  pa.F = h->F; pa.Fp = h->Fp; pa.B = (int32_t)h->B; pa.members = nmem;
+  pa.theta = theta; pa.theta_stride = h->P; pa.scal = h->scal;
+  pa.off_bias0 = h->nd.off_bias[0]; pa.off_bias1 = h->nd.off_bias[1]; pa.off_bias_out = h->nd.off_bias[2];
+  pa.off_ko = h->nd.off_kernel[2]; pa.off_ls0 = h->nd.off_ls[0]; pa.off_ls1 = h->nd.off_ls[1];
+  pa.off_os = h->nd.off_os; pa.off_law = h->nd.off_law; pa.off_lns = h->nd.off_lns;
+  pa.off_shape = h->nd.off_shape; pa.off_infl = h->nd.off_infl; pa.obs = h->nd.obs;
+  pa.H0 = (const bf16_t*)h->H0t; pa.H0rm = (const bf16_t*)h->H0; pa.h0_batch = Bp * h->Fp;   // fragment-major / row-major
+  pa.Wf0 = (const bf16_t*)h->Wf[0]; pa.Wf1 = (const bf16_t*)h->Wf[1];
+  pa.Wb0 = (const bf16_t*)h->Wb[0]; pa.Wb1 = (const bf16_t*)h->Wb[1];
+  pa.w0_batch = h->pack_batch[0]; pa.w1_batch = h->pack_batch[1];
+  pa.H1 = (bf16_t*)h->H[0]; pa.dZ1 = (bf16_t*)h->dZ[1]; pa.dZ0 = (bf16_t*)h->dZ[0]; pa.act_batch = Bp * h->W;
+  pa.dH0t = h->dH0; pa.dh0_batch = (int64_t)h->Fp * Bp; pa.ldt = (int32_t)Bp;
+  pa.ybat = h->ybat; pa.row_batch = Bp; pa.out = h->out; pa.out_batch = Bp;
+  pa.grad = h->grad; pa.grad_stride = h->P;
+  pa.loss = sink.loss; pa.loss_raw = sink.raw; pa.loss_stride = sink.stride; pa.S = h->S;
+  pa.loss_scale = sink.scale; pa.lik_c = c;
+  // 128-row panels at W = 512 (the feature panel staged in LDS when Fp = 64), 256-row panels at W = 256
+  if (h->W == 512) {
+    pa.panels = (int32_t)(Bp / panel_rows(8, 4));
+    if (h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L")) launch_panel<8, 4, true>(h, pa);
+    else launch_panel<8, 4, false>(h, pa);
+  } else {
+    pa.panels = (int32_t)(Bp / panel_rows(4, 4));
+    launch_panel<4, 4, false>(h, pa);
+  }
+  {
+    LaunchScope ls(h, KID_FEATBWD);
+    dim3 grid(cdiv(h->B, 256), (unsigned)nmem);
+    hipLaunchKernelGGL(k_feat_bwd, grid, dim3(256), 0, h->stream, h->nd, rs, h->X, h->stab, theta,
+                       (int64_t)h->P, h->scal, h->B, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->grad,
+                       (int64_t)h->P);
+  }
+  run_wgrad<bf16_t>(h, nmem);
+}
+
 static RowSrc make_rowsrc(const bnf_handle* h, int64_t epoch, int64_t step) {
   RowSrc rs{};
   rs.S = h->S;
@@ -720,7 +799,9 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
   const RowSrc rs = make_rowsrc(h, epoch, step);
   const int E = h->cfg.members;
   const float c = (float)((double)h->N / (double)h->B);
-  if (h->fused) {
+  if (h->panel) {
+    run_panel(h, h->params, E, rs, c, sink);
+  } else if (h->fused) {
     run_fused<T>(h, h->params, E, rs, c, sink);
   } else {
     run_pack<T>(h, h->params, E);
@@ -768,7 +849,9 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   const float kl = h->cfg.kl_weight;
   const float c = (float)((double)h->N / (double)h->B / (double)kl);
   LossSink sink{loss, loss_stride, kl / (float)S, nullptr};
-  if (h->fused) {
+  if (h->panel) {
+    run_panel(h, h->theta_c, h->Ev, rs, c, sink);
+  } else if (h->fused) {
     run_fused<T>(h, h->theta_c, h->Ev, rs, c, sink);
   } else {
     run_pack<T>(h, h->theta_c, h->Ev);
@@ -906,12 +989,20 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
       return fail(BNF_ERR_INVALID, "fused pipeline needs a NORMAL training handle with width 128/256/512 and <= 128 features");
     }
     h->fused = can && want == 2;   // opt-in: measured slower than the layer kernels
+    // pipeline 3: row-panel forward + backward kernel (bf16, two hidden layers, width 256 / 512)
+    const bool can_panel = !cfg->forward_only && h->bf16 && h->L == 2 && (h->W == 256 || h->W == 512) && h->Fp <= 128;
+    if (want == 3 && !can_panel) {
+      delete h;
+      return fail(BNF_ERR_INVALID, "panel pipeline needs a bf16 training handle with depth 2, width 256/512 and <= 128 features");
+    }
+    h->panel = can_panel && (want == 3 || want == 0);   // the default where it applies (C2: 2.71 -> 2.27 ms/step)
+    if (h->panel) h->Bp = align_up(h->B, 256);
     // pipeline 0 (auto): layer kernels with the one-kernel last layer where the width allows;
     // pipeline 1: every layer kernel separate and every activation materialised (validation)
     const bool fl_ok = h->bf16 ? fused_last_supported<bf16_t>(h->W) : fused_last_supported<float>(h->W);
-    h->fuse_last = !cfg->forward_only && !h->fused && want == 0 && fl_ok;
+    h->fuse_last = !cfg->forward_only && !h->fused && !h->panel && want == 0 && fl_ok;
     // its contraction depth is Fp <= 128: cheaper to redo than to write + gather A_0^T
-    h->recompute_a0 = !cfg->forward_only && !h->fused && want == 0 && h->L >= 2 && h->Fp <= 128;
+    h->recompute_a0 = !cfg->forward_only && !h->fused && !h->panel && want == 0 && h->L >= 2 && h->Fp <= 128;
     if (h->fused) {
       h->fused_lds = fused_lds_bytes(h->W, h->Fp, h->es);
       const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / h->fused_lds)));
@@ -931,7 +1022,7 @@ void bnf_destroy(bnf_handle* h) {
     if (h->prof_blocks > 0) {
       fprintf(stderr, "[phase clocks] %s: %d threads/workgroup, mean cycles per workgroup: total %.0f |",
               getenv("BNF_PHASE_PROF"), h->prof_threads, h->prof_gap[0] / h->prof_blocks);
-      for (int k = 1; k < 8; ++k) fprintf(stderr, " m%d %.0f", k, h->prof_gap[k] / h->prof_blocks);
+      for (int k = 1; k < 16; ++k) fprintf(stderr, " m%d %.0f", k, h->prof_gap[k] / h->prof_blocks);
       fprintf(stderr, "\n");
     }
     (void)hipFree(h->prof_buf);
@@ -1058,7 +1149,7 @@ int bnf_forward(bnf_handle* h, const float* theta, int64_t n_members, const floa
                 int64_t n_rows, float* loc, float* aux) {
   if (!h || !h->bound) return fail(BNF_ERR_STATE, "bnf_forward before bnf_bind");
   if (!theta || !Xnew || !loc || n_members < 1 || n_rows < 1) return fail(BNF_ERR_INVALID, "argument");
-  if (h->fused) return fail(BNF_ERR_STATE, "bnf_forward needs a forward_only (or pipeline=1) handle");
+  if (h->fused || h->panel) return fail(BNF_ERR_STATE, "bnf_forward needs a forward_only (or pipeline=1) handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   const int64_t row_chunk = h->Bp, mem_chunk = h->Ev;
   RowSrc rs{};
@@ -1336,6 +1427,8 @@ double bnf_kernel_flops(const bnf_handle* h, const char* name) {
     return 2.0 * Ev * B * W * W;
   if (!strcmp(name, "gemm_fwd_last"))   // last hidden layer + output-layer dot
     return 2.0 * Ev * B * (h->L > 1 ? W : F) * W + 2.0 * Ev * B * W;
+  if (!strcmp(name, "panel_fwd_bwd"))  // forward + backward-data contractions of both layers + output layer
+    return 4.0 * Ev * B * (F * W + W * W) + 2.0 * Ev * B * W;
   if (!strcmp(name, "fused_fwd_bwd"))  // forward + dgrad contractions of every layer + output layer
     return 4.0 * Ev * B * (F * W + (h->L - 1) * W * W) + 6.0 * Ev * B * W;
   return 0.0;

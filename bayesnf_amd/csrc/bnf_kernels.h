@@ -103,8 +103,12 @@ template <typename T>
 __global__ __launch_bounds__(kFeatRows) void k_featurize(
     NetDev nd, RowSrc rs, const float* __restrict__ X, const float* __restrict__ Stab,
     const float* __restrict__ y, const float* __restrict__ scal, int64_t B,
-    T* __restrict__ H0, int64_t h0_batch, T* __restrict__ H0t, int64_t h0t_batch, int32_t ldt,
+    T* __restrict__ H0, int64_t h0_batch, T* __restrict__ H0f, int64_t h0f_batch, int32_t ldt,
     float* __restrict__ ybat, int64_t ybat_batch) {
+  // H0f (optional, 2-byte T): a second copy in MFMA A-fragment-major order for the row-panel
+  // kernel: element (row r, k) at ((r / 32 * Fp / 16 + k / 16) * 64 + (k % 16) / 8 * 32 + r % 32) * 8 + k % 8,
+  // so that the 32-row x 16-deep fragment a wave multiplies is ONE contiguous 1 KiB load (a lane
+  // reading 16 bytes of its own row-major row touches 64 different 64-byte segments per wave).
   extern __shared__ __attribute__((aligned(16))) char fsm[];
   constexpr int kEpc = 16 / Elem<T>::kBytes;
   T* tile = reinterpret_cast<T*>(fsm);
@@ -124,11 +128,7 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
 #pragma unroll
     for (int d = 0; d < BNF_MAX_INPUTS; ++d) u[d] = xr[d] / sc[kScalInput + min(d, nd.D - 1)];
     T* trow = tile + threadIdx.x * pitch;
-    T* hcol = H0t ? H0t + (int64_t)e * h0t_batch + r : nullptr;
-    auto put = [&](int col, float v) {
-      Elem<T>::store(trow + col, v);
-      if (hcol) Elem<T>::store(hcol + (int64_t)col * ldt, v);
-    };
+    auto put = [&](int col, float v) { Elem<T>::store(trow + col, v); };
     for (int g = 0; g < nd.n_groups; ++g) {
       const float sp = sc[kScalGroup + g];
       const int c0 = nd.group_col0[g], nc = nd.group_ncols[g];
@@ -183,6 +183,20 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
       *reinterpret_cast<u32x4*>(dst + (r0 + lr) * nd.Fp + cc * kEpc) =
           *reinterpret_cast<const u32x4*>(tile + lr * pitch + cc * kEpc);
   }
+  if constexpr (sizeof(T) == 2) {
+    if (H0f) {
+      T* df = H0f + (int64_t)e * h0f_batch;
+      const int ks0 = nd.Fp / 16;
+      for (int q = threadIdx.x; q < kFeatRows * cpr; q += kFeatRows) {
+        const int lr = q % kFeatRows, cc = q / kFeatRows;   // rows fastest: 16-byte stores of a fragment are contiguous
+        const int64_t rr = r0 + lr;
+        if (rr < B)
+          *reinterpret_cast<u32x4*>(df + ((((rr >> 5) * ks0 + (cc >> 1)) * 64 + (cc & 1) * 32 + (rr & 31)) << 3)) =
+              *reinterpret_cast<const u32x4*>(tile + lr * pitch + cc * kEpc);
+      }
+    }
+  }
+  (void)ldt;
 }
 
 // ---------------------------------------------------------------------------

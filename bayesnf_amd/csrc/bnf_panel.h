@@ -1,0 +1,710 @@
+// bnf_panel.h -- row-panel forward + backward of a depth-2 BayesNF member in ONE kernel (bf16).
+//
+// A workgroup (8 waves, one per CU: 256 registers per lane) owns a panel of BM batch rows of one
+// ensemble member and carries it through the network and back (reference models.py:212-273,
+// inference.py:558-569 and their autodiff):
+//
+//   A0 = H0 K0        -> H1 = act(gamma0 (A0/sqrt F + b0))                  -> LDS panel + HBM
+//   A1 = H1 K1        -> out = gamma_o (act(A1) k_o/sqrt W + b_o), likelihood, d out
+//                     -> dZ1 = gamma1 (dv k_o/sqrt W) act'(A1)              -> LDS panel + HBM
+//   dH1 = dZ1 K1^T    -> dZ0 = gamma0 dH1/sqrt W act'(A0)  (A0 recomputed)   -> LDS panel + HBM
+//   dH0 = dZ0 K0^T /sqrt F                                                   -> HBM (f32, transposed)
+//
+// What leaves the chip is exactly what the weight-gradient contractions (gemm_tn) and the feature
+// backward kernel read afterwards: H1, dZ1, dZ0 (bf16, row-major) and dH0^T.  It replaces
+// gemm_fwd_l0 + gemm_fwd_last + gemm_dgrad + gemm_dgrad0 of the layer pipeline (and their HBM
+// round trips of H1 / dZ1 / dZ0 as contraction operands: 2.0 GB of the 8.0 GB per C2 step).
+//
+// Geometry (W = 64 WN, WN = 8 or 4): wave w = (row block rb = w / WN, column slab cs = w % WN) owns
+// rows [128 rb, +128) x columns [64 cs, +64) of every BM x W activation of the panel
+// (BM = 128 * 8 / WN): 4 x 2 MFMA 32x32 accumulators = 128 registers.  The A operand of every
+// W-deep contraction is the panel in LDS (row pitch W*2 + 16 bytes: the 16 lanes of a ds_read_b128
+// group hit 16 different 16-byte slots); the B operand -- the member's weights in fragment-major
+// packing, one contiguous 1 KiB wave load per 32 x 16 fragment -- streams L2 -> VGPR through a
+// ring of PD fragments per stream, never touching LDS: each weight fragment is consumed by exactly
+// one wave, and a panel of BM rows re-reads the weights BM/64 times less often than the 64-row
+// panels of gemm_nt<.., EPI_LAST, 1, 8>.  Measured ceilings this is designed against
+// (profiles/r02a_panel_probe.txt): L2-resident streams reach 31 TB/s into VGPRs or LDS alike
+// (51 B/clk/CU), and this contraction loop alone sustains 1.25-1.34 PFLOP/s (50-54 % of the
+// bf16 MFMA peak) against 0.41-0.50 for the LDS-staged K loops of gemm_nt.
+#pragma once
+
+#include "bnf_gemm.h"
+#include "bnf_kernels.h"
+
+namespace bnf {
+
+struct PanelArgs {
+  int32_t F, Fp, B, panels, members;
+  const float* theta;
+  int64_t theta_stride;
+  const float* scal;              // k_member_scalars table (kScalStride per member)
+  int32_t off_bias0, off_bias1, off_bias_out, off_ko, off_ls0, off_ls1, off_os, off_law;
+  int32_t off_lns, off_shape, off_infl, obs;
+  const bf16_t* H0;               // (members, Bp x Fp) features in A-fragment-major order (k_featurize H0f), rows >= B zero
+  const bf16_t* H0rm;             // the same, row-major (Bp, Fp): staged into LDS by the H0L variant
+  int64_t h0_batch;
+  const bf16_t* Wf0;              // fragment-major Bt[n][k] = K0[k][n]   (W/32 x Fp/16 fragments)
+  const bf16_t* Wf1;              //                 Bt[n][k] = K1[k][n]   (W/32 x W/16)
+  const bf16_t* Wb1;              //                 Bt[n][k] = K1[n][k]   (W/32 x W/16)
+  const bf16_t* Wb0;              //                 Bt[n][k] = K0[n][k]   (Fp/32 x W/16)
+  int64_t w0_batch, w1_batch;     // elements between members
+  bf16_t* H1;                     // (members, Bp, W) outputs, row-major
+  bf16_t* dZ1;
+  bf16_t* dZ0;
+  int64_t act_batch;
+  float* dH0t;                    // (members, Fp, ldt) f32
+  int64_t dh0_batch;
+  int32_t ldt;
+  const float* ybat;              // (members, row_batch) targets of the batch rows
+  int64_t row_batch;
+  float* out;                     // (members, out_batch) network output
+  int64_t out_batch;
+  float* grad;
+  int64_t grad_stride;
+  float* loss;                    // loss[(e / S) * loss_stride] += loss_scale * step loss
+  float* loss_raw;
+  int64_t loss_stride;
+  int32_t S;
+  float loss_scale, lik_c;
+  unsigned long long* prof;       // -DBNF_ENABLE_ABLATE builds: per-workgroup phase clocks
+  int32_t ablate;                 // perf experiments only (env BNF_ABLATE)
+};
+
+constexpr int kPanelPD = 4;       // weight fragments in flight per stream
+
+// RT = 32-row tiles per wave (4: one workgroup per CU, 256 registers; 2: two workgroups per CU, 128)
+__host__ __device__ constexpr int panel_rows(int wn, int rt) { return 32 * rt * (8 / wn); }
+// h0l: the feature panel (Fp = 64: BM x 144 bytes) is staged in LDS as well -- fits for W = 512
+__host__ __device__ constexpr int panel_lds_bytes(int wn, int rt, bool h0l) {
+  const int W = 64 * wn, BM = panel_rows(wn, rt), RB = 8 / wn;
+  return BM * (W * 2 + 16) + (BM * wn + BM + 2 * RB * W + 128) * 4 + (h0l ? BM * 144 : 0);
+}
+
+// Makes a lane value opaque to the optimiser at this point: everything derived from it (fragment
+// rows, LDS / global addresses) is recomputed where a phase starts instead of being computed once,
+// kept alive across the contractions (which need all 256 registers) and spilled -- a spill
+// reload is a scratch load, and the s_waitcnt vmcnt(0) it needs also drains the prefetched
+// operands and the panel stores in flight (measured: 16k of an epilogue's 42k cycles).
+__device__ __forceinline__ int opaque_lane(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains
+// vmcnt, i.e. would wait for the panel copies to HBM (128 KiB per workgroup) at every phase change
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// acc[4][2] += P[rows of this wave][0 .. 16 KS) . Bt-fragments (two streams: column tiles nt0, nt0 + 1)
+// A fragments from the LDS panel (next step's issued before this step's MFMAs), B fragments from
+// global memory through a PD-deep register ring per stream.
+// `side(it)` runs once per outer iteration (KS / PD of them) between MFMA groups: the caller
+// spreads the copy of the (static) panel to HBM over the contraction, so that its store issue
+// (~13 B/clk/CU, ~10k cycles per 128 KiB panel when done in one burst) hides under the MFMAs.
+template <int KPITCH_B, int RT, typename Side>
+__device__ __forceinline__ void panel_contract(f32x16 (&acc)[RT][2], const char* prow, const char* wp, int nt0, int KS,
+                                               int lane, Side side) {
+  constexpr int PD = kPanelPD;
+  const char* w0 = wp + (size_t)nt0 * KS * 1024;   // uniform
+  const char* w1 = w0 + (size_t)KS * 1024;
+  const uint32_t loff = (uint32_t)lane * 16u;
+  bf16x8 fb[PD][2];
+#pragma unroll
+  for (int p = 0; p < PD; ++p) {
+    fb[p][0] = *reinterpret_cast<const bf16x8*>(w0 + p * 1024 + loff);
+    fb[p][1] = *reinterpret_cast<const bf16x8*>(w1 + p * 1024 + loff);
+  }
+  auto load_a = [&](bf16x8 (&fa)[RT], int ks) {
+    const int ko = ks * 32;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)   // rows frow + 32 i  (two base registers keep the offsets in 16 bits)
+      fa[i] = *reinterpret_cast<const bf16x8*>(prow + (i >> 1) * 64 * KPITCH_B + (i & 1) * 32 * KPITCH_B + ko);
+  };
+  bf16x8 fa[2][RT];
+  load_a(fa[0], 0);
+#pragma unroll 1
+  for (int ks0 = 0; ks0 < KS; ks0 += PD) {
+    side(ks0 / PD);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+      const int cur = p & 1;
+      load_a(fa[cur ^ 1], min(ks0 + p + 1, KS - 1));
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[p][0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[p][1], acc[i][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int kn = min(ks0 + PD + p, KS - 1);    // (the tail re-reads the last fragment: unused)
+      fb[p][0] = *reinterpret_cast<const bf16x8*>(w0 + (size_t)kn * 1024 + loff);
+      fb[p][1] = *reinterpret_cast<const bf16x8*>(w1 + (size_t)kn * 1024 + loff);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// Layer-0 contraction of one 32-row block x this wave's 64 columns, both operands from global
+// memory, both fragment-major (one contiguous 1 KiB wave load per 32 x 16 fragment).
+// One 32 x 32 output tile at a time (16 accumulator registers: the backward epilogue runs with the
+// 128 dH accumulators live); the operands of FOUR k steps travel together (8 fragments, 32
+// registers): the caller issues the
+// loads of the next group right after the MFMAs that consumed the current one, so that they fly
+// during the block's (long, VALU-only) epilogue instead of being waited for one k step at a time
+// (measured: 16-20k of a panel's 170k cycles were exposed L2 latency with a one-step prefetch).
+struct L0Blk {
+  bf16x8 a[4], b[4];
+};
+__device__ __forceinline__ void l0_load(L0Blk& bk, const char* h0row, const char* w, int ks) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    bk.a[u] = *reinterpret_cast<const bf16x8*>(h0row + (size_t)(ks + u) * 1024);
+    bk.b[u] = *reinterpret_cast<const bf16x8*>(w + (size_t)(ks + u) * 1024);
+  }
+}
+__device__ __forceinline__ void l0_mma(f32x16& a0, const L0Blk& bk) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bk.a[u], bk.b[u], a0, 0, 0, 0);
+}
+
+// H0L (needs Fp = 64 and the LDS room, i.e. W = 512): the layer-0 contractions (forward, and the
+// recomputation of A0 in the backward epilogue) read their A fragments from a feature panel staged
+// in LDS and keep the wave's eight weight fragments in registers for the whole phase.  Without it
+// every 32 x 32 tile re-fetches 8 KiB of operands through the vector memory path -- 768 KiB per
+// panel over both passes, as much as the two W x W contractions stream -- and those phases were
+// bound by that stream (~10k of a panel's 160k cycles each).
+template <int WN, int RT, bool H0L>
+__global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const PanelArgs a) {
+  constexpr int W = 64 * WN, RB = 8 / WN, WR = 32 * RT, BM = WR * RB;   // WR = rows per wave
+  constexpr int kPitchE = W + 8;            // panel row pitch, elements (16 bytes of padding)
+  constexpr int kPitchB = kPitchE * 2;
+  constexpr int KS1 = W / 16;
+  constexpr int kCpr = W / 8;               // 16-byte chunks per row
+  constexpr int kHalves = (RT + 1) / 2;     // row dots go through a 64-row scratch image per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
+  float* xs = reinterpret_cast<float*>(smem + BM * kPitchB);
+  float* s_part = xs;                       // [BM][WN] row-dot partials
+  float* s_dv = s_part + BM * WN;           // [BM]
+  float* s_col = s_dv + BM;                 // [2][RB][W] column sums
+  float* s_sc = s_col + 2 * RB * W;         // scalars
+  constexpr int kH0Pitch = 144;             // Fp = 64: 128 bytes + 16 of padding
+  const char* h0s = reinterpret_cast<const char*>(s_sc + 128);   // [BM][144 B] feature panel (H0L)
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rb = wave / WN, cs = wave % WN;
+  const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
+  const int e = (int)(item / (uint32_t)a.panels), pn = (int)(item % (uint32_t)a.panels);
+  const int m0 = pn * BM;                   // first batch row of the panel
+  const int rbase = rb * WR, cbase = cs * 64;
+  const int KS0 = a.Fp / 16;
+
+  const float* th = a.theta + (int64_t)e * a.theta_stride;
+  const float* sc = a.scal + (int64_t)e * kScalStride;
+  const float gamma0 = sc[0], gamma1 = sc[1], alpha = sc[BNF_MAX_LAYERS];
+  const float inv_sw = 1.0f / sqrtf((float)W), inv_sf = 1.0f / sqrtf((float)a.F);
+  float* gr = a.grad + (int64_t)e * a.grad_stride;
+  // per-member scalars of the row phase and of the serial tails, fetched and transformed now (uniform):
+  // a lone thread reaching for them later pays a full memory latency with the workgroup waiting
+  const float gam_o = sc[BNF_MAX_LAYERS + 1], bias_o = th[a.off_bias_out];
+  const float dgam_o = sigmoidf(th[a.off_os]);
+  const float dgam1 = sigmoidf(th[a.off_ls1]) / gamma1, dgam0 = sigmoidf(th[a.off_ls0]) / gamma0;
+  const float lns = th[a.off_lns];
+  const float e_lns = expf(lns), sigma = 0.01f + e_lns, inv_sigma = 1.0f / sigma;
+  const float ll_const = -logf(sigma) - 0.918938533204672742f;
+  // the row phase's target value, fetched now (one thread per row; rows >= B read nothing)
+  const float y_row = (tid < BM && m0 + tid < a.B) ? a.ybat[(int64_t)e * a.row_batch + m0 + tid] : 0.f;
+
+  // fragment-major features: the fragment of (32-row block, k step) is 1 KiB, blocks are Fp/16 KiB apart
+  const char* h0p = reinterpret_cast<const char*>(a.H0 + (int64_t)e * a.h0_batch + (int64_t)m0 * a.Fp) +
+                    (size_t)(rbase / 32) * KS0 * 1024;                     // uniform; + i blocks, + lane * 16
+  const size_t h0blk = (size_t)KS0 * 1024;
+  const char* wf0 = reinterpret_cast<const char*>(a.Wf0 + (int64_t)e * a.w0_batch);
+  const char* wf1 = reinterpret_cast<const char*>(a.Wf1 + (int64_t)e * a.w1_batch);
+  const char* wb1 = reinterpret_cast<const char*>(a.Wb1 + (int64_t)e * a.w1_batch);
+  const char* wb0 = reinterpret_cast<const char*>(a.Wb0 + (int64_t)e * a.w0_batch);
+  const char* w00u = wf0 + (size_t)(2 * cs) * KS0 * 1024;                  // layer-0 fragment streams (uniform)
+  // lane-dependent values, re-derived at the start of every phase (see opaque_lane)
+  struct LaneCtx {
+    int lane, frow, kg;
+    const char *h0row, *w00, *w01, *prow;
+  };
+  auto lane_ctx = [&]() {
+    LaneCtx c;
+    c.lane = opaque_lane(tid) & 63;
+    c.frow = c.lane & 31;
+    c.kg = c.lane >> 5;
+    c.h0row = h0p + c.lane * 16;
+    c.w00 = w00u + c.lane * 16;
+    c.w01 = c.w00 + (size_t)KS0 * 1024;
+    c.prow = smem + (rbase + c.frow) * kPitchB + c.kg * 16;   // A fragments of this lane
+    return c;
+  };
+
+  // Copy of this wave's own 32-row x 64-column block (row block i) of the panel to the row-major
+  // (Bp, W) array `dst`, issued right after the wave has written the block: only its own LDS
+  // writes must have landed (lgkmcnt), no workgroup barrier, and the stores (128-byte runs, 1 KiB
+  // per wave instruction) issue underneath the VALU work of the next block instead of in a
+  // 10k-cycle burst per panel (a CU issues stores at ~13 B/clk).
+  auto block_to_global = [&](const LaneCtx& L, bf16_t* dst, int i) {
+    bf16_t* d = dst + (int64_t)e * a.act_batch + (int64_t)(m0 + rbase + i * 32) * W + cbase;
+    const bf16_t* sp = tile + (rbase + i * 32) * kPitchE + cbase;
+    u32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = L.lane + 64 * u;
+      v[u] = *reinterpret_cast<const u32x4*>(sp + (idx >> 3) * kPitchE + (idx & 7) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = L.lane + 64 * u;
+      *reinterpret_cast<u32x4*>(d + (int64_t)(idx >> 3) * W + (idx & 7) * 8) = v[u];
+    }
+  };
+
+  if constexpr (H0L) {   // feature panel -> LDS (row-major source, 16-byte chunks, 8 per row)
+    const bf16_t* src = a.H0rm + (int64_t)e * a.h0_batch + (int64_t)m0 * 64;
+#pragma unroll
+    for (int c = 0; c < (BM * 8) / 512; ++c) {
+      const int q = tid + c * 512;
+      *reinterpret_cast<u32x4*>(const_cast<char*>(h0s) + (q >> 3) * kH0Pitch + (q & 7) * 16) =
+          *reinterpret_cast<const u32x4*>(src + (int64_t)(q >> 3) * 64 + (q & 7) * 8);
+    }
+  }
+  BNF_MARK(a, 0);
+  f32x16 acc[RT][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  // Layer-0 pre-activations of the 32 x 32 tile (row block i, column half j) of this wave,
+  // a0 = H0 K0 (un-scaled).  `blk` enters holding the first four k steps of tile t = 2 i + j and
+  // leaves holding those of tile t + 1 (in flight during the caller's epilogue).
+  L0Blk blk;
+  auto l0_tile_src = [&](const LaneCtx& L, int t, const char** hr, const char** w) {
+    const int tt = min(t, 2 * RT - 1);
+    *hr = L.h0row + (size_t)(tt >> 1) * h0blk;
+    *w = (tt & 1) ? L.w01 : L.w00;
+  };
+  bf16x8 bres[H0L ? 2 : 1][4];     // H0L: this wave's layer-0 weight fragments [column half][k step]
+  auto l0_weights = [&](const LaneCtx& L) {
+    if constexpr (H0L) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bres[0][u] = *reinterpret_cast<const bf16x8*>(L.w00 + (size_t)u * 1024);
+        bres[1][u] = *reinterpret_cast<const bf16x8*>(L.w01 + (size_t)u * 1024);
+      }
+    } else {
+      l0_load(blk, L.h0row, L.w00, 0);
+    }
+  };
+  auto l0_tile = [&](const LaneCtx& L, f32x16& a0, int i, int j) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a0[r] = 0.f;
+    if constexpr (H0L) {
+      const char* ap = h0s + (rbase + i * 32 + L.frow) * kH0Pitch + L.kg * 16;
+      bf16x8 fa[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fa[u] = *reinterpret_cast<const bf16x8*>(ap + u * 32);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u], bres[j ? (H0L ? 1 : 0) : 0][u], a0, 0, 0, 0);
+      return;
+    }
+    const int t = 2 * i + j;
+    const char *hr, *w, *hn, *wn;
+    l0_tile_src(L, t, &hr, &w);
+    l0_tile_src(L, t + 1, &hn, &wn);
+#pragma unroll 1
+    for (int ks = 0; ks < KS0; ks += 4) {
+      l0_mma(a0, blk);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 4 < KS0) l0_load(blk, hr, w, ks + 4);
+      else l0_load(blk, hn, wn, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // =============================== layer 0 forward -> H1 panel ===============================
+  {
+    const LaneCtx L = lane_ctx();
+    const int frow = L.frow, kg = L.kg;
+    const float gs = gamma0 * inv_sf;
+    float gb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) gb[j] = gamma0 * th[a.off_bias0 + cbase + j * 32 + frow];
+    l0_weights(L);
+    if constexpr (H0L) lds_barrier();     // the staged feature panel is complete
+#pragma unroll 1
+    for (int i = 0; i < RT; ++i) {
+      f32x16 a0b[2];
+      if constexpr (H0L) {   // both tiles' MFMAs first: the second chain runs under the first tile's epilogue
+        l0_tile(L, a0b[0], i, 0);
+        l0_tile(L, a0b[1], i, 1);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16& a0 = a0b[j];
+        if constexpr (!H0L) {
+          if (!BNF_ABL(a, 1)) l0_tile(L, a0, i, j);
+          else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a0[r] = 0.25f;
+          }
+        }
+        const int lc = cbase + j * 32 + frow;
+        const float gbj = j ? gb[1] : gb[0];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int lr = rbase + i * 32 + 8 * rg + 4 * kg;
+#pragma unroll
+          for (int q = 0; q < 4; q += 2) {
+            const f32x2 av = f32x2{a0[rg * 4 + q], a0[rg * 4 + q + 1]} * gs + gbj;
+            const f32x2 h = BNF_ABL(a, 2) ? av : act_fwd2(av, alpha);
+            if (!BNF_ABL(a, 4)) store_pair(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, h.x, h.y);
+          }
+        }
+      }
+      block_to_global(L, a.H1, i);
+    }
+  }
+  BNF_MARK(a, 1);
+  lds_barrier();
+  BNF_MARK(a, 2);
+
+  // =============================== layer 1 forward ============================================
+  zero_acc();
+  {
+    const LaneCtx L = lane_ctx();
+    panel_contract<kPitchB, RT>(acc, L.prow, wf1, 2 * cs, KS1, L.lane, [](int) {});
+  }
+  BNF_MARK(a, 3);
+  lds_barrier();     // every wave is done reading H1: the panel doubles as row-dot scratch below
+
+  // ---- A1 = gamma1 (acc / sqrt W + b1) kept in the accumulators; row dots act(A1) . k_o ----
+  {
+    const LaneCtx L = lane_ctx();
+    const int lane = L.lane, frow = L.frow, kg = L.kg;
+    const float gs = gamma1 * inv_sw;
+    float gb[2], kov[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      gb[j] = gamma1 * th[a.off_bias1 + cbase + j * 32 + frow];
+      kov[j] = th[a.off_ko + cbase + j * 32 + frow];
+    }
+    float* s_dot = reinterpret_cast<float*>(smem) + wave * (64 * kRowDotPitch);   // [64 rows][32 lanes]
+#pragma unroll
+    for (int half = 0; half < kHalves; ++half) {   // (unrolled: a runtime index would push acc to scratch)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = half * 2 + ii;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          float pd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+              const f32x2 raw = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
+              const f32x2 av = raw * gs + gb[j];
+              acc[i][j][rg * 4 + q] = av.x;
+              acc[i][j][rg * 4 + q + 1] = av.y;
+              const f32x2 hk = act_fwd2(av, alpha) * kov[j];
+              pd[q] += hk.x;
+              pd[q + 1] += hk.y;
+            }
+          }
+          float* dst = s_dot + (ii * 32 + 8 * rg + 4 * kg) * kRowDotPitch + frow;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dst[q * kRowDotPitch] = pd[q];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const f32x4* rp = reinterpret_cast<const f32x4*>(s_dot + lane * kRowDotPitch);
+      f32x4 t4 = rp[0];
+#pragma unroll
+      for (int c = 1; c < 8; ++c) t4 += rp[c];
+      s_part[(rbase + half * 64 + lane) * WN + cs] = (t4.x + t4.y) + (t4.z + t4.w);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  BNF_MARK(a, 4);
+  lds_barrier();
+  // ---- one thread per row: output, likelihood, d out (models.py:269-273,157-191) -----------
+  {
+    float ll = 0.f, s_doutv = 0.f, s_dvsum = 0.f, s_par = 0.f, s_infl = 0.f;
+    if (tid < BM) {
+      const int m = m0 + tid;
+      float vsum = 0.f;
+#pragma unroll
+      for (int c = 0; c < WN; ++c) vsum += s_part[tid * WN + c];
+      float dvv = 0.f;
+      if (m < a.B) {
+        const float v = vsum * inv_sw + bias_o;
+        const float outv = gam_o * v;
+        a.out[(int64_t)e * a.out_batch + m] = outv;
+        RowLoss rl;
+        if (a.obs == BNF_OBS_NORMAL) {   // row_loss_eval's NORMAL branch on the precomputed member scalars
+          const float z = (y_row - outv) * inv_sigma;
+          rl.ll = -0.5f * z * z + ll_const;
+          rl.dout = -a.lik_c * z * inv_sigma;
+          rl.d_par = -a.lik_c * (z * z - 1.0f) * inv_sigma * e_lns;
+          rl.d_infl = 0.f;
+        } else {
+          rl = row_loss_eval(a.obs, th, a.off_lns, a.off_shape, a.off_infl, y_row, outv, a.lik_c);
+        }
+        ll = rl.ll; s_par = rl.d_par; s_infl = rl.d_infl;
+        s_doutv = rl.dout * v;
+        dvv = gam_o * rl.dout;
+        s_dvsum = dvv;
+      }
+      s_dv[tid] = dvv;
+      const float t0 = wave_sum(ll), t1 = wave_sum(s_doutv), t2 = wave_sum(s_dvsum), t3 = wave_sum(s_par),
+                  t4 = wave_sum(s_infl);
+      if ((tid & 63) == 0) {
+        float* q = s_sc + wave * 5;
+        q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; q[4] = t4;
+      }
+    }
+  }
+  lds_barrier();
+  BNF_MARK(a, 5);
+  if (tid == 0) {
+    float u[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w2 = 0; w2 < (BM + 63) / 64; ++w2)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) u[i] += s_sc[w2 * 5 + i];
+    const float step_loss = -a.lik_c * u[0];
+    atomicAdd(&a.loss[(int64_t)(e / a.S) * a.loss_stride], a.loss_scale * step_loss);
+    if (a.loss_raw) atomicAdd(&a.loss_raw[e], step_loss);
+    atomicAdd(&gr[a.off_os], dgam_o * u[1]);
+    atomicAdd(&gr[a.off_bias_out], u[2]);
+    atomicAdd(&gr[a.obs == BNF_OBS_NORMAL ? a.off_lns : a.off_shape], u[3]);
+    if (a.obs == BNF_OBS_ZINB) atomicAdd(&gr[a.off_infl], u[4]);
+  }
+  // ---- dZ1 = gamma1 (dv k_o / sqrt W) act'(A1) -> panel; column sums and scalar gradients ----
+  {
+    const LaneCtx L = lane_ctx();
+    const int lane = L.lane, frow = L.frow, kg = L.kg;
+    f32x2 sa[2], sg[2], cp[2], ck[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) sa[j] = sg[j] = cp[j] = ck[j] = f32x2{0.f, 0.f};
+    const float kvn[2] = {th[a.off_ko + cbase + frow] * inv_sw, th[a.off_ko + cbase + 32 + frow] * inv_sw};
+    const float gk[2] = {gamma1 * kvn[0], gamma1 * kvn[1]};
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int lr = rbase + i * 32 + 8 * rg + 4 * kg;
+        const f32x4 dv4 = *reinterpret_cast<const f32x4*>(s_dv + lr);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int lc = cbase + j * 32 + frow;
+#pragma unroll
+          for (int q = 0; q < 4; q += 2) {
+            f32x2 av = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
+            asm volatile("" : "+v"(av));
+            const f32x2 dv2 = {dv4[q], dv4[q + 1]};
+            const ActOut2 o = act_eval2(av, alpha);
+            const f32x2 p = dv2 * o.dact;
+            sa[j] += dv2 * o.ediff;
+            sg[j] += p * av;
+            cp[j] += p;
+            ck[j] += o.h * dv2;
+            const f32x2 z = gk[j] * p;
+            store_pair(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, z.x, z.y);
+          }
+        }
+        asm volatile("" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sg[0]), "+v"(sg[1]), "+v"(cp[0]), "+v"(cp[1]),
+                     "+v"(ck[0]), "+v"(ck[1]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (rg == 3) block_to_global(L, a.dZ1, i);
+      }
+    float wsa = kvn[0] * (sa[0].x + sa[0].y) + kvn[1] * (sa[1].x + sa[1].y);
+    float wsg = kvn[0] * (sg[0].x + sg[0].y) + kvn[1] * (sg[1].x + sg[1].y);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float b = gk[j] * (cp[j].x + cp[j].y), k = ck[j].x + ck[j].y;
+      b += __shfl_xor(b, 32, 64);
+      k += __shfl_xor(k, 32, 64);
+      if (lane < 32) {
+        s_col[rb * W + cbase + j * 32 + lane] = b;
+        s_col[(RB + rb) * W + cbase + j * 32 + lane] = k;
+      }
+    }
+    wsa = wave_sum(wsa);
+    wsg = wave_sum(wsg);
+    if (lane == 0) {
+      s_sc[32 + wave * 2] = wsa;
+      s_sc[33 + wave * 2] = wsg;
+    }
+  }
+  BNF_MARK(a, 6);
+  lds_barrier();
+  for (int c = tid; c < W; c += 512) {
+    float b = 0.f, k = 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      b += s_col[r * W + c];
+      k += s_col[(RB + r) * W + c];
+    }
+    atomicAdd(&gr[a.off_bias1 + c], b);
+    atomicAdd(&gr[a.off_ko + c], k * inv_sw);
+  }
+  float ta1 = 0.f;   // d alpha (layer 1 share), kept by thread 0 until layer 0's share is known
+  if (tid == 0) {
+    float tg = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 8; ++w2) {
+      ta1 += s_sc[32 + w2 * 2];
+      tg += s_sc[33 + w2 * 2];
+    }
+    atomicAdd(&gr[a.off_ls1], dgam1 * tg);
+  }
+
+  // =============================== dH1 = dZ1 K1^T ============================================
+  BNF_MARK(a, 7);
+  zero_acc();
+  {
+    const LaneCtx L = lane_ctx();
+    panel_contract<kPitchB, RT>(acc, L.prow, wb1, 2 * cs, KS1, L.lane, [](int) {});
+  }
+  BNF_MARK(a, 8);
+  const LaneCtx L2 = lane_ctx();
+  l0_weights(L2);                         // first operands of the A0 recomputation, in flight across the barrier
+  lds_barrier();     // every wave is done reading dZ1: the panel is overwritten with dZ0 (and s_col / s_sc reused)
+
+  // ---- dZ0 = gamma0 (dH1 / sqrt W) act'(A0), A0 recomputed per 32-row block ----------------
+  {
+    const LaneCtx& L = L2;
+    const int lane = L.lane, frow = L.frow, kg = L.kg;
+    const float gs0 = gamma0 * inv_sf;
+    float gb0[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) gb0[j] = gamma0 * th[a.off_bias0 + cbase + j * 32 + frow];
+    f32x2 sa2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, cs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    f32x16 a0b[2];
+    if constexpr (H0L) l0_tile(L, a0b[0], 0, 0);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        constexpr int kDummy = 0;
+        (void)kDummy;
+        const int t = 2 * i + j;
+        f32x16& a0 = a0b[t & 1];
+        if constexpr (H0L) {   // the next tile's MFMA chain runs under this tile's epilogue
+          if (t + 1 < 2 * RT) l0_tile(L, a0b[(t + 1) & 1], (t + 1) >> 1, (t + 1) & 1);
+        } else {
+          if (!BNF_ABL(a, 1)) l0_tile(L, a0, i, j);
+          else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a0[r] = 0.25f;
+          }
+        }
+        const int lc = cbase + j * 32 + frow;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int lr = rbase + i * 32 + 8 * rg + 4 * kg;
+#pragma unroll
+          for (int q = 0; q < 4; q += 2) {
+            const f32x2 dh = f32x2{acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]} * inv_sw;
+            const f32x2 a2 = f32x2{a0[rg * 4 + q], a0[rg * 4 + q + 1]} * gs0 + gb0[j];
+            ActOut2 o;
+            if (BNF_ABL(a, 2)) { o.h = a2; o.dact = f32x2{1.f, 1.f}; o.ediff = a2; }
+            else o = act_eval2(a2, alpha);
+            sa2 += dh * o.ediff;
+            const f32x2 da = dh * o.dact;
+            sg2 += da * a2;
+            const f32x2 z = gamma0 * da;
+            cs2[j] += z;
+            if (!BNF_ABL(a, 4)) store_pair(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, z.x, z.y);
+          }
+          asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(cs2[0]), "+v"(cs2[1]));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      block_to_global(L, a.dZ0, i);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float c = cs2[j].x + cs2[j].y;
+      c += __shfl_xor(c, 32, 64);
+      if (lane < 32) s_col[rb * W + cbase + j * 32 + lane] = c;
+    }
+    const float sa = wave_sum(sa2.x + sa2.y), sg = wave_sum(sg2.x + sg2.y);
+    if (lane == 0) {
+      s_sc[32 + wave * 2] = sa;
+      s_sc[33 + wave * 2] = sg;
+    }
+  }
+  // =============================== dH0^T = (dZ0 K0^T / sqrt F)^T ==============================
+  // Output tiles of 32 x 32 over the waves.  All W/16 weight fragments of a tile are requested
+  // at once -- those of the wave's first tile BEFORE the barrier that completes the dZ0 panel --
+  // and the contraction runs as two independent accumulator chains.
+  {
+    const LaneCtx L = lane_ctx();
+    const int lane = L.lane, frow = L.frow, kg = L.kg;
+    const int ct = a.Fp / 32;                     // column tiles of dH0
+    const int n_t = (BM / 32) * ct;
+    float* dh0 = a.dH0t + (int64_t)e * a.dh0_batch;
+    bf16x8 fb[KS1];
+    auto load_b = [&](int t) {
+      const char* bp = wb0 + (size_t)(t % ct) * KS1 * 1024 + lane * 16;
+#pragma unroll
+      for (int u = 0; u < KS1; ++u) fb[u] = *reinterpret_cast<const bf16x8*>(bp + (size_t)u * 1024);
+    };
+    if (wave < n_t) load_b(wave);
+    BNF_MARK(a, 9);
+    lds_barrier();
+    for (int t = wave; t < n_t; t += 8) {
+      const int mi = t / ct, ni = t - mi * ct;
+      if (t != wave) load_b(t);
+      const char* ap = smem + (mi * 32 + frow) * kPitchB + kg * 16;
+      f32x16 c0, c1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < KS1; u += 2) {
+        const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(ap + u * 32);
+        const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(ap + (u + 1) * 32);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb[u], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb[u + 1], c1, 0, 0, 0);
+      }
+      float* col_ptr = dh0 + (int64_t)(ni * 32 + frow) * a.ldt + m0 + mi * 32 + 4 * kg;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+        store4(col_ptr + 8 * rg, (c0[rg * 4] + c1[rg * 4]) * inv_sf, (c0[rg * 4 + 1] + c1[rg * 4 + 1]) * inv_sf,
+               (c0[rg * 4 + 2] + c1[rg * 4 + 2]) * inv_sf, (c0[rg * 4 + 3] + c1[rg * 4 + 3]) * inv_sf);
+    }
+  }
+  BNF_MARK(a, 10);
+  for (int c = tid; c < W; c += 512) {
+    float b = 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) b += s_col[r * W + c];
+    atomicAdd(&gr[a.off_bias0 + c], b);
+  }
+  if (tid == 0) {
+    float ta = ta1, tg = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 8; ++w2) {
+      ta += s_sc[32 + w2 * 2];
+      tg += s_sc[33 + w2 * 2];
+    }
+    atomicAdd(&gr[a.off_law], alpha * (1.f - alpha) * ta);
+    atomicAdd(&gr[a.off_ls0], dgam0 * tg);
+  }
+  BNF_MARK(a, 11);
+}
+
+}  // namespace bnf

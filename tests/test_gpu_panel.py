@@ -1,0 +1,103 @@
+"""The row-panel forward + backward kernel (pipeline 'panel': bf16, depth 2, width 256 / 512;
+bayesnf_amd/csrc/bnf_panel.h) against the oracle and against the layer pipeline in the same
+arithmetic.  bf16 contractions: statistical bars vs the float64 oracle (loss 5e-3, gradient leaves
+6e-2 of the leaf's max); against the bf16 layer pipeline -- same operand rounding, different
+accumulation order and an un-rounded recomputed A_0 -- loss 1e-3 and leaves 2e-2."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bnf_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(net, X, y, **kw):
+  from bayesnf_amd.engine import Engine
+  return Engine(net, X=X, y=y, **kw)
+
+
+def _leaf_errs(model, g, ref):
+  return util.per_leaf_rel_err(model, g, ref)
+
+
+@pytest.mark.parametrize('width,n_rows,obs', [(256, 300, 'NORMAL'), (512, 300, 'NORMAL'), (512, 1000, 'NORMAL'),
+                                              (256, 700, 'NB'), (512, 260, 'ZINB')])
+def test_panel_step_vs_oracle_and_layer_pipeline(width, n_rows, obs):
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=2, observation_model=obs)
+  E = 3
+  theta = util.random_theta(model, E, scale=0.3)
+  res = {}
+  for pipe in ('panel', 'layers'):
+    eng = _engine(net, X, y, members=E, compute_dtype='bf16', pipeline=pipe)
+    eng.set_params(theta)
+    res[pipe] = eng.debug_loss_and_grad()
+    if pipe == 'panel':
+      out_d = eng.debug_activation(200)
+      H1 = eng.debug_activation(1)
+      dZ1, dZ0 = eng.debug_activation(301), eng.debug_activation(300)
+    else:
+      H1_l, dZ1_l, dZ0_l = eng.debug_activation(1), eng.debug_activation(301), eng.debug_activation(300)
+    eng.close()
+  loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
+  out_o, ch = O.forward(model, theta, X, keep=True)
+  # activations written for the weight-gradient contractions
+  assert util.rel_err(H1, ch['Hs'][1]) < 2e-2
+  assert util.rel_err(H1, H1_l) < 1e-2
+  assert util.rel_err(dZ1, dZ1_l) < 3e-2 and util.rel_err(dZ0, dZ0_l) < 3e-2
+  assert util.rel_err(out_d, out_o) < 3e-2
+  loss_p, g_p = res['panel']
+  loss_l, g_l = res['layers']
+  np.testing.assert_allclose(loss_p, loss_o, rtol=5e-3)
+  np.testing.assert_allclose(loss_p, loss_l, rtol=1e-3)
+  bad = {k: v for k, v in _leaf_errs(model, g_p, g_o).items() if v > 6e-2}
+  assert not bad, ('vs oracle', bad)
+  bad = {k: v for k, v in _leaf_errs(model, g_p, g_l).items() if v > 2e-2}
+  assert not bad, ('vs layers', bad)
+
+
+def test_panel_minibatch_and_training_tracks_fp32():
+  n_rows, B, E = 1500, 600, 4
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=256, depth=2)
+  out = {}
+  for name, kw in [('panel', dict(compute_dtype='bf16', pipeline='panel')), ('fp32', dict(compute_dtype='fp32'))]:
+    eng = _engine(net, X, y, members=E, batch=B, seed=5, learning_rate=0.005, **kw)
+    eng.init_params(0.3)
+    losses = eng.train(0, 6)
+    torch.cuda.synchronize()
+    out[name] = (losses.cpu().numpy(), eng.get_params())
+    eng.close()
+  lp, l32 = out['panel'][0], out['fp32'][0]
+  assert np.all(np.isfinite(lp)) and np.all(lp[:, -1] < lp[:, 0])
+  np.testing.assert_allclose(lp, l32, rtol=2e-2)
+  assert np.abs(out['panel'][1] - out['fp32'][1]).max() < 0.05
+
+
+def test_panel_vi_step():
+  n_rows, E, S = 400, 2, 3
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=256, depth=2)
+  res = {}
+  for pipe in ('panel', 'layers'):
+    eng = _engine(net, X, y, mode='vi', members=E, vi_samples=S, kl_weight=0.2, seed=3, learning_rate=0.01,
+                  compute_dtype='bf16', pipeline=pipe)
+    eng.init_params(0.0)
+    res[pipe] = eng.debug_loss_and_grad(0, 0)
+    eng.close()
+  np.testing.assert_allclose(res['panel'][0], res['layers'][0], rtol=2e-3)
+  for k in (0, 1):
+    bad = {n: v for n, v in _leaf_errs(model, res['panel'][1][k], res['layers'][1][k]).items() if v > 3e-2}
+    assert not bad, (k, bad)
+
+
+def test_panel_repeated_step_is_reproducible():
+  net, model, X, y = util.make_problem(n_rows=2000, width=512, depth=2)
+  eng = _engine(net, X, y, members=4, seed=1, compute_dtype='bf16', pipeline='panel')
+  eng.init_params(0.2)
+  loss0, g0 = eng.debug_loss_and_grad()
+  scale = np.abs(g0).max(axis=1, keepdims=True)
+  for _ in range(8):
+    loss, g = eng.debug_loss_and_grad()
+    assert np.abs(loss - loss0).max() <= 1e-5 * np.abs(loss0).max()
+    assert (np.abs(g - g0) / scale).max() < 1e-4
+  eng.close()
