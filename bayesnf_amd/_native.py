@@ -30,7 +30,7 @@ EXPORTS = (
     'bnf_normal_mixture_quantiles', 'bnf_count_mixture_quantiles', 'bnf_debug_loss_and_grad',
     'bnf_debug_row_index', 'bnf_debug_vi_eps', 'bnf_debug_activation',
     'bnf_debug_gemm_nt', 'bnf_debug_gemm_tn', 'bnf_profile_enable', 'bnf_profile_read',
-    'bnf_kernel_flops')
+    'bnf_kernel_flops', 'bnf_comm_unique_id', 'bnf_comm_create', 'bnf_allgather', 'bnf_comm_destroy')
 
 
 class BnfConfig(C.Structure):
@@ -102,6 +102,11 @@ def load():
   lib.bnf_bind.argtypes = [vp, vp, vp, vp, vp, vp, vp]
   lib.bnf_init_params.argtypes = [vp, C.c_float]
   lib.bnf_train.argtypes = [vp, i64, i64, f32p]
+  lib.bnf_comm_unique_id.argtypes = [vp]
+  lib.bnf_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+  lib.bnf_allgather.argtypes = [vp, vp, vp, C.c_size_t, vp]
+  lib.bnf_comm_destroy.argtypes = [vp]
+  lib.bnf_comm_destroy.restype = None
   lib.bnf_vi_posterior_draws.argtypes = [vp, i32, f32p]
   lib.bnf_forward.argtypes = [vp, vp, i64, vp, i64, vp, vp]
   lib.bnf_normal_mixture_quantiles.argtypes = [
@@ -139,6 +144,37 @@ def check(rc: int, what: str):
   if rc == -1:
     raise ValueError(msg)
   raise RuntimeError(msg)
+
+
+_comm_cache = {}
+
+
+def allgather(send, recv, world: int, rank: int):
+  """RCCL all-gather through the engine library's own entry point (include/bnf.h:
+  bnf_allgather): `send` (…) and `recv` (world, …) are contiguous device tensors.  The
+  communicator is created once per (world, rank, device): rank 0 makes the id, the existing
+  torch.distributed process group only carries those 128 bytes to the other ranks."""
+  import torch
+  lib = load()
+  dev = send.device.index
+  key = (world, rank, dev)
+  if key not in _comm_cache:
+    ident = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+      buf = (C.c_char * 128)()
+      check(lib.bnf_comm_unique_id(buf), 'bnf_comm_unique_id')
+      ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    if world > 1:
+      carrier = ident.to(send.device) if torch.distributed.get_backend() == 'nccl' else ident
+      torch.distributed.broadcast(carrier, src=0)
+      ident = carrier.cpu()
+    comm = C.c_void_p()
+    raw = (C.c_char * 128).from_buffer_copy(bytes(ident.numpy().tobytes()))
+    check(lib.bnf_comm_create(raw, world, rank, dev, C.byref(comm)), 'bnf_comm_create')
+    _comm_cache[key] = comm
+  stream = torch.cuda.current_stream(send.device).cuda_stream
+  check(lib.bnf_allgather(_comm_cache[key], C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
+                          C.c_size_t(send.numel() * send.element_size()), C.c_void_p(stream)), 'bnf_allgather')
 
 
 def seed_to_u64(seed) -> int:

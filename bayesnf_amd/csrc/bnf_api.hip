@@ -13,6 +13,8 @@
 // are the reparameterised samples, bracketed by k_vi_sample / k_vi_adam.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1416,6 +1418,86 @@ int bnf_profile_read(bnf_handle* h, int32_t* n, const char** names, double* avg_
   }
   *n = used;
   return BNF_OK;
+}
+
+// ---- posterior gather: RCCL all-gather behind the C ABI (librccl dlopen'ed on first use) ----
+namespace {
+struct RcclId { char internal[BNF_COMM_ID_BYTES]; };   // ncclUniqueId (rccl.h: 128 opaque bytes)
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load() {
+  if (g_rccl.lib) return BNF_OK;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* lib = nullptr;
+  for (const char* n : names)
+    if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!lib) return fail(BNF_ERR_STATE, "cannot dlopen librccl.so: %s", dlerror());
+  g_rccl.GetUniqueId = (int (*)(RcclId*))dlsym(lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(lib, "ncclCommInitRank");
+  g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
+  g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
+    return fail(BNF_ERR_STATE, "librccl.so lacks an expected nccl* symbol");
+  g_rccl.lib = lib;
+  return BNF_OK;
+}
+int rccl_fail(const char* what, int rc) {
+  return fail(BNF_ERR_HIP, "%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "rccl error");
+}
+}  // namespace
+
+struct bnf_comm {
+  void* comm = nullptr;
+  int32_t world = 0, rank = 0, device = 0;
+};
+
+int bnf_comm_unique_id(void* id) {
+  if (!id) return fail(BNF_ERR_INVALID, "null");
+  if (int rc = rccl_load()) return rc;
+  RcclId u;
+  if (int rc = g_rccl.GetUniqueId(&u)) return rccl_fail("ncclGetUniqueId", rc);
+  memcpy(id, u.internal, BNF_COMM_ID_BYTES);
+  return BNF_OK;
+}
+
+int bnf_comm_create(const void* id, int32_t world, int32_t rank, int32_t device, bnf_comm** out) {
+  if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail(BNF_ERR_INVALID, "argument");
+  *out = nullptr;
+  if (int rc = rccl_load()) return rc;
+  HIPCHK(hipSetDevice(device));
+  RcclId u;
+  memcpy(u.internal, id, BNF_COMM_ID_BYTES);
+  bnf_comm* c = new bnf_comm();
+  c->world = world; c->rank = rank; c->device = device;
+  if (int rc = g_rccl.CommInitRank(&c->comm, world, u, rank)) {
+    delete c;
+    return rccl_fail("ncclCommInitRank", rc);
+  }
+  *out = c;
+  return BNF_OK;
+}
+
+int bnf_allgather(bnf_comm* c, const void* send, void* recv, size_t bytes_per_rank, void* stream) {
+  if (!c || !send || !recv) return fail(BNF_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(c->device));
+  // ncclChar = 0: byte count is dtype-agnostic
+  if (int rc = g_rccl.AllGather(send, recv, bytes_per_rank, 0, c->comm, (hipStream_t)stream))
+    return rccl_fail("ncclAllGather", rc);
+  return BNF_OK;
+}
+
+void bnf_comm_destroy(bnf_comm* c) {
+  if (!c) return;
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  delete c;
 }
 
 double bnf_kernel_flops(const bnf_handle* h, const char* name) {

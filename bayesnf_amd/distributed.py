@@ -61,13 +61,22 @@ def maybe_init_from_env():
 
 
 def all_gather_stack(t: torch.Tensor) -> torch.Tensor:
-  """(…) per rank -> (world, …) on every rank: the posterior gather."""
+  """(…) per rank -> (world, …) on every rank: the posterior gather.  ONE collective into one
+  preallocated device tensor (`all_gather_into_tensor`: RCCL all-gather over xGMI under backend
+  nccl), no per-rank list and no stack copy.  BNF_GATHER=cabi routes it through the engine
+  library's own RCCL entry point (`bnf_allgather`, include/bnf.h) instead."""
   if not is_distributed():
     return t.unsqueeze(0)
   t = t.contiguous()
-  out = [torch.empty_like(t) for _ in range(device_count())]
-  torch.distributed.all_gather(out, t)
-  return torch.stack(out, dim=0)
+  world = device_count()
+  flat = t.reshape(1, -1)                  # (1, n): the collective concatenates along dim 0
+  out = torch.empty((world, flat.shape[1]), dtype=t.dtype, device=t.device)
+  if os.environ.get('BNF_GATHER') == 'cabi' and t.is_cuda:
+    from . import _native
+    _native.allgather(flat, out, world, rank())
+  else:
+    torch.distributed.all_gather_into_tensor(out, flat)
+  return out.view((world,) + tuple(t.shape))
 
 
 def all_gather_numpy(a: np.ndarray, device=None) -> np.ndarray:

@@ -215,14 +215,23 @@ def predict_bnf(features, observation_model, params, model_args, quantiles,
   return means_np, [q_np[i] for i in range(q_np.shape[0])]
 
 
-class EnsembleLikelihood:
-  """Minimal stand-in for the TFP distribution returned by the reference's
-  `likelihood_model` (spatiotemporal.py:433-468): Independent Normal per
-  member with event shape (n_rows,) and batch shape = ensemble dims."""
+def _quantile_engine(net, obs, compute_dtype):
+  """Forward-only handle that owns the quantile kernels (bnf_*_mixture_quantiles)."""
+  return Engine(net, mode='map', members=1, forward_only=True, row_capacity=128, compute_dtype=compute_dtype)
 
-  def __init__(self, loc: np.ndarray, scale: np.ndarray):
+
+class EnsembleLikelihood:
+  """Stand-in for the TFP distribution returned by the reference's `likelihood_model`
+  (spatiotemporal.py:433-468): Independent Normal per member with event shape (n_rows,) and
+  batch shape = ensemble dims.  mean / stddev / log_prob / sample are per member (as TFP's);
+  cdf is the per-member, per-row Normal cdf; mixture_cdf / quantile treat the ensemble as the
+  equally weighted mixture `predict` reports quantiles of (inference.py:42-52), the root found
+  on the GPU by the same kernel (`bnf_normal_mixture_quantiles`)."""
+
+  def __init__(self, loc: np.ndarray, scale: np.ndarray, net=None, compute_dtype=None):
     self.loc = loc                       # (*ens, R)
     self.scale = scale[..., None]        # (*ens, 1)
+    self._net, self._dtype = net, compute_dtype
 
   def mean(self):
     return self.loc
@@ -235,6 +244,26 @@ class EnsembleLikelihood:
     z = (y - self.loc) / self.scale
     return np.sum(-0.5 * z * z - np.log(self.scale) - 0.5 * np.log(2 * np.pi), axis=-1)
 
+  def cdf(self, x):
+    from scipy import special as sp
+    return sp.ndtr((np.asarray(x, dtype=np.float64) - self.loc) / self.scale)
+
+  def mixture_cdf(self, x):
+    c = self.cdf(x)
+    return c.reshape(-1, c.shape[-1]).mean(axis=0)
+
+  def quantile(self, q, approximate=False):
+    """Mixture quantile(s) per row: q scalar -> (R,), sequence -> (len(q), R)."""
+    qs = np.atleast_1d(np.asarray(q, dtype=np.float64))
+    eng = _quantile_engine(self._net, 'NORMAL', self._dtype)
+    means = torch.from_numpy(np.ascontiguousarray(self.loc.reshape(-1, self.loc.shape[-1]), dtype=np.float32)).to(eng.device)
+    scales = torch.from_numpy(np.ascontiguousarray(self.scale.reshape(-1), dtype=np.float32)).to(eng.device)
+    out = eng.normal_mixture_quantiles(means, scales, qs.tolist(), approximate=approximate)
+    torch.cuda.synchronize(eng.device)
+    res = out.cpu().numpy().astype(np.float64)
+    eng.close()
+    return res[0] if np.ndim(q) == 0 else res
+
   def sample(self, seed=0):
     rng = np.random.default_rng(_native.seed_to_u64(seed))
     return self.loc + self.scale * rng.standard_normal(self.loc.shape)
@@ -242,12 +271,16 @@ class EnsembleLikelihood:
 
 class CountEnsembleLikelihood:
   """NB / ZINB counterpart (models.py:166-191): Independent (ZI)NegativeBinomial per member.
-  total_count (*ens, 1), logits (*ens, R), inflated_loc_probs (*ens, 1) or None."""
+  total_count (*ens, 1), logits (*ens, R), inflated_loc_probs (*ens, 1) or None.  cdf /
+  mixture_cdf / quantile as in EnsembleLikelihood; the integer quantile follows
+  inference.py:298-333 (`bnf_count_mixture_quantiles`)."""
 
-  def __init__(self, total_count, logits, inflated_loc_probs=None):
+  def __init__(self, total_count, logits, inflated_loc_probs=None, net=None, compute_dtype=None, loc=None,
+               aux=None):
     self.total_count = total_count[..., None]
     self.logits = logits
     self.inflated_loc_probs = None if inflated_loc_probs is None else inflated_loc_probs[..., None]
+    self._net, self._dtype, self._loc, self._aux = net, compute_dtype, loc, aux
 
   def _nb_mean_var(self):
     mean = self.total_count * np.exp(self.logits)
@@ -275,6 +308,31 @@ class CountEnsembleLikelihood:
       lp = np.where(y == 0, np.logaddexp(np.log1p(-pi) + lp, np.log(pi)), np.log1p(-pi) + lp)
     return np.sum(lp, axis=-1)
 
+  def cdf(self, x):
+    """P(Y <= x) per member and row (TFP: betainc(total_count, 1 + floor(x), sigmoid(-logits)))."""
+    from scipy import special as sp
+    x = np.floor(np.asarray(x, dtype=np.float64))
+    tc = np.broadcast_to(self.total_count, self.logits.shape)
+    c = np.where(x < 0, 0.0, sp.betainc(tc, 1.0 + np.maximum(x, 0.0), sp.expit(-self.logits)))
+    if self.inflated_loc_probs is not None:
+      c = np.where(x < 0, 0.0, self.inflated_loc_probs + (1.0 - self.inflated_loc_probs) * c)
+    return c
+
+  def mixture_cdf(self, x):
+    c = self.cdf(x)
+    return c.reshape(-1, c.shape[-1]).mean(axis=0)
+
+  def quantile(self, q):
+    qs = np.atleast_1d(np.asarray(q, dtype=np.float64))
+    eng = Engine(self._net, mode='map', members=1, forward_only=True, row_capacity=128, compute_dtype=self._dtype)
+    loc = torch.from_numpy(np.ascontiguousarray(self._loc.reshape(-1, self._loc.shape[-1]), dtype=np.float32)).to(eng.device)
+    aux = torch.from_numpy(np.ascontiguousarray(self._aux.reshape(-1, 3), dtype=np.float32)).to(eng.device)
+    _, out = eng.count_mixture_quantiles(loc, aux, qs.tolist())
+    torch.cuda.synchronize(eng.device)
+    res = out.cpu().numpy().astype(np.float64)
+    eng.close()
+    return res[0] if np.ndim(q) == 0 else res
+
   def sample(self, seed=0):
     rng = np.random.default_rng(_native.seed_to_u64(seed))
     shape = np.broadcast_shapes(self.total_count.shape, self.logits.shape)
@@ -297,8 +355,9 @@ def likelihood_model(features, observation_model, params, model_args,
   aux = aux_all.cpu().numpy().reshape(tuple(lead) + (3,)).astype(np.float64)
   eng.close()
   if observation_model == 'NORMAL':
-    return EnsembleLikelihood(loc, aux[..., 0])
+    return EnsembleLikelihood(loc, aux[..., 0], net=net, compute_dtype=compute_dtype)
   shape = aux[..., 1]
   logits = -np.log(shape)[..., None] - np.log(np.logaddexp(loc, 0.0))
   return CountEnsembleLikelihood(1.0 / shape, logits,
-                                 aux[..., 2] if observation_model == 'ZINB' else None)
+                                 aux[..., 2] if observation_model == 'ZINB' else None, net=net,
+                                 compute_dtype=compute_dtype, loc=loc, aux=aux)

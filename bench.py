@@ -18,8 +18,12 @@ K-step loop is enqueued by ONE C call (bnf_train) with inputs resident in HBM.
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      dominant kernel: algorithmic FLOPs per launch / its mean HIP-event
                 duration inside the timed region, vs the dense bf16 MFMA peak.
-  cpu_baseline  the numpy oracle (a port of the reference algorithm, NOT JAX)
-                timed on this box's host cores on a bounded sample (N=1 only).
+  cpu_baseline  the oracle's algorithm on torch CPU float32 with torch.bmm over members (a port of
+                the reference algorithm, NOT JAX) timed on this box's host cores on a bounded
+                sample (N=1 only).
+`--gpus N` without a launcher starts the N ranks itself (torch.distributed.run, 127.0.0.1) and
+refuses to run when fewer than N devices are visible; the line carries `rccl_world_size` (from an
+actual all_reduce), every rank's ms/step and, for N > 1, the one posterior all-gather.
 """
 
 from __future__ import annotations
@@ -93,32 +97,126 @@ MODEL_KW = dict(width=512, depth=2, fourier_degrees=[5, 5, 5], interactions=[],
                 seasonality_periods=[4.0, 52.1775], num_seasonal_harmonics=[2, 10])
 
 
-def cpu_baseline(X, y, input_scales, members=4, steps=6):
-  """Oracle train steps on the host: float32 numpy (BLAS threads = all cores); a bounded sample
-  of the bench workload (about 10 s of CPU work at the default 4 members x 6 steps)."""
+def cpu_baseline(X, y, input_scales, members=8, steps=3):
+  """The oracle's train step on the host cores: torch CPU float32, members batched with torch.bmm,
+  hand-derived backward (oracle/torch_baseline.py, checked against the numpy oracle in
+  tests/test_torch_baseline.py).  A bounded sample of the bench workload: `members` members x
+  `steps` timed full-batch steps after one warm-up step, same C2 inputs."""
+  import torch
   from oracle import bnf_oracle as O
+  from oracle.torch_baseline import TorchStep
   model = O.Model(input_scales=input_scales, **MODEL_KW)
   rng = np.random.default_rng(0)
-  theta0 = O.map_init(model, y, rng.standard_normal((members, model.P)).clip(-2, 2),
-                      dtype=np.float32)
-  Xf = X.astype(np.float32)
-  yf = y.astype(np.float32)
-  O.train_map(model, theta0, Xf, yf, lr=0.005, num_epochs=1, dtype=np.float32)   # warm-up
+  theta0 = O.map_init(model, y, rng.standard_normal((members, model.P)).clip(-2, 2), dtype=np.float32)
+  ts = TorchStep(model, X, y, lr=0.005)
+  ts.train(theta0, 1)                                    # warm-up
   t0 = time.perf_counter()
-  O.train_map(model, theta0, Xf, yf, lr=0.005, num_epochs=steps, dtype=np.float32)
+  _, losses = ts.train(theta0, steps)
   dt = time.perf_counter() - t0
+  if not np.all(np.isfinite(losses)):
+    raise RuntimeError('non-finite loss in the CPU baseline')
+  cpu = 'unknown'
   try:
-    from threadpoolctl import threadpool_info
-    threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    with open('/proc/cpuinfo') as f:
+      cpu = next(l.split(':', 1)[1].strip() for l in f if l.startswith('model name'))
   except Exception:  # pylint: disable=broad-except
-    threads = os.cpu_count() or 1
-  return dict(value=members * steps / dt, unit='member-steps/s', cores=int(threads),
-              kind='port',
-              sample=f'{members} members x {steps} full-batch steps (N={len(y)}, W=512, depth 2), '
-                     'numpy float32 oracle (oracle/bnf_oracle.py), not JAX')
+    pass
+  flops = 6.0 * len(y) * (model.F * model.width + (model.depth - 1) * model.width**2 + model.width)
+  return dict(value=members * steps / dt, unit='member-steps/s', cores=int(torch.get_num_threads()),
+              kind='port', cpu=cpu, host_cores=os.cpu_count(),
+              achieved_tflops=flops * members * steps / dt / 1e12,
+              sample=f'{members} members x {steps} full-batch steps (N={len(y)}, W=512, depth 2) after 1 warm-up, '
+                     'torch CPU float32 + torch.bmm port of the oracle (oracle/torch_baseline.py), not JAX')
 
 
-def main():
+# ---------------------------------------------------------------------------------------------
+# one process per GPU: launcher, process group, collectives (shared by the real run and the CPU self-test)
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+  import socket
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    return sk.getsockname()[1]
+
+
+def self_launch(args, argv):
+  """`python bench.py --gpus N` without a launcher: start N ranks of this file under
+  torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and pass their output through.
+  Fails loudly when fewer than N devices are visible (never measures 1 GPU and calls it N)."""
+  import subprocess
+  if not args.selftest_cpu:
+    import torch
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible < args.gpus:
+      raise SystemExit(f'[bench] --gpus {args.gpus} requested but devices visible: {visible}; refusing to run '
+                       'a smaller job under that label')
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+  return subprocess.call(cmd, env=env)
+
+
+def init_group(selftest):
+  """-> (world, rank, device).  backend nccl (= RCCL over xGMI) on GPUs, gloo for the CPU self-test."""
+  import torch
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if world > 1 and not torch.distributed.is_initialized():
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if selftest:
+      torch.distributed.init_process_group(backend='gloo')
+    else:
+      from bayesnf_amd import distributed
+      distributed.maybe_init_from_env()
+  rank = torch.distributed.get_rank() if world > 1 else 0
+  if selftest:
+    return world, rank, torch.device('cpu')
+  from bayesnf_amd import distributed
+  return world, rank, torch.device(f'cuda:{distributed.local_device_index()}')
+
+
+def collective_world_size(world, device):
+  """Number of ranks an actual all_reduce saw (1 without a process group)."""
+  import torch
+  if world == 1:
+    return 1
+  one = torch.ones(1, dtype=torch.float32, device=device)
+  torch.distributed.all_reduce(one)
+  return int(round(one.item()))
+
+
+def gather_rank_times(world, device, elapsed):
+  """-> list of every rank's elapsed seconds (one all_gather of a scalar)."""
+  import torch
+  if world == 1:
+    return [elapsed]
+  mine = torch.tensor([elapsed], dtype=torch.float64, device=device)
+  out = torch.empty(world, dtype=torch.float64, device=device)
+  torch.distributed.all_gather_into_tensor(out, mine)
+  return [float(v) for v in out.cpu()]
+
+
+def gather_posterior(world, device, local_means):
+  """The job's only data collective (reference inference.py:452,486-492: pmap's output gather):
+  every rank's device-resident predictive means (E_local, R) -> (world * E_local, R) on every rank
+  with ONE all_gather_into_tensor (RCCL over xGMI under backend nccl).  -> (tensor, ms)."""
+  import torch
+  local_means = local_means.contiguous()
+  if world == 1:
+    return local_means, 0.0
+  out = torch.empty((world * local_means.shape[0],) + tuple(local_means.shape[1:]), dtype=local_means.dtype,
+                    device=device)
+  if device.type == 'cuda':
+    torch.cuda.synchronize(device)
+  torch.distributed.barrier()
+  t0 = time.perf_counter()
+  torch.distributed.all_gather_into_tensor(out, local_means)
+  if device.type == 'cuda':
+    torch.cuda.synchronize(device)
+  return out, (time.perf_counter() - t0) * 1e3
+
+
+def main(argv=None):
+  argv = list(sys.argv[1:] if argv is None else argv)
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=30)
@@ -128,72 +226,105 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--profile-all', action='store_true',
                   help='also print the per-kernel HIP-event table to stderr')
-  args = ap.parse_args()
+  ap.add_argument('--selftest-cpu', action='store_true',
+                  help='no GPU: exercise launcher, process group (gloo), timing reduction, posterior gather and '
+                       'the JSON line with a stand-in step (tests/test_bench_launcher.py)')
+  args = ap.parse_args(argv)
+
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(self_launch(args, argv))
 
   import torch
-  from bayesnf_amd import distributed
-  from bayesnf_amd.engine import Engine
-  from bayesnf_amd.spec import NetSpec
-
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  if world > 1:
-    distributed.maybe_init_from_env()
-  rank = distributed.rank()
-  if args.gpus != world and rank == 0:
-    print(f'[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}',
-          file=sys.stderr)
+  world, rank, device = init_group(args.selftest_cpu)
+  if args.gpus != world:
+    raise SystemExit(f'[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+  seen = collective_world_size(world, device)
+  if seen != world:
+    raise SystemExit(f'[bench] all_reduce saw {seen} ranks, expected {world}')
 
   X, y, input_scales = synthetic_grid()
-  net = NetSpec(input_scales=input_scales, **MODEL_KW)
   E = args.members_per_gpu
-  eng = Engine(net, mode='map', X=X, y=y, members=E, member_offset=rank * E, seed=0,
-               learning_rate=0.005, prior_weight=1.0, compute_dtype=args.dtype)
-  eng.init_params(float(np.log(np.nanstd(y) / 2)))
 
   def sync():
-    torch.cuda.synchronize(eng.device)
+    if device.type == 'cuda':
+      torch.cuda.synchronize(device)
     if world > 1:
       torch.distributed.barrier()
-      torch.cuda.synchronize(eng.device)
+      if device.type == 'cuda':
+        torch.cuda.synchronize(device)
 
-  # ---- warm-up (also finds the dominant kernel) --------------------------------
-  eng.profile('*')
-  eng.train(0, max(args.warmup, 1))
-  sync()
-  warm = eng.profile_read()
-  eng.profile(None)
-  total_ms = {k: v['avg_ms'] * v['calls'] for k, v in warm.items()}
-  dominant = max(total_ms, key=total_ms.get)
-  if args.profile_all and rank == 0:
-    for k, v in sorted(warm.items(), key=lambda kv: -total_ms[kv[0]]):
-      tf = v['flops'] / (v['avg_ms'] * 1e-3) / 1e12 if v['flops'] else 0.0
-      print(f'[bench] {k:16s} avg {v["avg_ms"]*1e3:9.1f} us  x{v["calls"]:4d}  '
-            f'{tf:8.1f} TFLOP/s', file=sys.stderr)
+  if args.selftest_cpu:
+    # stand-in for the engine: a fixed amount of host work per "step", rank-dependent means
+    work = torch.randn(256, 256)
+    def run_steps(k):
+      for _ in range(k):
+        torch.mm(work, work)
+    run_steps(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    local_means = torch.full((E, 16), float(rank), device=device)
+    prof, dominant, final_loss, net, eng = None, 'selftest', 0.0, None, None
+  else:
+    from bayesnf_amd.engine import Engine
+    from bayesnf_amd.spec import NetSpec
+    net = NetSpec(input_scales=input_scales, **MODEL_KW)
+    eng = Engine(net, mode='map', X=X, y=y, members=E, member_offset=rank * E, seed=0,
+                 learning_rate=0.005, prior_weight=1.0, compute_dtype=args.dtype)
+    eng.init_params(float(np.log(np.nanstd(y) / 2)))
+    # ---- warm-up (also finds the dominant kernel) --------------------------------
+    eng.profile('*')
+    eng.train(0, max(args.warmup, 1))
+    sync()
+    warm = eng.profile_read()
+    eng.profile(None)
+    total_ms = {k: v['avg_ms'] * v['calls'] for k, v in warm.items()}
+    dominant = max(total_ms, key=total_ms.get)
+    if args.profile_all and rank == 0:
+      for k, v in sorted(warm.items(), key=lambda kv: -total_ms[kv[0]]):
+        tf = v['flops'] / (v['avg_ms'] * 1e-3) / 1e12 if v['flops'] else 0.0
+        print(f'[bench] {k:16s} avg {v["avg_ms"]*1e3:9.1f} us  x{v["calls"]:4d}  '
+              f'{tf:8.1f} TFLOP/s', file=sys.stderr)
+    # ---- timed region: exactly K steps, events only around the dominant kernel ---
+    eng.profile(dominant)
+    sync()
+    t0 = time.perf_counter()
+    losses = eng.train(args.warmup, args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile(None)
+    final_loss = float(losses[:, -1].mean().item())
+    if not np.isfinite(final_loss):
+      raise RuntimeError('non-finite training loss in the benchmark run')
+    local_means = None
 
-  # ---- timed region: exactly K steps, events only around the dominant kernel ---
-  eng.profile(dominant)
-  sync()
-  t0 = time.perf_counter()
-  losses = eng.train(args.warmup, args.steps)
-  sync()
-  elapsed = time.perf_counter() - t0
-  prof = eng.profile_read()
-  eng.profile(None)
+  rank_s = gather_rank_times(world, device, elapsed)
+  elapsed = max(rank_s)
+
+  gather = None
   if world > 1:
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
-    torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-  final_loss = float(losses[:, -1].mean().item())
-  if not np.isfinite(final_loss):
-    raise RuntimeError('non-finite training loss in the benchmark run')
+    if local_means is None:
+      # predictive means of this rank's members on the first 1024 training rows (forward-only handle)
+      fwd = Engine(net, members=E, forward_only=True, row_capacity=1024, compute_dtype=args.dtype)
+      Xd = torch.from_numpy(np.ascontiguousarray(X[:1024], dtype=np.float32)).to(device)
+      local_means, _ = fwd.forward(eng.params.view(E, net.P), Xd)
+      torch.cuda.synchronize(device)
+    allm, ms = gather_posterior(world, device, local_means)
+    gather = {'impl': 'torch.distributed.all_gather_into_tensor (backend %s)' % torch.distributed.get_backend(),
+              'shape': list(allm.shape), 'bytes_per_rank': local_means.numel() * local_means.element_size(),
+              'ms': ms, 'finite': bool(torch.isfinite(allm).all().item())}
+    if args.selftest_cpu:   # every rank's block must hold that rank's id
+      blocks = allm.view(world, E, -1)[:, 0, 0].tolist()
+      gather['rank_blocks_ok'] = blocks == [float(r) for r in range(world)]
+    if not args.selftest_cpu:
+      fwd.close()
 
   if rank == 0:
     total_members = E * world
     value = total_members * args.steps / elapsed
-    d = prof[dominant]
-    achieved = d['flops'] / (d['avg_ms'] * 1e-3) / 1e12 if d['flops'] else 0.0
-    peak = PEAK_TFLOPS[args.dtype]
-    flops_step = net.flops_per_member_step(len(y)) * total_members
     line = {
         'metric': 'train-steps/sec x ensemble_size (member-steps/s, whole job)',
         'value': value, 'unit': 'member-steps/s', 'n_gpus': world, 'steps': args.steps,
@@ -204,18 +335,29 @@ def main():
                                'depth=2, NORMAL, full batch, lr=0.005',
                    'members_per_gpu': E, 'ensemble_size': total_members, 'parallelism':
                    f'ensemble-shard x{world} (no data-path collective)'},
-        'algorithmic_tflops': flops_step * args.steps / elapsed / 1e12,
+        'rccl_world_size': seen, 'per_rank_ms_per_step': [t / args.steps * 1e3 for t in rank_s],
         'final_loss_mean': final_loss,
-        'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': peak,
-                     'unit': 'TFLOP/s', 'frac': achieved / peak,
-                     'traffic': pmc_traffic(dominant, args.dtype, E),
-                     'avg_launch_us': d['avg_ms'] * 1e3, 'launches': d['calls'],
-                     'flops_per_launch': d['flops']},
     }
-    if world == 1 and not args.no_cpu_baseline:
-      line['cpu_baseline'] = cpu_baseline(X, y, input_scales)
+    if gather is not None:
+      line['posterior_gather'] = gather
+    if args.selftest_cpu:
+      line['selftest'] = True
+    else:
+      d = prof[dominant]
+      achieved = d['flops'] / (d['avg_ms'] * 1e-3) / 1e12 if d['flops'] else 0.0
+      peak = PEAK_TFLOPS[args.dtype]
+      flops_step = net.flops_per_member_step(len(y)) * total_members
+      line['algorithmic_tflops'] = flops_step * args.steps / elapsed / 1e12
+      line['roofline'] = {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': peak,
+                          'unit': 'TFLOP/s', 'frac': achieved / peak,
+                          'traffic': pmc_traffic(dominant, args.dtype, E),
+                          'avg_launch_us': d['avg_ms'] * 1e3, 'launches': d['calls'],
+                          'flops_per_launch': d['flops']}
+      if world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(X, y, input_scales)
     print(json.dumps(line), flush=True)
-  eng.close()
+  if eng is not None:
+    eng.close()
   if world > 1:
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

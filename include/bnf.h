@@ -234,6 +234,23 @@ int bnf_profile_read(bnf_handle* h, int32_t* n, const char** names, double* avg_
  * (DESIGN.md section 4), 0 for non-contraction kernels. */
 double bnf_kernel_flops(const bnf_handle* h, const char* name);
 
+/* ---- the job's one data collective: the posterior gather -----------------------------------
+ * Replaces what `jax.pmap` does implicitly when the reference's fit / predict return
+ * (/root/reference/src/bayesnf/inference.py:452 `np.array(params_i)`, :486-492 the per-device
+ * predictive means concatenated on the default device): every rank contributes its members'
+ * device-resident parameters / predictive means and receives everyone's.  One RCCL all-gather
+ * over xGMI; librccl.so is dlopen'ed on first use (the engine itself has no link dependency).
+ *   id       BNF_COMM_ID_BYTES bytes made by rank 0 (bnf_comm_unique_id) and handed to every
+ *            rank by the host (any side channel: the Python layer broadcasts it)
+ *   send     DEVICE, bytes_per_rank bytes;  recv DEVICE, world * bytes_per_rank bytes, rank-major
+ *   stream   hipStream_t the collective is enqueued on (no host synchronisation) */
+#define BNF_COMM_ID_BYTES 128
+typedef struct bnf_comm bnf_comm;
+int bnf_comm_unique_id(void* id);
+int bnf_comm_create(const void* id, int32_t world, int32_t rank, int32_t device, bnf_comm** out);
+int bnf_allgather(bnf_comm* c, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+void bnf_comm_destroy(bnf_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,15 @@ WORKER = textwrap.dedent('''
     np.testing.assert_array_equal(theta.reshape(E, net.P), full)
     np.testing.assert_array_equal(means.reshape(E, R),
                                   np.arange(E)[:, None] * 10.0 + np.arange(R)[None, :])
+    # real sharded work (host side of fit_map): every rank draws ITS members' initial parameters
+    # from the reference's seed chain; the gathered ensemble equals the one-process result
+    from bayesnf_amd import jaxseed
+    keys = jaxseed.member_keys(7, world, 3)
+    init_local = jaxseed.map_initial_params(net, keys[rank], 0.5)
+    init_all = distributed.all_gather_stack(torch.from_numpy(init_local)).numpy()
+    ref = jaxseed.map_initial_params(net, jaxseed.member_keys(7, 1, 6)[0], 0.5)
+    np.testing.assert_array_equal(init_all.reshape(6, net.P), ref)
+    assert np.abs(ref).max() > 0.5 and not np.array_equal(ref[0], ref[3])
     # StructTuple round trip with the (devices, E/devices) leading dims of the reference
     params = inference._struct_tuple(net, theta)
     assert params.var0.shape == (2, 3) and params[4].shape == (2, 3) + net.leaves[4].shape

@@ -158,3 +158,70 @@ def test_count_observation_models_end_to_end(golden_dir, obs):
   vi = BayesianNeuralFieldVI(**kw).fit(df, seed=1, ensemble_size=2, num_epochs=5, sample_size_posterior=3)
   m2, q2 = vi.predict(df, quantiles=(0.5,))
   assert m2.shape == (1, 3, 2, 100) and np.all(np.isfinite(m2)) and np.all(q2[0] >= 0)
+
+
+def test_posterior_gather_through_the_c_abi_single_rank():
+  """bnf_allgather (include/bnf.h): RCCL all-gather behind the C ABI, here with a one-rank
+  communicator on the one GPU a test box has (the N-rank path is the same call; RCCL's ring over
+  xGMI needs >= 2 devices, which only the driver's scaling run has)."""
+  import torch
+  from bayesnf_amd import _native
+  dev = torch.device('cuda:0')
+  send = torch.arange(3 * 1000, dtype=torch.float32, device=dev).reshape(3, 1000)
+  recv = torch.zeros((1, 3, 1000), dtype=torch.float32, device=dev)
+  _native.allgather(send, recv, world=1, rank=0)
+  torch.cuda.synchronize(dev)
+  assert torch.equal(recv[0], send)
+  # a second call reuses the cached communicator
+  send2 = send * 2
+  _native.allgather(send2, recv, world=1, rank=0)
+  torch.cuda.synchronize(dev)
+  assert torch.equal(recv[0], send2)
+
+
+@pytest.mark.parametrize('obs', ['NORMAL', 'NB', 'ZINB'])
+def test_likelihood_model_against_the_oracle(golden_dir, obs):
+  """N3: the object `likelihood_model(table)` returns (reference spatiotemporal.py:433-468 returns
+  the TFP distribution) against the oracle evaluated on the fitted parameters: mean, stddev,
+  log_prob, cdf per member, and the mixture quantile as a root of the oracle's mixture cdf."""
+  from bayesnf_amd.spec import NetSpec
+  df = _train_frame(golden_dir)
+  kw = dict(MODEL, observation_model=obs, width=64, compute_dtype='fp32')
+  est = BayesianNeuralFieldMAP(**kw).fit(df, seed=5, ensemble_size=3, num_epochs=40, learning_rate=0.01)
+  lik = est.likelihood_model(df)
+  X = est.data_handler.get_test(df).astype(np.float32).astype(np.float64)
+  y = df['chickenpox'].to_numpy().astype(np.float64)
+  args = est._model_args(X.shape)
+  model = O.Model(observation_model=obs, **{k: args[k] for k in (
+      'width', 'depth', 'input_scales', 'fourier_degrees', 'interactions', 'seasonality_periods',
+      'num_seasonal_harmonics')})
+  theta = NetSpec(observation_model=obs, **args).pack(list(est.params_))[0].astype(np.float64)
+  out = O.forward(model, theta, X)
+  if obs == 'NORMAL':
+    sigma = O.noise_scale(model, theta)
+    np.testing.assert_allclose(lik.mean()[0], out, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(lik.stddev()[0], np.broadcast_to(sigma[:, None], out.shape), rtol=1e-5)
+    np.testing.assert_allclose(lik.log_prob(y)[0], O.normal_loglik(out, y, sigma), rtol=2e-5)
+    xs = np.linspace(y.min(), y.max(), 100)
+    np.testing.assert_allclose(lik.cdf(xs)[0], O._ndtr((xs[None, :] - out) / sigma[:, None]), atol=2e-5)
+    np.testing.assert_allclose(lik.mixture_cdf(xs), O.mixture_cdf(out, sigma, xs), atol=2e-5)
+    for q in (0.1, 0.5, 0.9):
+      np.testing.assert_allclose(O.mixture_cdf(out, sigma, lik.quantile(q)), q, atol=3e-5)
+    assert lik.quantile([0.25, 0.75]).shape == (2, 100)
+  else:
+    fc = O.count_forecast(model, theta, out)
+    np.testing.assert_allclose(lik.mean()[0], fc['mean'], rtol=5e-4)
+    np.testing.assert_allclose(lik.stddev()[0], fc['stddev'], rtol=5e-4)
+    tc, logits = O.nb_logits_total_count(model, theta, out)
+    if obs == 'NB':
+      lp = O.nb_log_prob(y[None, :], tc, logits).sum(axis=-1)
+    else:
+      lp = O.zinb_log_prob(y[None, :], tc, logits, fc['pi']).sum(axis=-1)
+    np.testing.assert_allclose(lik.log_prob(y)[0], lp, rtol=2e-4)
+    xs = np.arange(0, 100, dtype=np.float64)
+    np.testing.assert_allclose(lik.cdf(xs)[0], O.count_cdf(fc, xs[None, :]), atol=2e-4)
+    for q in (0.2, 0.5, 0.9):
+      got = lik.quantile(q)
+      np.testing.assert_array_equal(got, O.count_quantile_via_root(fc, q))
+      # an integer quantile: cdf(k) >= q > cdf(k - 1) up to the root tolerance
+      assert np.all(lik.mixture_cdf(got) >= q - 2e-5)
