@@ -253,7 +253,7 @@ def make_config(net: _spec.NetSpec, *, device, dtype, mode, n_rows, batch,
   c.members, c.member_offset = int(members), int(member_offset)
   c.vi_samples = int(vi_samples)
   c.forward_only = 1 if forward_only else 0
-  c.pipeline = {'auto': 0, 'layers': 1, 'fused': 2, 'panel': 3}.get(pipeline, pipeline)
+  c.pipeline = {'auto': 0, 'layers': 1, 'panel': 3}.get(pipeline, pipeline)
   c.learning_rate = float(learning_rate)
   c.prior_weight = float(prior_weight)
   c.kl_weight = float(kl_weight)

@@ -26,7 +26,6 @@
 #include "../../include/bnf.h"
 #include "bnf_gemm.h"
 #include "bnf_kernels.h"
-#include "bnf_fused.h"
 #include "bnf_panel.h"
 
 using namespace bnf;
@@ -55,12 +54,12 @@ static int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 enum KernelId {
   KID_PACK = 0, KID_FEAT, KID_FWD0, KID_FWD, KID_ROWLOSS, KID_LASTBWD, KID_DGRAD, KID_DGRAD0,
-  KID_FEATBWD, KID_WGRAD0, KID_WGRAD, KID_ADAM, KID_VISAMPLE, KID_VIADAM, KID_FUSED, KID_FWDLAST, KID_PANEL, KID_COUNT
+  KID_FEATBWD, KID_WGRAD0, KID_WGRAD, KID_ADAM, KID_VISAMPLE, KID_VIADAM, KID_FWDLAST, KID_PANEL, KID_COUNT
 };
 static const char* kKernelNames[KID_COUNT] = {
     "pack_weights", "featurize", "gemm_fwd_l0", "gemm_fwd", "row_loss", "last_bwd", "gemm_dgrad",
     "gemm_dgrad0", "feat_bwd", "gemm_wgrad_l0", "gemm_wgrad", "adam_map", "vi_sample", "vi_adam",
-    "fused_fwd_bwd", "gemm_fwd_last", "panel_fwd_bwd"};
+    "gemm_fwd_last", "panel_fwd_bwd"};
 
 struct TimedLaunch {
   int kid;
@@ -84,7 +83,7 @@ struct bnf_handle {
   int64_t N = 0, B = 0, Bp = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;            // weight-gradient contractions overlap the dgrad chain
-  hipEvent_t ev_dz[BNF_MAX_LAYERS];         // dZ_l is complete (main stream)
+  hipEvent_t ev_dz[BNF_MAX_LAYERS] = {};    // dZ_l is complete (main stream)
   hipEvent_t ev_wg = nullptr;               // all weight gradients are complete (stream2)
   bool overlap = false;   // BNF_OVERLAP=1: measured neutral (3.79 vs 3.76 ms/step), off by default
   bool bound = false;
@@ -107,14 +106,9 @@ struct bnf_handle {
   int64_t pack_batch[BNF_MAX_LAYERS];
   float* dH0 = nullptr; float* out = nullptr; float* ybat = nullptr; float* loss_raw = nullptr;
   float* vacc = nullptr; float* dv = nullptr;   // output-layer dot accumulator, d loss / d v
-  // fused row-panel pipeline
   bool panel = false;         // row-panel forward + backward kernel (bnf_panel.h): bf16, depth 2, W = 256 / 512
-  bool fused = false;
-  int fused_grid = 0;
-  size_t fused_lds = 0;
   void* Wf[BNF_MAX_LAYERS]; void* Wb[BNF_MAX_LAYERS];   // fragment-major packed weights
-  void* spill = nullptr;
-  unsigned long long* prof_buf = nullptr;   // phase clocks (ABLATE builds)
+    unsigned long long* prof_buf = nullptr;   // phase clocks (ABLATE builds)
   double prof_gap[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   double prof_blocks = 0;
   int prof_threads = 0;
@@ -159,23 +153,21 @@ static size_t carve(bnf_handle* h, char* base) {
   // kernel reads the features as MFMA A fragments from a second, fragment-major copy (H0t slot)
   h->H0t = h->panel ? take((size_t)Ev * Bp * Fp * es) : nullptr;
   for (int l = 0; l < h->L; ++l) {
-    h->A[l] = (h->fused || h->panel || (h->fuse_last && l == h->L - 1) || (h->recompute_a0 && l == 0)) ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
+    h->A[l] = (h->panel || (h->fuse_last && l == h->L - 1) || (h->recompute_a0 && l == 0)) ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
     h->H[l] = (l < h->L - 1) ? take((size_t)Ev * Bp * W * es) : nullptr;       // H_{l+1} (Bp, W)
     h->Ht[l] = nullptr;
     h->dZ[l] = fo ? nullptr : take((size_t)Ev * Bp * W * es);
     h->dZt[l] = nullptr;
     const int64_t npad = (l == 0) ? Fp : W;
     h->pack_batch[l] = npad * W;
-    h->Kn[l] = (h->fused || h->panel) ? nullptr : take((size_t)Ev * npad * W * es);
-    h->Kt[l] = (h->fused || h->panel) ? nullptr : take((size_t)Ev * npad * W * es);
+    h->Kn[l] = h->panel ? nullptr : take((size_t)Ev * npad * W * es);
+    h->Kt[l] = h->panel ? nullptr : take((size_t)Ev * npad * W * es);
   }
   for (int l = 0; l < h->L; ++l) {
     const int64_t npad = (l == 0) ? Fp : W;
-    h->Wf[l] = (h->fused || h->panel) ? take((size_t)Ev * npad * W * es) : nullptr;
-    h->Wb[l] = (h->fused || h->panel) ? take((size_t)Ev * npad * W * es) : nullptr;
+    h->Wf[l] = h->panel ? take((size_t)Ev * npad * W * es) : nullptr;
+    h->Wb[l] = h->panel ? take((size_t)Ev * npad * W * es) : nullptr;
   }
-  h->spill = (h->fused && h->L > 1)
-                 ? take((size_t)h->fused_grid * (h->L - 1) * kFusedBM * W * es) : nullptr;
   h->dH0 = fo ? nullptr : (float*)take((size_t)Ev * Fp * Bp * 4);            // dH0^T (Fp, Bp)
   h->out = (float*)take((size_t)Ev * Bp * 4);
   h->vacc = (float*)take((size_t)Ev * Bp * 4);
@@ -272,6 +264,19 @@ static void phase_prof_end(bnf_handle* h, int kid, unsigned blocks, int threads)
 #endif
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: remember per
+// (kernel instantiation, device) that it has been raised (a process may drive several GPUs).
+template <typename K>
+static void allow_lds(bnf_handle* h, K kernel, int bytes, uint64_t* done_mask) {
+  const uint64_t bit = 1ull << (h->cfg.device & 63);
+  if (*done_mask & bit) return;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess)
+    fprintf(stderr, "[bnf] hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed: %s\n", bytes, hipGetErrorString(e));
+  *done_mask |= bit;
+}
+
 template <typename T, int EPI, int TAG, int WGM, int WGN>
 static void launch_gemm_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep) {
   constexpr int kLds = Mma<T>::lds_bytes(WGM, WGN, epi_extra_lds(EPI, WGM, WGN, (int)sizeof(T)));
@@ -279,12 +284,8 @@ static void launch_gemm_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep
   g.tiles_m = (g.M + 64 * WGM - 1) / (64 * WGM);
   g.tiles_n = (g.N + 64 * WGN - 1) / (64 * WGN);
   if (g.splitk < 1) g.splitk = 1;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt<T, EPI, TAG, WGM, WGN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-    attr_set = true;
-  }
+  static uint64_t attr_done = 0;
+  allow_lds(h, &gemm_nt<T, EPI, TAG, WGM, WGN>, kLds, &attr_done);
   const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
   EpiArgs ep2 = ep;
   ep2.ablate = h->ablate;
@@ -343,12 +344,8 @@ static void launch_gemm_tn_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs&
   g.tiles_m = (g.M + 64 * WG - 1) / (64 * WG);
   g.tiles_n = (g.N + 64 * WG - 1) / (64 * WG);
   if (g.splitk < 1) g.splitk = 1;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn<T, TAG, WG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-    attr_set = true;
-  }
+  static uint64_t attr_done = 0;
+  allow_lds(h, &gemm_tn<T, TAG, WG>, kLds, &attr_done);
   const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
   LaunchScope ls(h, kid, st, true);
   hipLaunchKernelGGL((gemm_tn<T, TAG, WG>), dim3(blocks), dim3(64 * WG * WG), kLds, st, g, ep);
@@ -394,12 +391,8 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
     LaunchScope ls(h, KID_FEAT);
     dim3 grid(cdiv(rows, kFeatRows), (unsigned)nmem);
     const size_t lds = (size_t)kFeatRows * (h->Fp + 16 / h->es) * h->es;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_featurize<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
+    static uint64_t attr_done = 0;
+    allow_lds(h, &k_featurize<T>, 160 * 1024, &attr_done);
     hipLaunchKernelGGL((k_featurize<T>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, X, stab,
                        y, h->scal, rows, (T*)h->H0, Bp * h->Fp,
                        (T*)nullptr, (int64_t)h->Fp * Bp, (int32_t)Bp,
@@ -613,7 +606,7 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
 }
 
 // ---------------------------------------------------------------------------
-// fused row-panel pipeline: pack fragments -> k_fused_fwd_bwd -> gemm_tn weight gradients
+// fragment-major weights for the row-panel kernel
 // ---------------------------------------------------------------------------
 template <typename T>
 static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
@@ -630,76 +623,6 @@ static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
   }
 }
 
-template <typename T, int NT>
-static void launch_fused(bnf_handle* h, const FusedArgs& fa) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_fwd_bwd<T, NT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  LaunchScope ls(h, KID_FUSED);
-  hipLaunchKernelGGL((k_fused_fwd_bwd<T, NT>), dim3((unsigned)h->fused_grid), dim3(kFusedThreads),
-                     h->fused_lds, h->stream, fa);
-}
-
-template <typename T>
-static void run_fused(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs, float c,
-                      const LossSink& sink) {
-  const int64_t Bp = h->Bp;
-  run_pack_fragments<T>(h, theta, nmem);
-  {  // features (+ gathered targets) of every batch row, row-major: also the layer-0 wgrad operand
-    LaunchScope ls(h, KID_FEAT);
-    dim3 grid(cdiv(h->B, kFeatRows), (unsigned)nmem);
-    const size_t lds = (size_t)kFeatRows * (h->Fp + 16 / h->es) * h->es;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_featurize<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((k_featurize<T>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, h->X, h->stab,
-                       h->y, h->scal, h->B, (T*)h->H0, Bp * h->Fp, (T*)nullptr,
-                       (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp);
-  }
-  FusedArgs fa{};
-  fa.Fp = h->Fp; fa.F = h->F; fa.L = h->L;
-  for (int l = 0; l <= h->L; ++l) fa.off_bias[l] = h->nd.off_bias[l];
-  for (int l = 0; l < h->L; ++l) fa.off_ls[l] = h->nd.off_ls[l];
-  fa.off_ko = h->nd.off_kernel[h->L]; fa.off_os = h->nd.off_os; fa.off_lns = h->nd.off_lns;
-  fa.off_law = h->nd.off_law;
-  fa.theta = theta; fa.theta_stride = h->P; fa.B = h->B;
-  fa.n_tiles = (int32_t)((h->B + kFusedBM - 1) / kFusedBM); fa.members = nmem;
-  for (int l = 0; l < h->L; ++l) {
-    fa.Wfwd[l] = h->Wf[l]; fa.Wbwd[l] = h->Wb[l];
-    fa.wfwd_batch[l] = h->pack_batch[l]; fa.wbwd_batch[l] = h->pack_batch[l];
-    fa.H[l] = (l == 0) ? h->H0 : h->H[l - 1];
-    fa.dZ[l] = h->dZ[l];
-  }
-  fa.h0_batch = Bp * h->Fp; fa.act_batch = Bp * h->W;
-  fa.ybat = h->ybat; fa.yb_batch = Bp;
-  fa.dH0t = h->dH0; fa.dh0_batch = (int64_t)h->Fp * Bp; fa.ldt = (int32_t)Bp;
-  fa.spill = h->spill;
-  fa.out = h->out; fa.out_batch = Bp;
-  fa.grad = h->grad; fa.grad_stride = h->P;
-  fa.loss = sink.loss; fa.loss_stride = sink.stride; fa.S = h->S; fa.loss_scale = sink.scale;
-  fa.c = c; fa.loss_raw = sink.raw;
-  fa.ablate = h->ablate;
-  switch (h->W) {
-    case 128: launch_fused<T, 1>(h, fa); break;
-    case 256: launch_fused<T, 2>(h, fa); break;
-    default: launch_fused<T, 4>(h, fa); break;
-  }
-  {
-    LaunchScope ls(h, KID_FEATBWD);
-    dim3 grid(cdiv(h->B, 256), (unsigned)nmem);
-    hipLaunchKernelGGL(k_feat_bwd, grid, dim3(256), 0, h->stream, h->nd, rs, h->X, h->stab, theta,
-                       (int64_t)h->P, h->scal, h->B, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->grad,
-                       (int64_t)h->P);
-  }
-  run_wgrad<T>(h, nmem);
-}
-
 // ---------------------------------------------------------------------------
 // row-panel pipeline (bf16, depth 2): pack fragments -> featurise -> k_panel_fwd_bwd ->
 // featurise backward -> gemm_tn weight gradients
@@ -708,8 +631,8 @@ template <int WN, int RT, bool H0L>
 static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
   constexpr int kLds = panel_lds_bytes(WN, RT, H0L);
   static_assert(kLds <= 160 * 1024, "LDS per workgroup");
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel_fwd_bwd<WN, RT, H0L>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+  static uint64_t attr_done = 0;
+  allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L>, kLds, &attr_done);
   const unsigned blocks = (unsigned)(pa.members * pa.panels);
   PanelArgs pa2 = pa;
   pa2.ablate = h->ablate;
@@ -733,8 +656,8 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
     LaunchScope ls(h, KID_FEAT);
     dim3 grid(cdiv(h->B, kFeatRows), (unsigned)nmem);
     const size_t lds = (size_t)kFeatRows * (h->Fp + 8) * 2;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_featurize<bf16_t>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static uint64_t attr_done = 0;
+    allow_lds(h, &k_featurize<bf16_t>, 160 * 1024, &attr_done);
     hipLaunchKernelGGL((k_featurize<bf16_t>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, h->X, h->stab,
                        h->y, h->scal, h->B, (bf16_t*)h->H0, Bp * h->Fp, (bf16_t*)h->H0t,
                        (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp);
@@ -803,8 +726,6 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
   const float c = (float)((double)h->N / (double)h->B);
   if (h->panel) {
     run_panel(h, h->params, E, rs, c, sink);
-  } else if (h->fused) {
-    run_fused<T>(h, h->params, E, rs, c, sink);
   } else {
     run_pack<T>(h, h->params, E);
     run_forward<T>(h, h->params, E, rs, h->X, h->stab, h->y, h->B, true);
@@ -853,8 +774,6 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   LossSink sink{loss, loss_stride, kl / (float)S, nullptr};
   if (h->panel) {
     run_panel(h, h->theta_c, h->Ev, rs, c, sink);
-  } else if (h->fused) {
-    run_fused<T>(h, h->theta_c, h->Ev, rs, c, sink);
   } else {
     run_pack<T>(h, h->theta_c, h->Ev);
     run_forward<T>(h, h->theta_c, h->Ev, rs, h->X, h->stab, h->y, h->B, true);
@@ -938,6 +857,16 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   h->L = cfg->depth; h->W = cfg->width; h->F = cfg->n_features; h->P = cfg->n_params;
   h->Fp = (int)align_up(h->F, 64);
   h->N = cfg->n_rows; h->B = cfg->batch; h->Bp = align_up(h->B, 128);
+  {
+    // k_featurize stages kFeatRows rows of Fp (+ one 16-byte chunk) features in LDS
+    const size_t feat_lds = (size_t)kFeatRows * (h->Fp + 16 / h->es) * h->es;
+    if (feat_lds > 160 * 1024) {
+      const int F = h->F, es = h->es;
+      delete h;
+      return fail(BNF_ERR_INVALID, "%d features need %zu bytes of LDS per featurisation workgroup (limit 163840): "
+                  "at most %d features with this dtype", F, feat_lds, (160 * 1024 / (kFeatRows * es) - 16 / es) / 64 * 64);
+    }
+  }
   NetDev& nd = h->nd;
   memset(&nd, 0, sizeof(nd));
   nd.D = cfg->n_inputs; nd.F = h->F; nd.Fp = h->Fp; nd.W = h->W; nd.depth = h->L; nd.P = h->P;
@@ -981,16 +910,12 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   if (const char* ab = getenv("BNF_ABLATE")) h->ablate = atoi(ab);
   if (const char* bt = getenv("BNF_BIG_TILES")) h->big_tiles = atoi(bt);
   {
-    // fused row-panel pipeline: training handles with W = 128 / 256 / 512 and F <= 128
-    int want = cfg->pipeline;  // 0 auto, 1 unfused, 2 fused
+    int want = cfg->pipeline;  // 0 auto, 1 layer kernels with every activation materialised, 3 row-panel kernel
     if (const char* pf = getenv("BNF_PIPELINE")) want = atoi(pf);
-    const bool can = !cfg->forward_only && (h->W == 128 || h->W == 256 || h->W == 512) && h->Fp <= 128 &&
-                     cfg->obs_model == BNF_OBS_NORMAL;
-    if (want == 2 && !can) {
+    if (want != 0 && want != 1 && want != 3) {
       delete h;
-      return fail(BNF_ERR_INVALID, "fused pipeline needs a NORMAL training handle with width 128/256/512 and <= 128 features");
+      return fail(BNF_ERR_INVALID, "pipeline %d (0 auto, 1 layers, 3 panel)", want);
     }
-    h->fused = can && want == 2;   // opt-in: measured slower than the layer kernels
     // pipeline 3: row-panel forward + backward kernel (bf16, two hidden layers, width 256 / 512)
     const bool can_panel = !cfg->forward_only && h->bf16 && h->L == 2 && (h->W == 256 || h->W == 512) && h->Fp <= 128;
     if (want == 3 && !can_panel) {
@@ -1002,15 +927,9 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
     // pipeline 0 (auto): layer kernels with the one-kernel last layer where the width allows;
     // pipeline 1: every layer kernel separate and every activation materialised (validation)
     const bool fl_ok = h->bf16 ? fused_last_supported<bf16_t>(h->W) : fused_last_supported<float>(h->W);
-    h->fuse_last = !cfg->forward_only && !h->fused && !h->panel && want == 0 && fl_ok;
+    h->fuse_last = !cfg->forward_only && !h->panel && want == 0 && fl_ok;
     // its contraction depth is Fp <= 128: cheaper to redo than to write + gather A_0^T
-    h->recompute_a0 = !cfg->forward_only && !h->fused && !h->panel && want == 0 && h->L >= 2 && h->Fp <= 128;
-    if (h->fused) {
-      h->fused_lds = fused_lds_bytes(h->W, h->Fp, h->es);
-      const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / h->fused_lds)));
-      const int64_t items = (int64_t)h->Ev * ((h->B + kFusedBM - 1) / kFusedBM);
-      h->fused_grid = (int)std::min<int64_t>(items, (int64_t)prop.multiProcessorCount * per_cu);
-    }
+    h->recompute_a0 = !cfg->forward_only && !h->panel && want == 0 && h->L >= 2 && h->Fp <= 128;
   }
   h->ws_bytes = carve(h, nullptr);
   *out = h;
@@ -1019,7 +938,15 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
 
 void bnf_destroy(bnf_handle* h) {
   if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
   for (auto ev : h->event_pool) hipEventDestroy(ev);
+  if (h->stream2) {
+    (void)hipStreamSynchronize(h->stream2);
+    (void)hipStreamDestroy(h->stream2);
+  }
+  for (int l = 0; l < BNF_MAX_LAYERS; ++l)
+    if (h->ev_dz[l]) (void)hipEventDestroy(h->ev_dz[l]);
+  if (h->ev_wg) (void)hipEventDestroy(h->ev_wg);
   if (h->prof_buf) {
     if (h->prof_blocks > 0) {
       fprintf(stderr, "[phase clocks] %s: %d threads/workgroup, mean cycles per workgroup: total %.0f |",
@@ -1151,7 +1078,7 @@ int bnf_forward(bnf_handle* h, const float* theta, int64_t n_members, const floa
                 int64_t n_rows, float* loc, float* aux) {
   if (!h || !h->bound) return fail(BNF_ERR_STATE, "bnf_forward before bnf_bind");
   if (!theta || !Xnew || !loc || n_members < 1 || n_rows < 1) return fail(BNF_ERR_INVALID, "argument");
-  if (h->fused || h->panel) return fail(BNF_ERR_STATE, "bnf_forward needs a forward_only (or pipeline=1) handle");
+  if (h->panel) return fail(BNF_ERR_STATE, "bnf_forward needs a forward_only (or pipeline=1) handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   const int64_t row_chunk = h->Bp, mem_chunk = h->Ev;
   RowSrc rs{};
@@ -1511,8 +1438,6 @@ double bnf_kernel_flops(const bnf_handle* h, const char* name) {
     return 2.0 * Ev * B * (h->L > 1 ? W : F) * W + 2.0 * Ev * B * W;
   if (!strcmp(name, "panel_fwd_bwd"))  // forward + backward-data contractions of both layers + output layer
     return 4.0 * Ev * B * (F * W + W * W) + 2.0 * Ev * B * W;
-  if (!strcmp(name, "fused_fwd_bwd"))  // forward + dgrad contractions of every layer + output layer
-    return 4.0 * Ev * B * (F * W + (h->L - 1) * W * W) + 6.0 * Ev * B * W;
   return 0.0;
 }
 

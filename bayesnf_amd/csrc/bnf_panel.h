@@ -71,6 +71,37 @@ struct PanelArgs {
   int32_t ablate;                 // perf experiments only (env BNF_ABLATE)
 };
 
+// ---- fragment-major weight packing -------------------------------------------------
+// Wp[nt][ks][lane][8] : lane l of fragment (nt, ks) holds Bt[nt*32 + (l&31)][ks*16 + (l>>5)*8 + 0..7]
+//   which = 0 (forward):  Bt[n][k] = K[k][n], k < n_in, n < W          (n_tiles = W/32,  KS = n_pad/16)
+//   which = 1 (backward): Bt[n][k] = K[n][k], n < n_in, k < W          (n_tiles = n_pad/32, KS = W/16)
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_fragments(const float* __restrict__ theta,
+                                                        int64_t theta_stride, int32_t off_kernel,
+                                                        int32_t n_in, int32_t n_pad, int32_t W,
+                                                        int32_t which, T* __restrict__ out,
+                                                        int64_t out_batch) {
+  const int e = blockIdx.y;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one (nt, ks, lane) per thread
+  const int KS = (which == 0 ? n_pad : W) / 16;
+  const int NTt = (which == 0 ? W : n_pad) / 32;
+  if (idx >= (int64_t)NTt * KS * 64) return;
+  const int lane = (int)(idx & 63);
+  const int ks = (int)((idx >> 6) % KS);
+  const int nt = (int)((idx >> 6) / KS);
+  const int n = nt * 32 + (lane & 31);
+  const int k0 = ks * 16 + (lane >> 5) * 8;
+  const float* K = theta + (int64_t)e * theta_stride + off_kernel;  // (n_in, W) row-major
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = k0 + j;
+    if (which == 0) v[j] = (k < n_in && n < W) ? K[(int64_t)k * W + n] : 0.f;
+    else v[j] = (n < n_in && k < W) ? K[(int64_t)n * W + k] : 0.f;
+  }
+  store8(out + (int64_t)e * out_batch + idx * 8, v);
+}
+
 constexpr int kPanelPD = 4;       // weight fragments in flight per stream
 
 // RT = 32-row tiles per wave (4: one workgroup per CU, 256 registers; 2: two workgroups per CU, 128)
@@ -181,7 +212,6 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   constexpr int kPitchE = W + 8;            // panel row pitch, elements (16 bytes of padding)
   constexpr int kPitchB = kPitchE * 2;
   constexpr int KS1 = W / 16;
-  constexpr int kCpr = W / 8;               // 16-byte chunks per row
   constexpr int kHalves = (RT + 1) / 2;     // row dots go through a 64-row scratch image per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem);

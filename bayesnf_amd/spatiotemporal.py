@@ -11,8 +11,14 @@ to the HIP library instead of jax.
 
 Differences a caller can see:
   * `seed` is an int or a length-2 uint32 array (a `jax.random.PRNGKey` also
-    works, it is such an array); the random streams are this package's own
-    counter-based generator, not threefry.
+    works, it is such an array).  MAP / MLE draw their initial parameters from the
+    reference's own streams for that seed (threefry + TFP seed chain, `jaxseed`: a
+    full-batch fit reproduces the reference's golden predictions); minibatch shuffles
+    and everything VI draws come from this package's counter-based generator.
+  * limits of the HIP engine, checked when the estimator is constructed / fitted
+    (the reference accepts any size): `width` a multiple of 64; `depth` <= 8;
+    at most 8 feature columns, 96 distinct seasonal frequencies, 16 interactions;
+    at most 512 (fp32: 256) features in total; `batch_size` <= number of rows.
   * the leading `(num_devices, ensemble_size // num_devices)` dimensions use
     `num_devices = torch.distributed world size` (one process per GPU).
   * `likelihood_model()` returns `bayesnf_amd.inference.EnsembleLikelihood`,
@@ -213,6 +219,7 @@ class BayesianNeuralFieldEstimator:
     self.standardize = standardize
     self.compute_dtype = compute_dtype
     self.init_rng = init_rng
+    self._check_engine_limits(len(feature_cols))
     self.losses_ = None
     self.params_ = None
     self.data_handler = SpatiotemporalDataHandler(
@@ -268,7 +275,21 @@ class BayesianNeuralFieldEstimator:
       return np.fmin(.5, self._get_seasonality_periods() / 2)
     raise AssertionError(f'Impossible {self.timetype=}.')
 
+  def _check_engine_limits(self, n_inputs=None):
+    """The HIP engine's hard limits, reported here with the estimator's own argument names
+    instead of as an error code from deep inside `fit` (include/bnf.h BNF_MAX_*)."""
+    if not isinstance(self.width, (int, np.integer)) or self.width < 64 or self.width % 64:
+      raise ValueError(f'width={self.width}: the MI355X engine needs a positive multiple of 64 '
+                       '(MFMA tile granularity); the reference default 512 and its dataset configs qualify')
+    if not 1 <= int(self.depth) <= 8:
+      raise ValueError(f'depth={self.depth}: the MI355X engine supports 1..8 hidden layers')
+    if n_inputs is not None and n_inputs > 8:
+      raise ValueError(f'{n_inputs} feature columns: the MI355X engine supports at most 8')
+    if self.interactions is not None and len(self.interactions) > 16:
+      raise ValueError(f'{len(self.interactions)} interactions: the MI355X engine supports at most 16')
+
   def _model_args(self, batch_shape):
+    self._check_engine_limits(batch_shape[-1])
     return dict(
         depth=self.depth,
         input_scales=self.data_handler.get_input_scales(),

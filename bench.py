@@ -52,7 +52,6 @@ KERNEL_SYMBOL = {   # gemm_nt<T, epilogue, tag, wave rows, wave cols>
     'gemm_wgrad_l0': 'void bnf::gemm_tn<{T}, 0, 2>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_wgrad': 'void bnf::gemm_tn<{T}, 1, 4>(bnf::GemmArgs, bnf::EpiArgs)',
     'last_bwd': 'void bnf::k_last_bwd<{T}>',
-    'fused_fwd_bwd': 'void bnf::k_fused_fwd_bwd<{T}',
     'panel_fwd_bwd': 'void bnf::k_panel_fwd_bwd<8, 4, true>(bnf::PanelArgs)',
 }
 

@@ -108,8 +108,7 @@ typedef struct bnf_config {
                                layer + output layer + likelihood + its backward in ONE kernel when
                                the width is 64/128/256 (512: bf16 only).  1: one kernel per layer and
                                every activation materialised (validation; bnf_debug_activation can
-                               read all of them).  2: experimental persistent row-panel kernel
-                               (NORMAL, width 128/256/512, <= 128 features; slower, opt-in).
+                               read all of them).
                                3: row-panel forward + backward kernel (bnf_panel.h: bf16, depth 2,
                                width 256/512, <= 128 features) -- what 0 selects where it applies */
   float   learning_rate;

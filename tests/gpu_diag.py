@@ -97,11 +97,6 @@ if __name__ == '__main__':
   for name, fn in [('gemm', gemm_diag),
                    ('stages fp32', lambda: stage_diag('fp32')),
                    ('stages fp32 depth3 W192 N257', lambda: stage_diag('fp32', 3, 192, 257)),
-                   ('FUSED fp32 depth1 W128', lambda: stage_diag('fp32', 1, 128, 130, pipeline='fused')),
-                   ('FUSED fp32 depth2 W128', lambda: stage_diag('fp32', 2, 128, 300, pipeline='fused')),
-                   ('FUSED fp32 depth3 W256', lambda: stage_diag('fp32', 3, 256, 257, pipeline='fused')),
-                   ('FUSED fp32 depth2 W512', lambda: stage_diag('fp32', 2, 512, 100, pipeline='fused')),
-                   ('FUSED bf16 depth2 W256', lambda: stage_diag('bf16', 2, 256, 300, pipeline='fused')),
                    ('stages fp32 mle', lambda: stage_diag('fp32', pw=0.0)),
                    ('stages bf16', lambda: stage_diag('bf16')),
                    ('train fp32', lambda: train_diag('fp32')),

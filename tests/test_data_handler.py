@@ -191,3 +191,18 @@ def test_evaluate_tables_match_published_configs():
   assert ev.INFERENCE_CONFIG['sst']['vi']['learning_rate'] == 0.005
   with pytest.raises(ValueError):
     ev.run_experiment('chickenpox', '/nonexistent', '8', '/tmp/x', 'ais', {}, {}, {}, 0)
+
+
+def test_engine_limits_are_reported_at_construction():
+  """Hard limits of the HIP engine surface as ValueErrors naming the estimator argument
+  (the reference accepts any width / depth; see the module docstring of spatiotemporal.py)."""
+  import pytest as _pytest
+  from bayesnf_amd import BayesianNeuralFieldMAP
+  kw = dict(feature_cols=['t', 'x'], target_col='y', timetype='float')
+  with _pytest.raises(ValueError, match='width=100'):
+    BayesianNeuralFieldMAP(width=100, **kw)
+  with _pytest.raises(ValueError, match='depth=9'):
+    BayesianNeuralFieldMAP(depth=9, **kw)
+  with _pytest.raises(ValueError, match='feature columns'):
+    BayesianNeuralFieldMAP(feature_cols=[f'c{i}' for i in range(9)], target_col='y', timetype='float')
+  BayesianNeuralFieldMAP(width=192, depth=3, **kw)

@@ -98,13 +98,12 @@ def test_large_tile_kernels_forced(dtype, monkeypatch):
 # --------------------------------------------------------------------------- forward / grads
 @pytest.mark.parametrize('depth,width,n_rows,pipeline', [
     (2, 64, 300, 'layers'), (1, 128, 130, 'layers'), (3, 192, 257, 'layers'), (2, 256, 200, 'layers'),
-    (2, 64, 300, 'auto'), (1, 128, 130, 'auto'), (3, 256, 257, 'auto'), (2, 192, 140, 'auto'),
-    (1, 128, 130, 'fused'), (2, 128, 300, 'fused'), (3, 256, 257, 'fused'), (2, 512, 100, 'fused')])
+    (2, 64, 300, 'auto'), (1, 128, 130, 'auto'), (3, 256, 257, 'auto'), (2, 192, 140, 'auto')])
 def test_forward_and_grad_fp32(depth, width, n_rows, pipeline):
   """The train-step pipelines: 'layers' = one kernel per layer, every activation materialised;
   'auto' (default) = the same with the last hidden layer, the output layer, the likelihood and
   its backward fused into one kernel where the width allows (64/128/256, 512 in bf16; 192
-  falls back); 'fused' = the experimental row-panel kernel."""
+  falls back).  (The bf16 row-panel kernel has its own file, tests/test_gpu_panel.py.)"""
   net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth)
   E = 3
   theta = util.random_theta(model, E)
@@ -151,8 +150,7 @@ def test_many_seasonal_frequencies(harmonics):
   eng.close()
 
 
-@pytest.mark.parametrize('width,pipeline', [(64, 'layers'), (64, 'auto'), (256, 'auto'), (128, 'fused'),
-                                            (256, 'fused')])
+@pytest.mark.parametrize('width,pipeline', [(64, 'layers'), (64, 'auto'), (256, 'auto')])
 def test_train_full_batch_fp32(width, pipeline):
   n_rows, E, steps = 200, 4, 30
   net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=2)
@@ -323,7 +321,7 @@ def test_count_models_loss_grad_and_training_fp32(obs):
   assert util.rel_err(eng.get_params(), theta_o) < 2e-3
   eng.close()
   with pytest.raises(ValueError):
-    _engine(net, X, y, members=E, compute_dtype='fp32', pipeline='fused')
+    _engine(net, X, y, members=E, compute_dtype='fp32', pipeline='panel')   # bf16 only
 
 
 @pytest.mark.parametrize('obs', ['NB', 'ZINB'])
@@ -359,7 +357,7 @@ def test_count_models_forecast_means_and_quantiles(obs):
 
 
 # --------------------------------------------------------------------------- bf16
-@pytest.mark.parametrize('pipeline', ['layers', 'auto', 'fused'])
+@pytest.mark.parametrize('pipeline', ['layers', 'auto'])
 def test_bf16_tracks_fp32(pipeline):
   n_rows, E, steps = 512, 4, 40
   net, model, X, y = util.make_problem(n_rows=n_rows, width=128, depth=2)
