@@ -72,8 +72,12 @@ def test_random_model_shapes_bf16(seed):
   eng.set_params(theta)
   loss_d, g_d = eng.debug_loss_and_grad()
   loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=X.shape[0], prior_weight=pw)
-  np.testing.assert_allclose(loss_d, loss_o, rtol=3e-2, err_msg=str(kw))
+  # measured over these 16 shapes (scripts/sweep_bf16_diag.py, MI355X): loss 9e-6, Dense kernels
+  # 3.3e-3, biases 3.0e-3, scalar leaves (scales, log_scale_adjustment, activation weight: sums of
+  # O(rows x width) bf16-rounded products with cancellation) 3.0e-2.  Bars per leaf class at 2-5x that.
+  np.testing.assert_allclose(loss_d, loss_o, rtol=2e-3, err_msg=str(kw))
   errs = util.per_leaf_rel_err(model, g_d, g_o)
-  bad = {k: v for k, v in errs.items() if v > 0.12}
+  tol = lambda k: 1.5e-2 if k.endswith(('/kernel', '/bias')) else 6e-2
+  bad = {k: v for k, v in errs.items() if v > tol(k)}
   assert not bad, (bad, kw)
   eng.close()
