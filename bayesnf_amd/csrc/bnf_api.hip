@@ -117,6 +117,11 @@ struct bnf_handle {
   int big_tiles = 1;          // env BNF_BIG_TILES: 0 = 128 x 128 tiles everywhere, 1 = auto, 2 = 256 x 256
                               // wherever the shape divides (tests of the large-tile kernels at small sizes)
   float* scal = nullptr;      // (Ev, kScalStride) transformed scalar leaves (k_member_scalars)
+  StepState* step_state = nullptr;   // device: per-step state of the graph-replayed loop
+  hipGraphExec_t graph_exec = nullptr;   // one captured full-batch MAP step (launch-bound sizes)
+  int64_t graph_cols = 0;     // loss row stride the captured step was recorded with
+  float* graph_losses = nullptr;
+  int graph_mode = 0;         // env BNF_GRAPH=1: replay full-batch MAP steps from a hipGraph
   float* qscratch = nullptr;  // quantile partials: 2*1024*2 + 2 floats
   float* dbg_a = nullptr; float* dbg_b = nullptr;  // small debug staging (gmu/grho)
   uint8_t* is_matrix = nullptr;
@@ -176,6 +181,7 @@ static size_t carve(bnf_handle* h, char* base) {
   h->loss_raw = (float*)take((size_t)Ev * 4);
   h->qscratch = (float*)take((size_t)(4 * 1024 + 16) * 4);
   h->scal = (float*)take((size_t)Ev * kScalStride * 4);
+  h->step_state = (StepState*)take(sizeof(StepState));
   h->dbg_a = (float*)take(256);
   h->is_matrix = (uint8_t*)take((size_t)P);
   return off;
@@ -438,6 +444,7 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
 struct LossSink {
   float* loss; int64_t stride; float scale;   // loss[(e/S)*stride] += scale * step_loss
   float* raw;                                  // optional per-virtual-member raw loss
+  const StepState* st = nullptr;               // graph replay: per-step state in device memory
 };
 
 // weight gradient of layer l from the row-major H_l / dZ_l left in HBM, on stream `st`
@@ -522,7 +529,7 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
     ep.ybat = h->ybat; ep.row_batch = Bp;
     ep.out = h->out; ep.out_batch = Bp;
     ep.loss = sink.loss; ep.loss_raw = sink.raw; ep.loss_stride = sink.stride; ep.S = h->S;
-    ep.loss_scale = sink.scale; ep.lik_c = c;
+    ep.loss_scale = sink.scale; ep.lik_c = c; ep.st = sink.st;
     ep.off_os = h->nd.off_os; ep.off_bias_out = h->nd.off_bias[L];
     ep.off_lns = h->nd.off_lns; ep.off_shape = h->nd.off_shape; ep.off_infl = h->nd.off_infl;
     ep.obs = h->nd.obs;
@@ -536,7 +543,7 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
       a.out = h->out; a.out_batch = Bp; a.dv = h->dv;
       a.grad = h->grad; a.grad_stride = h->P;
       a.loss = sink.loss; a.loss_stride = sink.stride; a.S = h->S; a.loss_scale = sink.scale;
-      a.c = c; a.loss_raw = sink.raw;
+      a.c = c; a.loss_raw = sink.raw; a.st = sink.st;
       LaunchScope ls(h, KID_ROWLOSS);
       hipLaunchKernelGGL((k_row_loss<true>), dim3(cdiv(rows, 256), (unsigned)nmem), dim3(256), 0,
                          h->stream, h->nd, a);
@@ -678,7 +685,7 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   pa.ybat = h->ybat; pa.row_batch = Bp; pa.out = h->out; pa.out_batch = Bp;
   pa.grad = h->grad; pa.grad_stride = h->P;
   pa.loss = sink.loss; pa.loss_raw = sink.raw; pa.loss_stride = sink.stride; pa.S = h->S;
-  pa.loss_scale = sink.scale; pa.lik_c = c;
+  pa.loss_scale = sink.scale; pa.lik_c = c; pa.st = sink.st;
   // 128-row panels at W = 512 (the feature panel staged in LDS when Fp = 64), 256-row panels at W = 256
   if (h->W == 512) {
     pa.panels = (int32_t)(Bp / panel_rows(8, 4));
@@ -740,7 +747,7 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
   a.bc2 = (float)(1.0 - std::pow(0.999, (double)t));
   a.prior_weight = h->cfg.prior_weight;
   a.loss = sink.loss; a.loss_stride = sink.stride; a.loss_scale = sink.scale;
-  a.apply = apply ? 1 : 0; a.loss_raw = sink.raw;
+  a.apply = apply ? 1 : 0; a.loss_raw = sink.raw; a.st = sink.st;
   {
     LaunchScope ls(h, KID_ADAM);
     if (h->P % 4 == 0) {
@@ -909,6 +916,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   for (int k = 0; k < KID_COUNT; ++k) { h->acc_ms[k] = 0; h->acc_calls[k] = 0; }
   if (const char* ab = getenv("BNF_ABLATE")) h->ablate = atoi(ab);
   if (const char* bt = getenv("BNF_BIG_TILES")) h->big_tiles = atoi(bt);
+  if (const char* gm = getenv("BNF_GRAPH")) h->graph_mode = atoi(gm);
   {
     int want = cfg->pipeline;  // 0 auto, 1 layer kernels with every activation materialised, 3 row-panel kernel
     if (const char* pf = getenv("BNF_PIPELINE")) want = atoi(pf);
@@ -947,6 +955,7 @@ void bnf_destroy(bnf_handle* h) {
   for (int l = 0; l < BNF_MAX_LAYERS; ++l)
     if (h->ev_dz[l]) (void)hipEventDestroy(h->ev_dz[l]);
   if (h->ev_wg) (void)hipEventDestroy(h->ev_wg);
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->prof_buf) {
     if (h->prof_blocks > 0) {
       fprintf(stderr, "[phase clocks] %s: %d threads/workgroup, mean cycles per workgroup: total %.0f |",
@@ -1040,6 +1049,52 @@ int bnf_train(bnf_handle* h, int64_t epoch0, int64_t num_epochs, float* losses) 
   int rc = BNF_OK;
   if (h->cfg.mode == BNF_MODE_MAP) {
     const int64_t steps = h->N / h->B;  // ragged tail dropped (inference.py:583-589)
+    // Launch-bound sizes (C1: W = 256, 8 members, 100 rows = 130 us per step of ~11
+    // launches): a full-batch step is the same launch sequence every epoch, so ONE step can be
+    // captured into a hipGraph and replayed; what changes per step (Adam bias corrections, loss
+    // column) is read from StepState in device memory.  MEASURED (profiles/r02_c1_step_time.md):
+    // replay 135 us vs 131 us eager -- the C loop already runs ahead of the GPU (11 launches x
+    // ~3.5 us of host time), the step is bound by its ~11 DEPENDENT kernel boundaries on the device,
+    // which a graph does not remove.  Hence opt-in; the lever for this regime is fewer kernels.
+    const bool graph_ok = h->B >= h->N && !h->prof && !h->overlap && h->stream2 && num_epochs >= 8 &&
+                          h->graph_mode == 1;   // opt-in (BNF_GRAPH=1): measured neutral, see below
+    if (graph_ok) {
+      StepState st0{};
+      st0.t = h->adam_t + 1; st0.col = 0;
+      st0.bc1 = (float)(1.0 - std::pow(0.9, (double)st0.t));
+      st0.bc2 = (float)(1.0 - std::pow(0.999, (double)st0.t));
+      HIPCHK(hipMemcpyAsync(h->step_state, &st0, sizeof(st0), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));   // st0 lives on this stack frame
+      if (!h->graph_exec || h->graph_cols != num_epochs || h->graph_losses != losses) {
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        // (the caller's stream may be the legacy default stream, which cannot capture: record the
+        // step on the handle's own side stream; the graph is then launched on the caller's)
+        hipStream_t user_stream = h->stream;
+        h->stream = h->stream2;
+        const hipError_t be = hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed);
+        if (be != hipSuccess) {
+          h->stream = user_stream;
+          return fail(BNF_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(be));
+        }
+        LossSink sink{losses, num_epochs, 1.0f, nullptr, h->step_state};
+        rc = h->bf16 ? step_map<bf16_t>(h, epoch0, 0, sink, true) : step_map<float>(h, epoch0, 0, sink, true);
+        h->adam_t -= 1;   // step_map counted the captured (not executed) step
+        hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(1), 0, h->stream, h->step_state);
+        const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+        h->stream = user_stream;
+        if (rc != BNF_OK) return rc;
+        if (ce != hipSuccess) return fail(BNF_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+        const hipError_t ie = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) return fail(BNF_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+        h->graph_cols = num_epochs; h->graph_losses = losses;
+      }
+      for (int64_t ep = 0; ep < num_epochs; ++ep) HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
+      h->adam_t += num_epochs;
+      HIPCHK(hipGetLastError());
+      return BNF_OK;
+    }
     for (int64_t ep = 0; ep < num_epochs && rc == BNF_OK; ++ep) {
       for (int64_t s = 0; s < steps && rc == BNF_OK; ++s) {
         LossSink sink{losses + ep, num_epochs, 1.0f / (float)steps, nullptr};

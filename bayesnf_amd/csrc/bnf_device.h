@@ -23,6 +23,17 @@
 
 namespace bnf {
 
+// Per-step quantities of a train loop replayed from a hipGraph (bnf_train, launch-bound sizes): a
+// captured launch freezes its by-value arguments, so what changes from step to step lives in
+// device memory and is advanced by k_step_advance at the end of every step.  Kernels take a
+// `const StepState*` (null in the eager path, which passes the same quantities by value).
+struct StepState {
+  long long t;        // 1-based Adam step about to be taken
+  long long col;      // loss column of this step: loss pointers are offset by it
+  float bc1, bc2;     // Adam bias corrections 1 - 0.9^t, 1 - 0.999^t
+  float pad[2];
+};
+
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;

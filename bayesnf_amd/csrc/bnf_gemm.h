@@ -75,6 +75,7 @@ struct EpiArgs {
   int64_t row_batch, out_batch;
   float* loss;         // loss[(e / S) * loss_stride] += loss_scale * step loss
   float* loss_raw;     // optional (members,) raw step loss
+  const StepState* st; // graph replay: loss column offset
   int64_t loss_stride;
   int32_t S;
   float loss_scale, lik_c;   // lik_c = (N / B) * likelihood scale
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
 #pragma unroll
         for (int i = 0; i < 5; ++i) u[i] += s_sc[w2 * 5 + i];
       const float step_loss = -ep.lik_c * u[0];
-      atomicAdd(&ep.loss[(int64_t)(e / ep.S) * ep.loss_stride], ep.loss_scale * step_loss);
+      atomicAdd(&ep.loss[(int64_t)(e / ep.S) * ep.loss_stride + (ep.st ? ep.st->col : 0)], ep.loss_scale * step_loss);
       if (ep.loss_raw) atomicAdd(&ep.loss_raw[e], step_loss);
       atomicAdd(&gr[ep.off_os], sigmoidf(th[ep.off_os]) * u[1]);
       atomicAdd(&gr[ep.off_bias_out], u[2]);

@@ -380,6 +380,7 @@ struct RowLossArgs {
   float loss_scale;
   float c;               // (N/B) * lik_scale
   float* loss_raw;
+  const StepState* st;   // graph replay: loss column offset
 };
 
 template <bool TRAIN>
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256) void k_row_loss(NetDev nd, RowLossArgs a) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) u[i] = s_red[0][i] + s_red[1][i] + s_red[2][i] + s_red[3][i];
     const float step_loss = -a.c * u[0];
-    atomicAdd(&a.loss[(int64_t)(e / a.S) * a.loss_stride], a.loss_scale * step_loss);
+    atomicAdd(&a.loss[(int64_t)(e / a.S) * a.loss_stride + (a.st ? a.st->col : 0)], a.loss_scale * step_loss);
     if (a.loss_raw) atomicAdd(&a.loss_raw[e], step_loss);
     atomicAdd(&gr[nd.off_os], sigmoidf(th[nd.off_os]) * u[1]);
     atomicAdd(&gr[nd.off_bias[L]], u[2]);
@@ -588,13 +589,26 @@ struct AdamArgs {
   float* loss; int64_t loss_stride; float loss_scale;
   int32_t apply;          // 0: only add the prior gradient into grad (debug path)
   float* loss_raw;
+  const StepState* st;    // graph replay: bias corrections and loss column from device memory
 };
+
+// end of a replayed step: next Adam step, next loss column
+__global__ void k_step_advance(StepState* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long t = st->t + 1;
+    st->t = t;
+    st->col += 1;
+    st->bc1 = (float)(1.0 - pow(0.9, (double)t));
+    st->bc2 = (float)(1.0 - pow(0.999, (double)t));
+  }
+}
 
 template <int VEC>
 __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
   __shared__ float red[4];
   const int e = blockIdx.y;
   const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  const float bc1 = a.st ? a.st->bc1 : a.bc1, bc2 = a.st ? a.st->bc2 : a.bc2;
   float lp = 0.f;
   if (p0 < a.P) {
     const int64_t i0 = (int64_t)e * a.stride + p0;
@@ -616,7 +630,7 @@ __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
       if (a.apply) {
         m[k] = 0.9f * m[k] + 0.1f * g[k];
         v[k] = 0.999f * v[k] + 0.001f * g[k] * g[k];
-        th[k] = th[k] - a.lr * (m[k] / a.bc1) / (sqrtf(v[k] / a.bc2) + 1e-8f);
+        th[k] = th[k] - a.lr * (m[k] / bc1) / (sqrtf(v[k] / bc2) + 1e-8f);
         g[k] = 0.f;  // ready for the next step's atomics
       }
     }
@@ -637,7 +651,7 @@ __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
   __syncthreads();
   if (threadIdx.x == 0 && a.prior_weight != 0.f) {
     const float t = -(a.prior_weight) * (red[0] + red[1] + red[2] + red[3]);
-    atomicAdd(&a.loss[(int64_t)e * a.loss_stride], a.loss_scale * t);
+    atomicAdd(&a.loss[(int64_t)e * a.loss_stride + (a.st ? a.st->col : 0)], a.loss_scale * t);
     if (a.loss_raw) atomicAdd(&a.loss_raw[e], t);
   }
 }

@@ -67,6 +67,7 @@ struct PanelArgs {
   int64_t loss_stride;
   int32_t S;
   float loss_scale, lik_c;
+  const StepState* st;            // graph replay: loss column offset
   unsigned long long* prof;       // -DBNF_ENABLE_ABLATE builds: per-workgroup phase clocks
   int32_t ablate;                 // perf experiments only (env BNF_ABLATE)
 };
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
 #pragma unroll
       for (int i = 0; i < 5; ++i) u[i] += s_sc[w2 * 5 + i];
     const float step_loss = -a.lik_c * u[0];
-    atomicAdd(&a.loss[(int64_t)(e / a.S) * a.loss_stride], a.loss_scale * step_loss);
+    atomicAdd(&a.loss[(int64_t)(e / a.S) * a.loss_stride + (a.st ? a.st->col : 0)], a.loss_scale * step_loss);
     if (a.loss_raw) atomicAdd(&a.loss_raw[e], step_loss);
     atomicAdd(&gr[a.off_os], dgam_o * u[1]);
     atomicAdd(&gr[a.off_bias_out], u[2]);

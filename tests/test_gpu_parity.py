@@ -406,3 +406,21 @@ def test_extreme_quantiles_normal_and_counts():
         lo = np.maximum(k - 1, 0)
         assert np.all((O.count_cdf(fc, lo[None, :]).mean(axis=0) <= q + 3e-5) | (k == 0))
     eng.close()
+
+
+def test_graph_replayed_training_equals_eager(monkeypatch):
+  """BNF_GRAPH=1: full-batch MAP steps replayed from one captured hipGraph (per-step Adam bias
+  corrections and loss column read from device memory) give the eager loop's losses and parameters."""
+  net, model, X, y = util.make_problem(n_rows=200, width=64, depth=2)
+  out = {}
+  for mode in ('0', '1'):
+    monkeypatch.setenv('BNF_GRAPH', mode)
+    eng = _engine(net, X, y, members=3, seed=4, learning_rate=0.005, compute_dtype='fp32')
+    eng.init_params(0.1)
+    l1 = eng.train(0, 12)
+    l2 = eng.train(12, 9)          # second call: new loss tensor, Adam step count carries on
+    torch.cuda.synchronize()
+    out[mode] = (np.concatenate([l1.cpu().numpy(), l2.cpu().numpy()], axis=1), eng.get_params())
+    eng.close()
+  np.testing.assert_allclose(out['1'][0], out['0'][0], rtol=1e-5)
+  assert util.rel_err(out['1'][1], out['0'][1]) < 1e-5
