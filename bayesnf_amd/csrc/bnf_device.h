@@ -15,7 +15,7 @@
 // -DBNF_ENABLE_ABLATE (make ABLATE=1); production kernels carry no such branches.
 #ifdef BNF_ENABLE_ABLATE
 #define BNF_ABL(args, bit) ((args).ablate & (bit))
-#define BNF_MARK(args, k) do { if ((args).prof && threadIdx.x == 0) (args).prof[(size_t)blockIdx.x * 16 + (k)] = clock64(); } while (0)
+#define BNF_MARK(args, k) do { if ((args).prof && threadIdx.x == (((args).ablate >> 8) & 0x3ff)) (args).prof[(size_t)blockIdx.x * 16 + (k)] = clock64(); } while (0)
 #else
 #define BNF_ABL(args, bit) false
 #define BNF_MARK(args, k) do { } while (0)
