@@ -27,7 +27,6 @@
 #include "bnf_gemm.h"
 #include "bnf_kernels.h"
 #include "bnf_panel.h"
-#include "bnf_panel2.h"
 
 using namespace bnf;
 
@@ -107,8 +106,6 @@ struct bnf_handle {
   int64_t pack_batch[BNF_MAX_LAYERS];
   float* dH0 = nullptr; float* out = nullptr; float* ybat = nullptr; float* loss_raw = nullptr;
   float* vacc = nullptr; float* dv = nullptr;   // output-layer dot accumulator, d loss / d v
-  int panel2 = 0;             // bnf_panel2.h (env BNF_PANEL2): 1 = 64-row panels, two workgroups per CU; 2 = two groups in one
-  int panel_stagger = 0;      // env BNF_PANEL_STAGGER
   bool panel = false;         // row-panel forward + backward kernel (bnf_panel.h): bf16, depth 2, W = 256 / 512
   void* Wf[BNF_MAX_LAYERS]; void* Wb[BNF_MAX_LAYERS];   // fragment-major packed weights
     unsigned long long* prof_buf = nullptr;   // phase clocks (ABLATE builds)
@@ -658,27 +655,6 @@ static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
   phase_prof_end(h, KID_PANEL, blocks, 512);
 }
 
-template <int GROUPS>
-static void launch_panel2(bnf_handle* h, const PanelArgs& pa) {
-  constexpr int kLds = panel2_lds_bytes(GROUPS);
-  static_assert(kLds * (3 - GROUPS) <= 160 * 1024, "LDS per CU");
-  static uint64_t attr_done = 0;
-  allow_lds(h, &k_panel2_fwd_bwd<GROUPS>, kLds, &attr_done);
-  const unsigned blocks = (unsigned)(pa.members * pa.panels);
-  PanelArgs pa2 = pa;
-  pa2.ablate = h->ablate;
-  {
-    EpiArgs tmp{};
-    phase_prof_begin(h, KID_PANEL, blocks, &tmp);
-    pa2.prof = tmp.prof;
-  }
-  {
-    LaunchScope ls(h, KID_PANEL);
-    hipLaunchKernelGGL(k_panel2_fwd_bwd<GROUPS>, dim3(blocks), dim3(256 * GROUPS), kLds, h->stream, pa2);
-  }
-  phase_prof_end(h, KID_PANEL, blocks, 256 * GROUPS);
-}
-
 static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs, float c,
                       const LossSink& sink) {
   const int64_t Bp = h->Bp;
@@ -711,11 +687,7 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   pa.loss = sink.loss; pa.loss_raw = sink.raw; pa.loss_stride = sink.stride; pa.S = h->S;
   pa.loss_scale = sink.scale; pa.lik_c = c; pa.st = sink.st;
   // 128-row panels at W = 512 (the feature panel staged in LDS when Fp = 64), 256-row panels at W = 256
-  if (h->W == 512 && h->Fp == 64 && h->panel2) {
-    pa.stagger = h->panel_stagger;
-    if (h->panel2 == 1) { pa.panels = (int32_t)(Bp / 64); launch_panel2<1>(h, pa); }
-    else { pa.panels = (int32_t)(Bp / 128); launch_panel2<2>(h, pa); }
-  } else if (h->W == 512) {
+  if (h->W == 512) {
     pa.panels = (int32_t)(Bp / panel_rows(8, 4));
     if (h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L")) launch_panel<8, 4, true>(h, pa);
     else launch_panel<8, 4, false>(h, pa);
@@ -960,8 +932,6 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
     }
     h->panel = can_panel && (want == 3 || want == 0);   // the default where it applies (C2: 2.71 -> 2.27 ms/step)
     if (h->panel) h->Bp = align_up(h->B, 256);
-    if (const char* p2 = getenv("BNF_PANEL2")) h->panel2 = atoi(p2);
-    if (const char* sg = getenv("BNF_PANEL_STAGGER")) h->panel_stagger = atoi(sg);
     // pipeline 0 (auto): layer kernels with the one-kernel last layer where the width allows;
     // pipeline 1: every layer kernel separate and every activation materialised (validation)
     const bool fl_ok = h->bf16 ? fused_last_supported<bf16_t>(h->W) : fused_last_supported<float>(h->W);

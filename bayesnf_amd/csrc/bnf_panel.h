@@ -70,7 +70,6 @@ struct PanelArgs {
   const StepState* st;            // graph replay: loss column offset
   unsigned long long* prof;       // -DBNF_ENABLE_ABLATE builds: per-workgroup phase clocks
   int32_t ablate;                 // perf experiments only (env BNF_ABLATE)
-  int32_t stagger;                // two-group kernel: initial delay of group 1, units of 64 cycles
 };
 
 // ---- fragment-major weight packing -------------------------------------------------
