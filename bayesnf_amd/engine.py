@@ -17,7 +17,21 @@ from . import distributed
 from .spec import NetSpec
 
 
+_warned_default_dtype = False
+
+
 def default_dtype(compute_dtype=None) -> str:
+  """'fp32' unless the caller or BNF_DTYPE says otherwise: the float32 engine is the parity path
+  (exact-f32 MFMA; it reproduces the reference's golden predictions), 'bf16' the throughput path
+  (bf16 contraction operands, f32 accumulation -- the numerics class of the reference's TPU runs;
+  ~5x the member-steps/s at the benchmark size).  Said once per process when the default applies."""
+  global _warned_default_dtype
+  if compute_dtype is None and 'BNF_DTYPE' not in os.environ and not _warned_default_dtype:
+    _warned_default_dtype = True
+    import warnings
+    warnings.warn("bayesnf_amd: compute_dtype defaults to 'fp32' (parity arithmetic). Pass "
+                  "compute_dtype='bf16' (or set BNF_DTYPE=bf16) for the ~5x faster bf16-MFMA engine.",
+                  stacklevel=3)
   dt = compute_dtype or os.environ.get('BNF_DTYPE', 'fp32')
   if dt not in _native.DTYPE:
     raise ValueError(f'compute_dtype must be one of {sorted(_native.DTYPE)}')
