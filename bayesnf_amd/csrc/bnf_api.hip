@@ -618,16 +618,21 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
 template <typename T>
 static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
   LaunchScope ls(h, KID_PACK);
-  hipLaunchKernelGGL(k_member_scalars, dim3(cdiv(nmem, 64)), dim3(64), 0, h->stream, h->nd, theta,
-                     (int64_t)h->P, (int32_t)nmem, h->scal);
-  for (int l = 0; l < h->L; ++l) {
-    const int n_in = (l == 0) ? h->F : h->W, n_pad = (l == 0) ? h->Fp : h->W;
-    const int64_t threads = (int64_t)n_pad * h->W / 8;
-    for (int which = 0; which < 2; ++which)
-      hipLaunchKernelGGL((k_pack_fragments<T>), dim3(cdiv(threads, 256), (unsigned)nmem), dim3(256), 0,
-                         h->stream, theta, (int64_t)h->P, h->nd.off_kernel[l], n_in, n_pad, h->W, which,
-                         (T*)(which == 0 ? h->Wf[l] : h->Wb[l]), h->pack_batch[l]);
+  PackJobs jb{};   // (the row-panel pipeline is a two-hidden-layer pipeline: bnf_create)
+  jb.n_layers = h->L; jb.W = h->W;
+  int tiles = 0;
+  for (int l = 0; l < h->L && l < 2; ++l) {
+    jb.off_kernel[l] = h->nd.off_kernel[l];
+    jb.n_in[l] = (l == 0) ? h->F : h->W;
+    jb.n_pad[l] = (l == 0) ? h->Fp : h->W;   // multiples of 64
+    jb.tile0[l] = tiles;
+    tiles += (jb.n_pad[l] / 64) * (h->W / 64);
+    jb.wf[l] = h->Wf[l]; jb.wb[l] = h->Wb[l]; jb.batch[l] = h->pack_batch[l];
   }
+  jb.tile0[2] = tiles;
+  if (h->L == 1) jb.tile0[1] = tiles;
+  hipLaunchKernelGGL((k_pack_layers<T>), dim3((unsigned)tiles, (unsigned)nmem), dim3(256), 0, h->stream,
+                     theta, (int64_t)h->P, jb);
 }
 
 // ---------------------------------------------------------------------------
@@ -658,7 +663,8 @@ static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
 static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs, float c,
                       const LossSink& sink) {
   const int64_t Bp = h->Bp;
-  run_pack_fragments<bf16_t>(h, theta, nmem);
+  hipLaunchKernelGGL(k_member_scalars, dim3(cdiv(nmem, 64)), dim3(64), 0, h->stream, h->nd, theta,
+                     (int64_t)h->P, (int32_t)nmem, h->scal);
   {
     LaunchScope ls(h, KID_FEAT);
     dim3 grid(cdiv(h->B, kFeatRows), (unsigned)nmem);
@@ -669,6 +675,7 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
                        h->y, h->scal, h->B, (bf16_t*)h->H0, Bp * h->Fp, (bf16_t*)h->H0t,
                        (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp);
   }
+  run_pack_fragments<bf16_t>(h, theta, nmem);
   PanelArgs pa{};
   pa.F = h->F; pa.Fp = h->Fp; pa.B = (int32_t)h->B; pa.members = nmem;
   pa.theta = theta; pa.theta_stride = h->P; pa.scal = h->scal;
@@ -1075,7 +1082,7 @@ int bnf_train(bnf_handle* h, int64_t epoch0, int64_t num_epochs, float* losses) 
         const hipError_t be = hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed);
         if (be != hipSuccess) {
           h->stream = user_stream;
-          return fail(BNF_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(be));
+            return fail(BNF_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(be));
         }
         LossSink sink{losses, num_epochs, 1.0f, nullptr, h->step_state};
         rc = h->bf16 ? step_map<bf16_t>(h, epoch0, 0, sink, true) : step_map<float>(h, epoch0, 0, sink, true);
