@@ -213,8 +213,8 @@ def make_config(net: _spec.NetSpec, *, device, dtype, mode, n_rows, batch,
     raise ValueError(f'more than {MAX_FREQS} seasonal frequencies')
   if net.interactions.shape[0] > MAX_INTERACT:
     raise ValueError(f'more than {MAX_INTERACT} interactions')
-  if net.width % 64 or net.width < 64:
-    raise ValueError('width must be a positive multiple of 64 on this backend')
+  if not 1 <= net.width <= 8192:
+    raise ValueError('width must be in 1..8192 on this backend')
   c = BnfConfig()
   c.abi_version = ABI_VERSION
   c.device = int(device)

@@ -80,6 +80,16 @@ struct bnf_handle {
   int Ev = 0;          // virtual members = members * S
   int S = 1;
   int L = 0, W = 0, F = 0, Fp = 0, P = 0;
+  // W: width the kernels run at (multiple of 64); Wt: the model's width.  Wt < W (pad): the
+  // forward / backward kernels read theta_pad (stride Pf = Pp) and accumulate into gradf (k_pad_params)
+  int Wt = 0;
+  bool pad = false;
+  int64_t Pf = 0, Pp = 0;
+  float* gradf = nullptr;
+  float* theta_pad = nullptr;
+  int32_t* pad_src = nullptr;
+  int32_t* fold_src = nullptr;
+  std::vector<int32_t> pad_src_h, fold_src_h;
   int64_t N = 0, B = 0, Bp = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;            // weight-gradient contractions overlap the dgrad chain
@@ -150,6 +160,13 @@ static size_t carve(bnf_handle* h, char* base) {
   const int nf2 = 2 * h->ft.n;
   const bool fo = h->cfg.forward_only != 0;
   h->grad = fo ? nullptr : (float*)take((size_t)Ev * P * 4);
+  h->gradf = h->grad;
+  if (h->pad) {
+    h->theta_pad = (float*)take((size_t)Ev * h->Pp * 4);
+    if (!fo) h->gradf = (float*)take((size_t)Ev * h->Pp * 4);
+    h->pad_src = (int32_t*)take((size_t)(h->Pp - P) * 4);
+    h->fold_src = (int32_t*)take((size_t)P * 4);
+  }
   if (h->cfg.mode == BNF_MODE_VI) h->theta_c = (float*)take((size_t)Ev * P * 4);
   h->stab = (float*)take((size_t)std::max<int64_t>(1, h->N * nf2) * 4);
   h->stab_pred = (float*)take((size_t)std::max<int64_t>(1, Bp * nf2) * 4);
@@ -376,11 +393,11 @@ template <typename T>
 static void run_pack(bnf_handle* h, const float* theta, int nmem) {
   LaunchScope ls(h, KID_PACK);
   hipLaunchKernelGGL(k_member_scalars, dim3(cdiv(nmem, 64)), dim3(64), 0, h->stream, h->nd, theta,
-                     (int64_t)h->P, (int32_t)nmem, h->scal);
+                     (int64_t)h->Pf, (int32_t)nmem, h->scal);
   for (int l = 0; l < h->L; ++l) {
     const int n_in = (l == 0) ? h->F : h->W, n_pad = (l == 0) ? h->Fp : h->W;
     dim3 grid((unsigned)((n_pad / 32) * (h->W / 32)), (unsigned)nmem);
-    hipLaunchKernelGGL((k_pack_weights<T>), grid, dim3(256), 0, h->stream, theta, (int64_t)h->P,
+    hipLaunchKernelGGL((k_pack_weights<T>), grid, dim3(256), 0, h->stream, theta, (int64_t)h->Pf,
                        h->nd.off_kernel[l], n_in, n_pad, h->W, (T*)h->Kn[l], (T*)h->Kt[l],
                        h->pack_batch[l]);
   }
@@ -421,8 +438,8 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
     g.members = nmem;
     EpiArgs ep{};
     ep.theta = theta;
-    ep.theta_stride = h->P;
-    ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->W));
+    ep.theta_stride = h->Pf;
+    ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->Wt));
     ep.off_bias = h->nd.off_bias[l];
     ep.off_layer_scale = h->nd.off_ls[l];
     ep.off_act_weight = h->nd.off_law;
@@ -464,8 +481,8 @@ static void run_wgrad_layer(bnf_handle* h, int nmem, int l, hipStream_t st) {
   sk = std::max(1, std::min(sk, std::max(1, nk / 4)));
   g.splitk = sk;
   EpiArgs ep{};
-  ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->W));
-  ep.grad = h->grad; ep.grad_stride = h->P; ep.off_out = h->nd.off_kernel[l]; ep.ld_f32 = h->W;
+  ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->Wt));
+  ep.grad = h->gradf; ep.grad_stride = h->Pf; ep.off_out = h->nd.off_kernel[l]; ep.ld_f32 = h->W;
   if (l == 0) launch_gemm_tn<T, 0>(h, KID_WGRAD0, g, ep, st);
   else launch_gemm_tn<T, 1>(h, KID_WGRAD, g, ep, st);
 }
@@ -496,7 +513,7 @@ static void run_wgrad(bnf_handle* h, int nmem) {
   wgrad_join(h);
 }
 
-// backward of one step: fills h->grad (likelihood part)
+// backward of one step: fills h->gradf (likelihood part)
 template <typename T>
 static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs,
                          int64_t rows, float c, const LossSink& sink) {
@@ -516,16 +533,16 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
     g.b_batch = h->pack_batch[l];
     g.M = (int)rows; g.N = h->W; g.K = g.a_ld; g.splitk = 1; g.members = nmem;
     EpiArgs ep{};
-    ep.theta = theta; ep.theta_stride = h->P;
-    ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->W));
+    ep.theta = theta; ep.theta_stride = h->Pf;
+    ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->Wt));
     ep.off_bias = h->nd.off_bias[l];
     ep.off_layer_scale = h->nd.off_ls[l];
     ep.off_act_weight = h->nd.off_law;
     ep.scal = h->scal; ep.scal_stride = kScalStride; ep.layer = l;
-    ep.off_ko = h->nd.off_kernel[L];
+    ep.off_ko = h->nd.off_kernel[L]; ep.inv_sw = 1.0f / sqrtf((float)h->Wt);
     ep.out_h = h->dZ[l];
     ep.act_batch = Bp * h->W; ep.ld = h->W;
-    ep.grad = h->grad; ep.grad_stride = h->P;
+    ep.grad = h->gradf; ep.grad_stride = h->Pf;
     ep.ybat = h->ybat; ep.row_batch = Bp;
     ep.out = h->out; ep.out_batch = Bp;
     ep.loss = sink.loss; ep.loss_raw = sink.raw; ep.loss_stride = sink.stride; ep.S = h->S;
@@ -538,10 +555,10 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
   } else {
     {
       RowLossArgs a{};
-      a.theta = theta; a.theta_stride = h->P; a.B = rows;
+      a.theta = theta; a.theta_stride = h->Pf; a.B = rows;
       a.vacc = h->vacc; a.vacc_batch = Bp; a.ybat = h->ybat;
       a.out = h->out; a.out_batch = Bp; a.dv = h->dv;
-      a.grad = h->grad; a.grad_stride = h->P;
+      a.grad = h->gradf; a.grad_stride = h->Pf;
       a.loss = sink.loss; a.loss_stride = sink.stride; a.S = h->S; a.loss_scale = sink.scale;
       a.c = c; a.loss_raw = sink.raw; a.st = sink.st;
       LaunchScope ls(h, KID_ROWLOSS);
@@ -550,10 +567,10 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
     }
     {
       LastBwdArgs a{};
-      a.theta = theta; a.theta_stride = h->P;
+      a.theta = theta; a.theta_stride = h->Pf;
       a.At = h->A[L - 1]; a.dZ = h->dZ[L - 1];
       a.act_batch = Bp * h->W; a.actt_batch = (int64_t)h->W * (Bp + kAtPad); a.ldt = (int32_t)(Bp + kAtPad);
-      a.dv = h->dv; a.dv_batch = Bp; a.grad = h->grad; a.grad_stride = h->P;
+      a.dv = h->dv; a.dv_batch = Bp; a.grad = h->gradf; a.grad_stride = h->Pf;
       a.n_row_tiles = (int32_t)((rows + 63) / 64);
       a.tiles_per_task = 4;
       const int tasks = (h->W / 64) * ((a.n_row_tiles + a.tiles_per_task - 1) / a.tiles_per_task);
@@ -572,11 +589,11 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
     g.B = h->Kn[l]; g.b_ld = h->W; g.b_batch = h->pack_batch[l];
     g.M = (int)rows; g.K = h->W; g.splitk = 1; g.members = nmem;
     EpiArgs ep{};
-    ep.theta = theta; ep.theta_stride = h->P;
-    ep.grad = h->grad; ep.grad_stride = h->P;
+    ep.theta = theta; ep.theta_stride = h->Pf;
+    ep.grad = h->gradf; ep.grad_stride = h->Pf;
     if (l > 0) {
       g.N = h->W;
-      ep.scale = 1.0f / sqrtf((float)h->W);
+      ep.scale = 1.0f / sqrtf((float)h->Wt);
       ep.off_bias = h->nd.off_bias[l - 1];
       ep.off_layer_scale = h->nd.off_ls[l - 1];
       ep.off_act_weight = h->nd.off_law;
@@ -606,8 +623,8 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
     dim3 grid(cdiv(rows, 256), (unsigned)nmem);
     const float* X = h->X;
     hipLaunchKernelGGL(k_feat_bwd, grid, dim3(256), 0, h->stream, h->nd, rs, X, h->stab, theta,
-                       (int64_t)h->P, h->scal, rows, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->grad,
-                       (int64_t)h->P);
+                       (int64_t)h->Pf, h->scal, rows, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->gradf,
+                       (int64_t)h->Pf);
   }
   wgrad_join(h);
 }
@@ -632,7 +649,7 @@ static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
   jb.tile0[2] = tiles;
   if (h->L == 1) jb.tile0[1] = tiles;
   hipLaunchKernelGGL((k_pack_layers<T>), dim3((unsigned)tiles, (unsigned)nmem), dim3(256), 0, h->stream,
-                     theta, (int64_t)h->P, jb);
+                     theta, (int64_t)h->Pf, jb);
 }
 
 // ---------------------------------------------------------------------------
@@ -664,7 +681,7 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
                       const LossSink& sink) {
   const int64_t Bp = h->Bp;
   hipLaunchKernelGGL(k_member_scalars, dim3(cdiv(nmem, 64)), dim3(64), 0, h->stream, h->nd, theta,
-                     (int64_t)h->P, (int32_t)nmem, h->scal);
+                     (int64_t)h->Pf, (int32_t)nmem, h->scal);
   {
     LaunchScope ls(h, KID_FEAT);
     dim3 grid(cdiv(h->B, kFeatRows), (unsigned)nmem);
@@ -677,8 +694,8 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   }
   run_pack_fragments<bf16_t>(h, theta, nmem);
   PanelArgs pa{};
-  pa.F = h->F; pa.Fp = h->Fp; pa.B = (int32_t)h->B; pa.members = nmem;
-  pa.theta = theta; pa.theta_stride = h->P; pa.scal = h->scal;
+  pa.F = h->F; pa.Fp = h->Fp; pa.B = (int32_t)h->B; pa.members = nmem; pa.Wt = h->Wt;
+  pa.theta = theta; pa.theta_stride = h->Pf; pa.scal = h->scal;
   pa.off_bias0 = h->nd.off_bias[0]; pa.off_bias1 = h->nd.off_bias[1]; pa.off_bias_out = h->nd.off_bias[2];
   pa.off_ko = h->nd.off_kernel[2]; pa.off_ls0 = h->nd.off_ls[0]; pa.off_ls1 = h->nd.off_ls[1];
   pa.off_os = h->nd.off_os; pa.off_law = h->nd.off_law; pa.off_lns = h->nd.off_lns;
@@ -690,7 +707,7 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   pa.H1 = (bf16_t*)h->H[0]; pa.dZ1 = (bf16_t*)h->dZ[1]; pa.dZ0 = (bf16_t*)h->dZ[0]; pa.act_batch = Bp * h->W;
   pa.dH0t = h->dH0; pa.dh0_batch = (int64_t)h->Fp * Bp; pa.ldt = (int32_t)Bp;
   pa.ybat = h->ybat; pa.row_batch = Bp; pa.out = h->out; pa.out_batch = Bp;
-  pa.grad = h->grad; pa.grad_stride = h->P;
+  pa.grad = h->gradf; pa.grad_stride = h->Pf;
   pa.loss = sink.loss; pa.loss_raw = sink.raw; pa.loss_stride = sink.stride; pa.S = h->S;
   pa.loss_scale = sink.scale; pa.lik_c = c; pa.st = sink.st;
   // 128-row panels at W = 512 (the feature panel staged in LDS when Fp = 64), 256-row panels at W = 256
@@ -706,10 +723,25 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
     LaunchScope ls(h, KID_FEATBWD);
     dim3 grid(cdiv(h->B, 256), (unsigned)nmem);
     hipLaunchKernelGGL(k_feat_bwd, grid, dim3(256), 0, h->stream, h->nd, rs, h->X, h->stab, theta,
-                       (int64_t)h->P, h->scal, h->B, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->grad,
-                       (int64_t)h->P);
+                       (int64_t)h->Pf, h->scal, h->B, h->dH0, (int64_t)h->Fp * Bp, (int32_t)Bp, h->gradf,
+                       (int64_t)h->Pf);
   }
   run_wgrad<bf16_t>(h, nmem);
+}
+
+// parameters as the forward / backward kernels read them (padded copy when the width is padded)
+static const float* fw_theta(bnf_handle* h, const float* theta, int nmem) {
+  if (!h->pad) return theta;
+  hipLaunchKernelGGL(k_pad_params, dim3(cdiv(h->Pp, 256), (unsigned)nmem), dim3(256), 0, h->stream, theta,
+                     (int64_t)h->P, h->theta_pad, h->Pp, h->pad_src);
+  return h->theta_pad;
+}
+// gradient of the padded copy -> gradient in the parameter layout (before the optimiser kernel)
+static void fold_grad(bnf_handle* h, int nmem) {
+  if (!h->pad) return;
+  hipLaunchKernelGGL(k_fold_grad, dim3(cdiv(h->P, 256), (unsigned)nmem), dim3(256), 0, h->stream, h->gradf,
+                     h->Pp, h->fold_src, h->grad, (int64_t)h->P);
+  (void)hipMemsetAsync(h->gradf, 0, (size_t)nmem * h->Pp * 4, h->stream);
 }
 
 static RowSrc make_rowsrc(const bnf_handle* h, int64_t epoch, int64_t step) {
@@ -738,13 +770,15 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
   const RowSrc rs = make_rowsrc(h, epoch, step);
   const int E = h->cfg.members;
   const float c = (float)((double)h->N / (double)h->B);
+  const float* thf = fw_theta(h, h->params, E);
   if (h->panel) {
-    run_panel(h, h->params, E, rs, c, sink);
+    run_panel(h, thf, E, rs, c, sink);
   } else {
-    run_pack<T>(h, h->params, E);
-    run_forward<T>(h, h->params, E, rs, h->X, h->stab, h->y, h->B, true);
-    run_backward<T>(h, h->params, E, rs, h->B, c, sink);
+    run_pack<T>(h, thf, E);
+    run_forward<T>(h, thf, E, rs, h->X, h->stab, h->y, h->B, true);
+    run_backward<T>(h, thf, E, rs, h->B, c, sink);
   }
+  fold_grad(h, E);
   AdamArgs a{};
   a.theta = h->params; a.m = h->state; a.v = h->state + (int64_t)E * h->P; a.grad = h->grad;
   a.stride = h->P; a.P = h->P; a.off_shape = h->nd.off_shape;
@@ -786,13 +820,15 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   const float kl = h->cfg.kl_weight;
   const float c = (float)((double)h->N / (double)h->B / (double)kl);
   LossSink sink{loss, loss_stride, kl / (float)S, nullptr};
+  const float* thf = fw_theta(h, h->theta_c, h->Ev);
   if (h->panel) {
-    run_panel(h, h->theta_c, h->Ev, rs, c, sink);
+    run_panel(h, thf, h->Ev, rs, c, sink);
   } else {
-    run_pack<T>(h, h->theta_c, h->Ev);
-    run_forward<T>(h, h->theta_c, h->Ev, rs, h->X, h->stab, h->y, h->B, true);
-    run_backward<T>(h, h->theta_c, h->Ev, rs, h->B, c, sink);
+    run_pack<T>(h, thf, h->Ev);
+    run_forward<T>(h, thf, h->Ev, rs, h->X, h->stab, h->y, h->B, true);
+    run_backward<T>(h, thf, h->Ev, rs, h->B, c, sink);
   }
+  fold_grad(h, h->Ev);
   ViAdamArgs a{};
   const int64_t EP = (int64_t)E * h->P;
   a.mu = mu; a.rho = rho;
@@ -845,8 +881,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   if (cfg->mode != BNF_MODE_MAP && cfg->mode != BNF_MODE_VI) return fail(BNF_ERR_INVALID, "mode");
   if (cfg->n_inputs < 1 || cfg->n_inputs > BNF_MAX_INPUTS) return fail(BNF_ERR_INVALID, "n_inputs");
   if (cfg->depth < 1 || cfg->depth > BNF_MAX_LAYERS) return fail(BNF_ERR_INVALID, "depth");
-  if (cfg->width < 64 || cfg->width % 64 != 0)
-    return fail(BNF_ERR_INVALID, "width %d must be a positive multiple of 64", cfg->width);
+  if (cfg->width < 1 || cfg->width > 8192) return fail(BNF_ERR_INVALID, "width %d (1..8192)", cfg->width);
   if (cfg->n_groups < 1 || cfg->n_groups > BNF_MAX_GROUPS) return fail(BNF_ERR_INVALID, "n_groups");
   if (cfg->n_freqs < 0 || cfg->n_freqs > BNF_MAX_FREQS) return fail(BNF_ERR_INVALID, "n_freqs");
   if (cfg->n_interact < 0 || cfg->n_interact > BNF_MAX_INTERACT)
@@ -868,7 +903,9 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   h->es = h->bf16 ? 2 : 4;
   h->S = S;
   h->Ev = cfg->members * S;
-  h->L = cfg->depth; h->W = cfg->width; h->F = cfg->n_features; h->P = cfg->n_params;
+  h->L = cfg->depth; h->Wt = cfg->width; h->W = (int)align_up(cfg->width, 64);
+  h->pad = h->W != h->Wt;
+  h->F = cfg->n_features; h->P = cfg->n_params;
   h->Fp = (int)align_up(h->F, 64);
   h->N = cfg->n_rows; h->B = cfg->batch; h->Bp = align_up(h->B, 128);
   {
@@ -883,7 +920,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   }
   NetDev& nd = h->nd;
   memset(&nd, 0, sizeof(nd));
-  nd.D = cfg->n_inputs; nd.F = h->F; nd.Fp = h->Fp; nd.W = h->W; nd.depth = h->L; nd.P = h->P;
+  nd.D = cfg->n_inputs; nd.F = h->F; nd.Fp = h->Fp; nd.W = h->W; nd.Wt = h->Wt; nd.depth = h->L; nd.P = h->P;
   nd.n_groups = cfg->n_groups; nd.n_freqs = cfg->n_freqs; nd.n_interact = cfg->n_interact;
   nd.obs = cfg->obs_model;
   for (int g = 0; g < cfg->n_groups; ++g) {
@@ -912,6 +949,34 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   for (int l = 0; l <= h->L; ++l) {
     nd.off_bias[l] = cfg->off_bias[l];
     nd.off_kernel[l] = cfg->off_kernel[l];
+  }
+  h->Pf = h->P;
+  if (h->pad) {
+    // padded copies of the width-dependent leaves behind the P verbatim floats (k_pad_params)
+    const int W = h->W, Wt = h->Wt;
+    int64_t pos = h->P;
+    h->fold_src_h.resize((size_t)h->P);
+    for (int64_t i = 0; i < h->P; ++i) h->fold_src_h[(size_t)i] = (int32_t)i;
+    auto leaf = [&](int32_t off_true, int rows_t, int cols_t, int rows_p, int cols_p) {
+      const int32_t off_pad = (int32_t)pos;
+      for (int r = 0; r < rows_p; ++r)
+        for (int c = 0; c < cols_p; ++c) {
+          const bool in = r < rows_t && c < cols_t;
+          const int32_t src = in ? off_true + r * cols_t + c : -1;
+          h->pad_src_h.push_back(src);
+          if (in) h->fold_src_h[(size_t)src] = (int32_t)pos;
+          ++pos;
+        }
+      return off_pad;
+    };
+    for (int l = 0; l < h->L; ++l) {
+      nd.off_bias[l] = leaf(cfg->off_bias[l], 1, Wt, 1, W);
+      const int rt = (l == 0) ? h->F : Wt, rp = (l == 0) ? h->F : W;
+      nd.off_kernel[l] = leaf(cfg->off_kernel[l], rt, Wt, rp, W);
+    }
+    nd.off_kernel[h->L] = leaf(cfg->off_kernel[h->L], Wt, 1, W, 1);   // output kernel (W, 1)
+    while (pos % 4) { h->pad_src_h.push_back(-1); ++pos; }
+    h->Pp = pos; h->Pf = pos;
   }
   for (int l = 0; l < h->L; ++l) nd.off_ls[l] = cfg->off_layer_scale[l];
   nd.off_os = cfg->off_output_scale; nd.off_lsa = cfg->off_lsa; nd.off_law = cfg->off_act_weight;
@@ -1004,10 +1069,15 @@ int bnf_bind(bnf_handle* h, void* params, void* opt_state, void* workspace, cons
   // which entries are Dense kernels (rank-2 leaves)
   std::vector<uint8_t> mm((size_t)h->P, 0);
   for (int l = 0; l <= h->L; ++l) {
-    const int64_t n_in = (l == 0) ? h->F : h->W, n_out = (l == h->L) ? 1 : h->W;
-    for (int64_t i = 0; i < n_in * n_out; ++i) mm[(size_t)h->nd.off_kernel[l] + i] = 1;
+    const int64_t n_in = (l == 0) ? h->F : h->Wt, n_out = (l == h->L) ? 1 : h->Wt;
+    for (int64_t i = 0; i < n_in * n_out; ++i) mm[(size_t)h->cfg.off_kernel[l] + i] = 1;   // (parameter layout, not the padded copy's)
   }
   HIPCHK(hipMemcpyAsync(h->is_matrix, mm.data(), (size_t)h->P, hipMemcpyHostToDevice, h->stream));
+  if (h->pad) {
+    HIPCHK(hipMemcpyAsync(h->pad_src, h->pad_src_h.data(), h->pad_src_h.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->fold_src, h->fold_src_h.data(), h->fold_src_h.size() * 4, hipMemcpyHostToDevice, h->stream));
+    if (h->gradf != h->grad) HIPCHK(hipMemsetAsync(h->gradf, 0, (size_t)h->Ev * h->Pp * 4, h->stream));
+  }
   HIPCHK(hipStreamSynchronize(h->stream));  // mm is a stack-owned host buffer
   if (h->ft.n > 0 && X) {
     hipLaunchKernelGGL(k_seasonal_table, dim3(cdiv(h->N, 256)), dim3(256), 0, h->stream, X, h->N,
@@ -1147,7 +1217,7 @@ int bnf_forward(bnf_handle* h, const float* theta, int64_t n_members, const floa
   rs.mode = 0; rs.S = 1;
   for (int64_t m0 = 0; m0 < n_members; m0 += mem_chunk) {
     const int nm = (int)std::min<int64_t>(mem_chunk, n_members - m0);
-    const float* th = theta + m0 * h->P;
+    const float* th = fw_theta(h, theta + m0 * h->P, nm);
     if (h->bf16) run_pack<bf16_t>(h, th, nm); else run_pack<float>(h, th, nm);
     for (int64_t r0 = 0; r0 < n_rows; r0 += row_chunk) {
       const int64_t rows = std::min<int64_t>(row_chunk, n_rows - r0);
@@ -1156,7 +1226,7 @@ int bnf_forward(bnf_handle* h, const float* theta, int64_t n_members, const floa
         hipLaunchKernelGGL(k_seasonal_table, dim3(cdiv(rows, 256)), dim3(256), 0, h->stream, Xc, rows,
                            h->nd.D, h->ft, h->stab_pred);
       RowLossArgs a{};
-      a.theta = th; a.theta_stride = h->P; a.B = rows;
+      a.theta = th; a.theta_stride = h->Pf; a.B = rows;
       a.vacc = h->vacc; a.vacc_batch = h->Bp;
       a.out = loc + m0 * n_rows + r0; a.out_batch = n_rows;
       a.S = 1;
@@ -1286,10 +1356,10 @@ int bnf_debug_activation(bnf_handle* h, int32_t what, float* out) {
   const void* src = nullptr;
   int64_t batch = 0; int ld = 0, cols = 0, transposed = 0;
   if (what == 0) { src = h->H0; batch = Bp * h->Fp; ld = h->Fp; cols = h->F; }
-  else if (what >= 1 && what < h->L) { src = h->H[what - 1]; batch = Bp * h->W; ld = h->W; cols = h->W; }
+  else if (what >= 1 && what < h->L) { src = h->H[what - 1]; batch = Bp * h->W; ld = h->W; cols = h->Wt; }
   else if (what >= 100 && what < 100 + h->L) {
-    src = h->A[what - 100]; batch = (int64_t)h->W * (Bp + kAtPad); ld = (int)(Bp + kAtPad); cols = h->W; transposed = 1;
-  } else if (what >= 300 && what < 300 + h->L) { src = h->dZ[what - 300]; batch = Bp * h->W; ld = h->W; cols = h->W; }
+    src = h->A[what - 100]; batch = (int64_t)h->W * (Bp + kAtPad); ld = (int)(Bp + kAtPad); cols = h->Wt; transposed = 1;
+  } else if (what >= 300 && what < 300 + h->L) { src = h->dZ[what - 300]; batch = Bp * h->W; ld = h->W; cols = h->Wt; }
   else if (what == 200) {
     for (int e = 0; e < h->Ev; ++e)
       HIPCHK(hipMemcpyAsync(out + (int64_t)e * B, h->out + (int64_t)e * Bp, (size_t)B * 4,
@@ -1491,7 +1561,7 @@ void bnf_comm_destroy(bnf_comm* c) {
 
 double bnf_kernel_flops(const bnf_handle* h, const char* name) {
   if (!h || !name) return 0.0;
-  const double Ev = h->Ev, B = (double)h->B, W = h->W, F = h->F;
+  const double Ev = h->Ev, B = (double)h->B, W = h->Wt, F = h->F;
   if (!strcmp(name, "gemm_fwd_l0") || !strcmp(name, "gemm_dgrad0") || !strcmp(name, "gemm_wgrad_l0"))
     return 2.0 * Ev * B * F * W;
   if (!strcmp(name, "gemm_fwd") || !strcmp(name, "gemm_dgrad") || !strcmp(name, "gemm_wgrad"))

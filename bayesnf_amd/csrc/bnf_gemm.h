@@ -59,6 +59,7 @@ struct EpiArgs {
   float* vdot;         // FWD (last layer): (members, vdot_batch) += H . k_o (un-normalised)
   int64_t vdot_batch;
   int32_t off_ko;      // offset of the output-layer kernel
+  float inv_sw;        // EPI_LAST: 1 / sqrt(model width)
   int64_t act_batch;   // elements between members, row-major buffers
   int64_t actt_batch;  // elements between members, transposed buffers
   int32_t ld, ldt;
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     // would otherwise spend ~200 VALU instructions on two log1p / exp expansions)
     const float gamma = ep.scal[(int64_t)e * ep.scal_stride + ep.layer];
     const float alpha = ep.scal[(int64_t)e * ep.scal_stride + BNF_MAX_LAYERS];
-    const float inv_sw = 1.0f / sqrtf((float)g.N);
+    const float inv_sw = ep.inv_sw;   // 1 / sqrt(model width): fan-in of the output layer
     T* tile = reinterpret_cast<T*>(smem);
     constexpr int kTileBytes = kBM * kPitch * (int)sizeof(T), kDotBytes = kWaves * 64 * kRowDotPitch * 4;
     float* xs = reinterpret_cast<float*>(smem + (kTileBytes > kDotBytes ? kTileBytes : kDotBytes));

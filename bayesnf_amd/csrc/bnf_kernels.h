@@ -28,7 +28,9 @@ __device__ __forceinline__ void sincos_rev(float x, float* s, float* c) {
 }
 
 struct NetDev {
-  int32_t D, F, Fp, W, depth, P, n_groups, n_freqs, n_interact, obs;
+  // W: width the kernels run at (a multiple of 64); Wt: the model's width (fan-in of the layers above
+  // layer 0).  Wt < W: the kernels see zero-padded copies of the width-dependent leaves (k_pad_params).
+  int32_t D, F, Fp, W, Wt, depth, P, n_groups, n_freqs, n_interact, obs;
   int32_t group_kind[BNF_MAX_GROUPS], group_arg[BNF_MAX_GROUPS], group_ncols[BNF_MAX_GROUPS],
       group_col0[BNF_MAX_GROUPS], group_scale_off[BNF_MAX_GROUPS];
   int32_t fdeg[BNF_MAX_INPUTS];
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void k_row_loss(NetDev nd, RowLossArgs a) {
   float ll = 0.f, s_doutv = 0.f, s_dvsum = 0.f, s_par = 0.f, s_infl = 0.f;
   if (r < a.B) {
     const int64_t vi = (int64_t)e * a.vacc_batch + r;
-    const float v = a.vacc[vi] * (1.0f / sqrtf((float)nd.W)) + th[nd.off_bias[L]];
+    const float v = a.vacc[vi] * (1.0f / sqrtf((float)nd.Wt)) + th[nd.off_bias[L]];
     a.vacc[vi] = 0.f;
     const float out = gam_o * v;
     a.out[(int64_t)e * a.out_batch + r] = out;
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void k_last_bwd(NetDev nd, const LastBwdArg
   const int rg = lane & 7, cg = lane >> 3;
   const int j0 = strip * 64 + cg * 8;
   const float* th = a.theta + (int64_t)e * a.theta_stride;
-  const float inv_sw = 1.0f / sqrtf((float)W);
+  const float inv_sw = 1.0f / sqrtf((float)nd.Wt);
   const float gamma = softplusf(th[nd.off_ls[l]]);
   const float alpha = sigmoidf(th[nd.off_law]);
   const T* __restrict__ At = reinterpret_cast<const T*>(a.At) + (int64_t)e * a.actt_batch;
@@ -571,6 +573,39 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
     const int j = tj * 32 + ty + s * 8, i = ti * 32 + tx;
     if (i < n_pad) Elem<T>::store(kt + (int64_t)j * n_pad + i, tile[tx][ty + s * 8]);
   }
+}
+
+// ---------------------------------------------------------------------------
+// Widths that are not a multiple of 64 (the reference accepts any: spatiotemporal.py:217-232).
+// The contraction kernels run at the padded width W on a padded COPY of the parameters:
+//   theta_pad[e] = [ theta[e] (P floats, verbatim) | padded Dense biases / kernels (zeros in the pad) ]
+// NetDev's bias / kernel offsets point into the second part, every other leaf is read from the
+// first.  Zero pad => the extra hidden units are exactly 0 in the forward pass (act(0) = 0) and
+// carry exactly 0 gradient, so the model is the width-Wt model; fan-in scales use Wt.  The
+// gradient comes back through the inverse map.  Optimiser, prior, initialisation and the VI
+// sampler only ever see the true layout.
+// ---------------------------------------------------------------------------
+__global__ void k_pad_params(const float* __restrict__ theta, int64_t P, float* __restrict__ theta_pad,
+                             int64_t Pp, const int32_t* __restrict__ pad_src) {
+  const int e = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Pp) return;
+  const float* th = theta + (int64_t)e * P;
+  float v;
+  if (j < P) v = th[j];
+  else {
+    const int32_t src = pad_src[j - P];
+    v = src >= 0 ? th[src] : 0.f;
+  }
+  theta_pad[(int64_t)e * Pp + j] = v;
+}
+// grad[e][i] = grad_pad[e][fold_src[i]]; the padded gradient is cleared for the next step's atomics
+__global__ void k_fold_grad(float* __restrict__ grad_pad, int64_t Pp, const int32_t* __restrict__ fold_src,
+                            float* __restrict__ grad, int64_t P) {
+  const int e = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  grad[(int64_t)e * P + i] = grad_pad[(int64_t)e * Pp + fold_src[i]];
 }
 
 // ---------------------------------------------------------------------------

@@ -36,6 +36,7 @@ namespace bnf {
 
 struct PanelArgs {
   int32_t F, Fp, B, panels, members;
+  int32_t Wt;                     // model width (fan-in of layer 1 and of the output layer); <= the kernel's W
   const float* theta;
   int64_t theta_stride;
   const float* scal;              // k_member_scalars table (kScalStride per member)
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   const float* th = a.theta + (int64_t)e * a.theta_stride;
   const float* sc = a.scal + (int64_t)e * kScalStride;
   const float gamma0 = sc[0], gamma1 = sc[1], alpha = sc[BNF_MAX_LAYERS];
-  const float inv_sw = 1.0f / sqrtf((float)W), inv_sf = 1.0f / sqrtf((float)a.F);
+  const float inv_sw = 1.0f / sqrtf((float)a.Wt), inv_sf = 1.0f / sqrtf((float)a.F);
   float* gr = a.grad + (int64_t)e * a.grad_stride;
   // per-member scalars of the row phase and of the serial tails, fetched and transformed now (uniform):
   // a lone thread reaching for them later pays a full memory latency with the workgroup waiting

@@ -16,7 +16,8 @@ Differences a caller can see:
     full-batch fit reproduces the reference's golden predictions); minibatch shuffles
     and everything VI draws come from this package's counter-based generator.
   * limits of the HIP engine, checked when the estimator is constructed / fitted
-    (the reference accepts any size): `width` a multiple of 64; `depth` <= 8;
+    (the reference accepts any size): `depth` <= 8 (any `width` up to 8192 -- widths that are
+    not a multiple of 64 run zero-padded inside the engine, same model and parameters);
     at most 8 feature columns, 96 distinct seasonal frequencies, 16 interactions;
     at most 512 (fp32: 256) features in total; `batch_size` <= number of rows.
   * the leading `(num_devices, ensemble_size // num_devices)` dimensions use
@@ -278,9 +279,8 @@ class BayesianNeuralFieldEstimator:
   def _check_engine_limits(self, n_inputs=None):
     """The HIP engine's hard limits, reported here with the estimator's own argument names
     instead of as an error code from deep inside `fit` (include/bnf.h BNF_MAX_*)."""
-    if not isinstance(self.width, (int, np.integer)) or self.width < 64 or self.width % 64:
-      raise ValueError(f'width={self.width}: the MI355X engine needs a positive multiple of 64 '
-                       '(MFMA tile granularity); the reference default 512 and its dataset configs qualify')
+    if not isinstance(self.width, (int, np.integer)) or not 1 <= self.width <= 8192:
+      raise ValueError(f'width={self.width}: the MI355X engine supports widths 1..8192')
     if not 1 <= int(self.depth) <= 8:
       raise ValueError(f'depth={self.depth}: the MI355X engine supports 1..8 hidden layers')
     if n_inputs is not None and n_inputs > 8:

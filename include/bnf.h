@@ -70,7 +70,9 @@ typedef struct bnf_config {
 
   /* network (models.py:197-273) */
   int32_t n_inputs;         /* D */
-  int32_t width;            /* W, multiple of 64 */
+  int32_t width;            /* W, 1..8192 (the kernels run at the next multiple of 64 on zero-padded
+                               copies of the width-dependent leaves; parameters, gradients and
+                               optimiser state keep the reference's shapes) */
   int32_t depth;            /* hidden layers, 1..BNF_MAX_LAYERS */
   int32_t n_features;       /* F */
   int32_t n_params;         /* P */

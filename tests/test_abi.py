@@ -61,8 +61,13 @@ def test_make_config_roundtrip():
   assert c.off_kernel[2] == net.offset('Dense_2/kernel')
   assert list(c.interact[0]) == [0, 1] and c.n_freqs == 12
   assert abs(c.freq[2] - 1 / 52.1775) < 1e-7
+  # any width is accepted (the engine pads to the next multiple of 64 internally); 0 is not
+  c100 = _native.make_config(NetSpec(width=100, depth=1, input_scales=[1], fourier_degrees=[1],
+                                     interactions=[]), device=0, dtype='fp32', mode=0, n_rows=4,
+                             batch=4, members=1, member_offset=0, seed=0)
+  assert c100.width == 100
   with pytest.raises(ValueError):
-    _native.make_config(NetSpec(width=100, depth=1, input_scales=[1], fourier_degrees=[1],
+    _native.make_config(NetSpec(width=0, depth=1, input_scales=[1], fourier_degrees=[1],
                                 interactions=[]), device=0, dtype='fp32', mode=0, n_rows=4,
                         batch=4, members=1, member_offset=0, seed=0)
 

@@ -195,12 +195,14 @@ def test_evaluate_tables_match_published_configs():
 
 def test_engine_limits_are_reported_at_construction():
   """Hard limits of the HIP engine surface as ValueErrors naming the estimator argument
-  (the reference accepts any width / depth; see the module docstring of spatiotemporal.py)."""
+  (the reference accepts any depth / column count; see the module docstring of spatiotemporal.py).
+  Any width is accepted, like the reference (widths off the 64 grid run zero-padded in the engine)."""
   import pytest as _pytest
   from bayesnf_amd import BayesianNeuralFieldMAP
   kw = dict(feature_cols=['t', 'x'], target_col='y', timetype='float')
-  with _pytest.raises(ValueError, match='width=100'):
-    BayesianNeuralFieldMAP(width=100, **kw)
+  BayesianNeuralFieldMAP(width=100, **kw)
+  with _pytest.raises(ValueError, match='width=0'):
+    BayesianNeuralFieldMAP(width=0, **kw)
   with _pytest.raises(ValueError, match='depth=9'):
     BayesianNeuralFieldMAP(depth=9, **kw)
   with _pytest.raises(ValueError, match='feature columns'):
