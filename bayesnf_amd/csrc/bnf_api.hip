@@ -90,6 +90,10 @@ struct bnf_handle {
   int32_t* pad_src = nullptr;
   int32_t* fold_src = nullptr;
   std::vector<int32_t> pad_src_h, fold_src_h;
+  // row-panel kernel, H0L variant: per-column table of the fused featurisation backward (bnf_panel.h)
+  int32_t* fbmeta = nullptr;
+  std::vector<int32_t> fbmeta_h;
+  int fb_in_group = -1;
   int64_t N = 0, B = 0, Bp = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;            // weight-gradient contractions overlap the dgrad chain
@@ -201,6 +205,7 @@ static size_t carve(bnf_handle* h, char* base) {
   h->step_state = (StepState*)take(sizeof(StepState));
   h->dbg_a = (float*)take(256);
   h->is_matrix = (uint8_t*)take((size_t)P);
+  h->fbmeta = h->fbmeta_h.empty() ? nullptr : (int32_t*)take(h->fbmeta_h.size() * 4);
   return off;
 }
 
@@ -693,6 +698,7 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
                        (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp);
   }
   run_pack_fragments<bf16_t>(h, theta, nmem);
+  bool feat_bwd_fused = false;
   PanelArgs pa{};
   pa.F = h->F; pa.Fp = h->Fp; pa.B = (int32_t)h->B; pa.members = nmem; pa.Wt = h->Wt;
   pa.theta = theta; pa.theta_stride = h->Pf; pa.scal = h->scal;
@@ -713,12 +719,19 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   // 128-row panels at W = 512 (the feature panel staged in LDS when Fp = 64), 256-row panels at W = 256
   if (h->W == 512) {
     pa.panels = (int32_t)(Bp / panel_rows(8, 4));
-    if (h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L")) launch_panel<8, 4, true>(h, pa);
-    else launch_panel<8, 4, false>(h, pa);
+    if (h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L")) {
+      pa.fbmeta = h->fbmeta; pa.off_lsa = h->nd.off_lsa; pa.n_groups = h->nd.n_groups; pa.n_inputs = h->nd.D;
+      pa.fb_in_group = h->fb_in_group;
+      feat_bwd_fused = h->fbmeta != nullptr;
+      launch_panel<8, 4, true>(h, pa);
+    } else {
+      launch_panel<8, 4, false>(h, pa);
+    }
   } else {
     pa.panels = (int32_t)(Bp / panel_rows(4, 4));
     launch_panel<4, 4, false>(h, pa);
   }
+  if (!feat_bwd_fused)
   {
     LaunchScope ls(h, KID_FEATBWD);
     dim3 grid(cdiv(h->B, 256), (unsigned)nmem);
@@ -1011,6 +1024,49 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
     // its contraction depth is Fp <= 128: cheaper to redo than to write + gather A_0^T
     h->recompute_a0 = !cfg->forward_only && !h->panel && want == 0 && h->L >= 2 && h->Fp <= 128;
   }
+  if (h->panel && h->W == 512 && h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L") &&
+      !(getenv("BNF_PANEL_FEATBWD") && atoi(getenv("BNF_PANEL_FEATBWD")) == 0)) {
+    // fused featurisation backward of the H0L panel kernel: what each feature column contributes
+    int in_group = -1;
+    for (int g = 0; g < cfg->n_groups; ++g)
+      if (cfg->group_kind[g] == BNF_GROUP_INPUT) in_group = g;
+    if (in_group >= 0) {
+      std::vector<int32_t>& m = h->fbmeta_h;
+      m.assign(64 * 4 + BNF_MAX_GROUPS, 0);
+      auto put = [&](int col, int kind, int g, int d1, int d2, int partner, int ucol, float coef) {
+        m[4 * col] = kind | (g << 8) | (d1 << 16) | (d2 << 24);
+        m[4 * col + 1] = partner | (ucol << 8);
+        memcpy(&m[4 * col + 2], &coef, 4);
+      };
+      for (int c = 0; c < 64; ++c) put(c, kFbNone, 0xff, 0xff, 0xff, 0, 0, 0.f);
+      const int cin = cfg->group_col0[in_group];
+      for (int g = 0; g < cfg->n_groups; ++g) {
+        const int c0 = cfg->group_col0[g], nc = cfg->group_ncols[g];
+        m[256 + g] = cfg->group_scale_off[g];
+        switch (cfg->group_kind[g]) {
+          case BNF_GROUP_INPUT:
+            for (int d = 0; d < nc; ++d) put(c0 + d, kFbInput, g, d, 0xff, 0, 0, 0.f);
+            break;
+          case BNF_GROUP_FOURIER: {
+            const int deg = nc / 2, d = cfg->group_arg[g];
+            for (int k = 0; k < deg; ++k) {
+              const float w = 6.28318530717958647692f * (float)(1u << k);
+              put(c0 + k, kFbFourier, g, d, 0xff, c0 + deg + k, cin + d, -w);
+              put(c0 + deg + k, kFbFourier, g, d, 0xff, c0 + k, cin + d, w);
+            }
+            break;
+          }
+          case BNF_GROUP_SEASONAL:
+            for (int j = 0; j < nc; ++j) put(c0 + j, kFbNone, g, 0xff, 0xff, 0, 0, 0.f);
+            break;
+          default:
+            for (int k = 0; k < nc; ++k)
+              put(c0 + k, kFbInter, g, cfg->interact[k][0], cfg->interact[k][1], 0, 0, 0.f);
+        }
+      }
+      h->fb_in_group = in_group;
+    }
+  }
   h->ws_bytes = carve(h, nullptr);
   *out = h;
   return BNF_OK;
@@ -1073,6 +1129,8 @@ int bnf_bind(bnf_handle* h, void* params, void* opt_state, void* workspace, cons
     for (int64_t i = 0; i < n_in * n_out; ++i) mm[(size_t)h->cfg.off_kernel[l] + i] = 1;   // (parameter layout, not the padded copy's)
   }
   HIPCHK(hipMemcpyAsync(h->is_matrix, mm.data(), (size_t)h->P, hipMemcpyHostToDevice, h->stream));
+  if (h->fbmeta)
+    HIPCHK(hipMemcpyAsync(h->fbmeta, h->fbmeta_h.data(), h->fbmeta_h.size() * 4, hipMemcpyHostToDevice, h->stream));
   if (h->pad) {
     HIPCHK(hipMemcpyAsync(h->pad_src, h->pad_src_h.data(), h->pad_src_h.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->fold_src, h->fold_src_h.data(), h->fold_src_h.size() * 4, hipMemcpyHostToDevice, h->stream));

@@ -71,7 +71,15 @@ struct PanelArgs {
   const StepState* st;            // graph replay: loss column offset
   unsigned long long* prof;       // -DBNF_ENABLE_ABLATE builds: per-workgroup phase clocks
   int32_t ablate;                 // perf experiments only (env BNF_ABLATE)
+  // H0L variant: the featurisation backward (d feature scales, d log_scale_adjustment: SURVEY A.3,
+  // k_feat_bwd) is finished here from the dH0 tiles in registers and the feature panel in LDS;
+  // dH0^T is then not written at all.  fbmeta: per feature column 4 words {kind | group << 8 |
+  // d1 << 16 | d2 << 24, partner | ucol << 8, coefficient (float bits), 0} followed by the
+  // theta offsets of the BNF_MAX_GROUPS group scales (build_featbwd_meta in bnf_api.hip).
+  const int32_t* fbmeta;
+  int32_t off_lsa, n_groups, n_inputs, fb_in_group;   // fb_in_group: feature group of the raw inputs
 };
+constexpr int kFbNone = 0, kFbInput = 1, kFbFourier = 2, kFbInter = 3;
 
 // ---- fragment-major weight packing -------------------------------------------------
 // Wp[nt][ks][lane][8] : lane l of fragment (nt, ks) holds Bt[nt*32 + (l&31)][ks*16 + (l>>5)*8 + 0..7]
@@ -275,6 +283,10 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   // the row phase's target value, fetched now (one thread per row; rows >= B read nothing)
   const float y_row = (tid < BM && m0 + tid < a.B) ? a.ybat[(int64_t)e * a.row_batch + m0 + tid] : 0.f;
 
+  float* s_grp = s_sc + 64;                 // [BNF_MAX_GROUPS + BNF_MAX_INPUTS] sums of the fused featurisation backward
+  if constexpr (H0L) {
+    if (tid < BNF_MAX_GROUPS + BNF_MAX_INPUTS) s_grp[tid] = 0.f;   // (ordered by the barriers of the phases below)
+  }
   // fragment-major features: the fragment of (32-row block, k step) is 1 KiB, blocks are Fp/16 KiB apart
   const char* h0p = reinterpret_cast<const char*>(a.H0 + (int64_t)e * a.h0_batch + (int64_t)m0 * a.Fp) +
                     (size_t)(rbase / 32) * KS0 * 1024;                     // uniform; + i blocks, + lane * 16
@@ -737,11 +749,72 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb[u], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb[u + 1], c1, 0, 0, 0);
       }
+      if constexpr (H0L) {
+        if (a.fbmeta) {
+          // featurisation backward on the tile: with H0 = softplus(scale_g) G,
+          //   d scale_g            ~ sum_r dH0[r][f] H0[r][f]                       (every column of group g)
+          //   d lsa_d (input / interaction columns)  ~ the same products
+          //   d lsa_d (Fourier cos / sin column k)   ~ -+ 2 pi 2^k sum_r dH0[r][f] H0[r][partner] u_d[r],
+          //                                            u_d = H0[r][input column d] / softplus(scale_in)
+          const int f = ni * 32 + frow;
+          const int4 md = *reinterpret_cast<const int4*>(a.fbmeta + 4 * f);
+          const char* hc = h0s + (mi * 32 + 4 * kg) * kH0Pitch;
+          const int o_f = f * 2, o_p = (md.y & 0xff) * 2, o_u = ((md.y >> 8) & 0xff) * 2;
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const char* hr = hc + (8 * rg + j) * kH0Pitch;
+              const float d = c0[rg * 4 + j] + c1[rg * 4 + j];
+              const float hf = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(hr + o_f));
+              const float hp = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(hr + o_p));
+              const float hu = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(hr + o_u));
+              s1 += d * hf;
+              s2 += d * hp * hu;
+            }
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (lane < 32) {   // this wave is the only writer of (mi, f)
+            s_col[W + mi * 64 + f] = s1 * inv_sf;
+            s_col[W + 256 + mi * 64 + f] = s2 * inv_sf;
+          }
+          continue;          // dH0^T itself is not needed any more
+        }
+      }
       float* col_ptr = dh0 + (int64_t)(ni * 32 + frow) * a.ldt + m0 + mi * 32 + 4 * kg;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg)
         store4(col_ptr + 8 * rg, (c0[rg * 4] + c1[rg * 4]) * inv_sf, (c0[rg * 4 + 1] + c1[rg * 4 + 1]) * inv_sf,
                (c0[rg * 4 + 2] + c1[rg * 4 + 2]) * inv_sf, (c0[rg * 4 + 3] + c1[rg * 4 + 3]) * inv_sf);
+    }
+  }
+  if constexpr (H0L) {
+    if (a.fbmeta) {
+      static_assert(!H0L || (BM == 128 && W >= 512), "fused featurisation backward: 4 row tiles x 64 columns in s_col[W..2W)");
+      lds_barrier();
+      if (wave == 0) {
+        const int f = opaque_lane(tid) & 63;
+        const int4 md = *reinterpret_cast<const int4*>(a.fbmeta + 4 * f);
+        const float t1 = (s_col[W + f] + s_col[W + 64 + f]) + (s_col[W + 128 + f] + s_col[W + 192 + f]);
+        const float t2 = (s_col[W + 256 + f] + s_col[W + 320 + f]) + (s_col[W + 384 + f] + s_col[W + 448 + f]);
+        const int kind = md.x & 0xff, g = (md.x >> 8) & 0xff, d1 = (md.x >> 16) & 0xff, d2 = (md.x >> 24) & 0xff;
+        const float sp_in = sc[kScalGroup + a.fb_in_group];
+        if (g < BNF_MAX_GROUPS) atomicAdd(&s_grp[g], t1);                       // LDS atomics
+        float v = 0.f;
+        if (kind == kFbInput || kind == kFbInter) v = t1;
+        else if (kind == kFbFourier) v = __int_as_float(md.z) * t2 / sp_in;
+        if (d1 < BNF_MAX_INPUTS) atomicAdd(&s_grp[BNF_MAX_GROUPS + d1], v);
+        if (d2 < BNF_MAX_INPUTS) atomicAdd(&s_grp[BNF_MAX_GROUPS + d2], v);
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS atomics have landed
+        __builtin_amdgcn_wave_barrier();
+        if (f < a.n_groups) {
+          const int off = a.fbmeta[256 + f];
+          atomicAdd(&gr[off], sigmoidf(th[off]) / sc[kScalGroup + f] * s_grp[f]);
+        } else if (f >= BNF_MAX_GROUPS && f < BNF_MAX_GROUPS + a.n_inputs) {
+          atomicAdd(&gr[a.off_lsa + f - BNF_MAX_GROUPS], -s_grp[f]);
+        }
+      }
     }
   }
   BNF_MARK(a, 10);

@@ -101,3 +101,34 @@ def test_panel_repeated_step_is_reproducible():
     assert np.abs(loss - loss0).max() <= 1e-5 * np.abs(loss0).max()
     assert (np.abs(g - g0) / scale).max() < 1e-4
   eng.close()
+
+
+def test_fused_featurisation_backward_matches_the_separate_kernel(monkeypatch):
+  """W = 512, <= 64 features: the panel kernel finishes the featurisation backward itself (d feature
+  scales, d log_scale_adjustment from the dH0 tiles in registers and the bf16 feature panel in LDS;
+  bnf_panel.h) instead of writing dH0^T for k_feat_bwd.  Both against the float64 oracle (2e-2 of the
+  leaf's max; measured <= 9e-3 fused, <= 6e-3 separate: scripts/featbwd_diag.py) and each other."""
+  n_rows, E = 1000, 3
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=512, depth=2)
+  theta = util.random_theta(model, E, scale=0.3)
+  _, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
+  g = {}
+  for flag in ('1', '0'):
+    monkeypatch.setenv('BNF_PANEL_FEATBWD', flag)
+    eng = _engine(net, X, y, members=E, compute_dtype='bf16', pipeline='panel')
+    eng.set_params(theta)
+    g[flag] = eng.debug_loss_and_grad()[1]
+    g2 = eng.debug_loss_and_grad()[1]          # LDS group sums are re-zeroed by every workgroup
+    assert util.rel_err(g2, g[flag]) < 2e-3
+    eng.close()
+  names = [k for k in model.leaf if k.startswith('feature_inv_sp_scale') or k == 'log_scale_adjustment']
+  assert len(names) >= 5
+  for flag in g:
+    errs = util.per_leaf_rel_err(model, g[flag], g_o)
+    bad = {k: errs[k] for k in names if errs[k] > 2e-2}
+    assert not bad, (flag, bad)
+  errs = util.per_leaf_rel_err(model, g['1'], g['0'])
+  bad = {k: errs[k] for k in names if errs[k] > 1e-2}
+  assert not bad, bad
+  rest = {k: v for k, v in errs.items() if k not in names and v > 2e-3}   # nothing else changes
+  assert not rest, rest
