@@ -114,6 +114,7 @@ struct bnf_handle {
   float* stab = nullptr;
   float* stab_pred = nullptr;
   void* H0 = nullptr; void* H0t = nullptr;
+  bool h0l = false;
   void* A[BNF_MAX_LAYERS]; void* H[BNF_MAX_LAYERS]; void* Ht[BNF_MAX_LAYERS];
   void* dZ[BNF_MAX_LAYERS]; void* dZt[BNF_MAX_LAYERS];
   void* Kn[BNF_MAX_LAYERS]; void* Kt[BNF_MAX_LAYERS];
@@ -177,7 +178,9 @@ static size_t carve(bnf_handle* h, char* base) {
   h->H0 = take((size_t)Ev * Bp * Fp * es);
   // no transposed copies (the weight-gradient contraction reads row-major, gemm_tn); the row-panel
   // kernel reads the features as MFMA A fragments from a second, fragment-major copy (H0t slot)
-  h->H0t = h->panel ? take((size_t)Ev * Bp * Fp * es) : nullptr;
+  // (the H0L variant -- W = 512, Fp = 64 -- stages the row-major copy in LDS instead and skips it)
+  h->h0l = h->panel && h->W == 512 && h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L");
+  h->H0t = (h->panel && !h->h0l) ? take((size_t)Ev * Bp * Fp * es) : nullptr;
   for (int l = 0; l < h->L; ++l) {
     h->A[l] = (h->panel || (h->fuse_last && l == h->L - 1) || (h->recompute_a0 && l == 0)) ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
     h->H[l] = (l < h->L - 1) ? take((size_t)Ev * Bp * W * es) : nullptr;       // H_{l+1} (Bp, W)
@@ -469,6 +472,15 @@ struct LossSink {
   const StepState* st = nullptr;               // graph replay: per-step state in device memory
 };
 
+// split-K of layer l's weight-gradient contraction (1: the kernel STORES dK_l, > 1: f32 atomics)
+static int wgrad_splitk(const bnf_handle* h, int nmem, int l) {
+  const int M = (l == 0) ? h->F : h->W, N = h->W;
+  const int tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
+  const int nk = (int)(h->Bp / (h->bf16 ? 64 : 32));
+  const int sk = (1024 + nmem * tiles - 1) / (nmem * tiles);
+  return std::max(1, std::min(sk, std::max(1, nk / 4)));
+}
+
 // weight gradient of layer l from the row-major H_l / dZ_l left in HBM, on stream `st`
 template <typename T>
 static void run_wgrad_layer(bnf_handle* h, int nmem, int l, hipStream_t st) {
@@ -480,11 +492,7 @@ static void run_wgrad_layer(bnf_handle* h, int nmem, int l, hipStream_t st) {
   g.a_ld = (l == 0) ? h->Fp : h->W; g.a_batch = Bp * g.a_ld;
   g.B = h->dZ[l]; g.b_ld = h->W; g.b_batch = Bp * h->W;
   g.M = (l == 0) ? h->F : h->W; g.N = h->W; g.K = (int)Bp; g.members = nmem;
-  const int tiles = ((g.M + kBM - 1) / kBM) * ((g.N + kBN - 1) / kBN);
-  const int nk = (int)(Bp / (h->bf16 ? 64 : 32));
-  int sk = (1024 + nmem * tiles - 1) / (nmem * tiles);
-  sk = std::max(1, std::min(sk, std::max(1, nk / 4)));
-  g.splitk = sk;
+  g.splitk = wgrad_splitk(h, nmem, l);
   EpiArgs ep{};
   ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->Wt));
   ep.grad = h->gradf; ep.grad_stride = h->Pf; ep.off_out = h->nd.off_kernel[l]; ep.ld_f32 = h->W;
@@ -719,7 +727,7 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   // 128-row panels at W = 512 (the feature panel staged in LDS when Fp = 64), 256-row panels at W = 256
   if (h->W == 512) {
     pa.panels = (int32_t)(Bp / panel_rows(8, 4));
-    if (h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L")) {
+    if (h->h0l) {
       pa.fbmeta = h->fbmeta; pa.off_lsa = h->nd.off_lsa; pa.n_groups = h->nd.n_groups; pa.n_inputs = h->nd.D;
       pa.fb_in_group = h->fb_in_group;
       feat_bwd_fused = h->fbmeta != nullptr;
@@ -802,6 +810,14 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
   a.prior_weight = h->cfg.prior_weight;
   a.loss = sink.loss; a.loss_stride = sink.stride; a.loss_scale = sink.scale;
   a.apply = apply ? 1 : 0; a.loss_raw = sink.raw; a.st = sink.st;
+  // the largest hidden-layer kernel whose gradient the next step stores (no split-K) is not cleared
+  a.keep_lo = a.keep_hi = 0;
+  if (!h->pad && h->P % 4 == 0 && !getenv("BNF_ADAM_CLEAR_ALL"))
+    for (int l = 1; l < h->L; ++l)
+      if (wgrad_splitk(h, E, l) == 1 && a.keep_hi == 0) {
+        a.keep_lo = (h->nd.off_kernel[l] + 3) / 4 * 4;
+        a.keep_hi = (h->nd.off_kernel[l] + h->W * h->W) / 4 * 4;
+      }
   {
     LaunchScope ls(h, KID_ADAM);
     if (h->P % 4 == 0) {
@@ -1024,7 +1040,8 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
     // its contraction depth is Fp <= 128: cheaper to redo than to write + gather A_0^T
     h->recompute_a0 = !cfg->forward_only && !h->panel && want == 0 && h->L >= 2 && h->Fp <= 128;
   }
-  if (h->panel && h->W == 512 && h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L") &&
+  h->h0l = h->panel && h->W == 512 && h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L");
+  if (h->h0l &&
       !(getenv("BNF_PANEL_FEATBWD") && atoi(getenv("BNF_PANEL_FEATBWD")) == 0)) {
     // fused featurisation backward of the H0L panel kernel: what each feature column contributes
     int in_group = -1;
