@@ -657,17 +657,25 @@ __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
       th[0] = a.theta[i0]; g[0] = a.grad[i0];
       if (a.apply) { m[0] = a.m[i0]; v[0] = a.v[i0]; }
     }
+    // One hardware exp2 / log2 / rcp / sqrt each (1 ulp) instead of the libm tanhf, expf + log1pf and
+    // the IEEE divide / sqrt sequences: 246 VALU instructions per element made this kernel VALU-bound
+    // (profiles/r02z_mfma_valu_counters.md: VALU busy ~100 %, 4.2 TB/s); with e = exp(-|z|):
+    //   tanh(z / 2) = sign(z) (1 - e) / (1 + e),   log Logistic(z) = -z - 2 softplus(-z) = -|z| - 2 log1p(e)
+    const float ibc1 = 1.0f / bc1, ibc2 = 1.0f / bc2;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       if (a.prior_weight != 0.f) {
         const float z = th[k] - ((p0 + k) == a.off_shape ? -1.5f : 0.f);
-        g[k] += a.prior_weight * tanhf(0.5f * z);
-        lp += -z - 2.f * softplusf(-z);
+        const float az = fabsf(z);
+        const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * az);
+        const float r = __builtin_amdgcn_rcpf(1.0f + e);
+        g[k] += a.prior_weight * copysignf((1.0f - e) * r, z);
+        lp += -az - 1.38629436111989061883f * __builtin_amdgcn_logf(1.0f + e);   // 2 ln 2 log2(1 + e)
       }
       if (a.apply) {
         m[k] = 0.9f * m[k] + 0.1f * g[k];
         v[k] = 0.999f * v[k] + 0.001f * g[k] * g[k];
-        th[k] = th[k] - a.lr * (m[k] / bc1) / (sqrtf(v[k] / bc2) + 1e-8f);
+        th[k] = th[k] - a.lr * (m[k] * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v[k] * ibc2) + 1e-8f);
         g[k] = 0.f;  // ready for the next step's atomics
       }
     }
