@@ -145,6 +145,20 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
           if (d == nd.group_arg[g]) ud = u[d];
         for (int k = 0; k < deg; ++k) {
           float sn, cs;
+          if constexpr (sizeof(T) == 2) {
+            // bf16 features (8 significant bits): the hardware v_sin / v_cos (argument in revolutions,
+            // ~1e-6 absolute) and v_rcp instead of ocml sincosf + IEEE divides -- the kernel was
+            // VALU-bound on them (r02z counters: VALU busy 85 %); the fp32 pipeline keeps the
+            // reference-accurate path
+            const float x = ud * (float)(1u << k);
+            const float fx = x - floorf(x);
+            sn = __builtin_amdgcn_sinf(fx);
+            cs = __builtin_amdgcn_cosf(fx);
+            const float q = __builtin_amdgcn_rcpf((float)(k + 1)) * sp;
+            put(c0 + k, cs * q);
+            put(c0 + deg + k, sn * q);
+            continue;
+          }
           sincos_rev(ud * (float)(1u << k), &sn, &cs);
           const float den = (float)(k + 1);
           put(c0 + k, (cs / den) * sp);
