@@ -126,6 +126,13 @@ def test_forward_and_grad_fp32(depth, width, n_rows, pipeline):
     np.testing.assert_allclose(loss_d, loss_o, rtol=2e-5)
     errs = util.per_leaf_rel_err(model, g_d, g_o)
     bad = {k: v for k, v in errs.items() if v > 5e-4}
+    if bad:   # diagnostics: is it the prior term (g_d - g_o ~ -+ tanh(theta / 2)) and is it reproducible?
+      d = g_d - g_o
+      pr = np.tanh(0.5 * theta)
+      loss_2, g_2 = eng.debug_loss_and_grad()
+      bad = dict(bad, _pw=pw, _corr_with_prior=float(np.corrcoef(d.ravel(), pr.ravel())[0, 1]),
+                 _second_eval_max_diff=float(np.abs(g_2 - g_d).max()),
+                 _second_eval_bad=len([k for k, v in util.per_leaf_rel_err(model, g_2, g_o).items() if v > 5e-4]))
     assert not bad, bad
     eng.close()
 
