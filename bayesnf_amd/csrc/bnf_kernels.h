@@ -718,7 +718,17 @@ __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
 // ---------------------------------------------------------------------------
 // mean-field VI (inference.py:687-720): sample, then combine S sample gradients.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float vi_sigma(float rho) { return 1e-4f + softplusf(rho); }
+// The optimiser-side kernels below evaluate a handful of transcendentals per parameter (and per VI
+// sample); with libm they were VALU-bound (k_adam_map: ~246 instructions per parameter), so they use
+// the hardware exp2 / log2 / rcp / sqrt (1 ulp each) -- parity bars unchanged (tests/test_gpu_parity.py).
+__device__ __forceinline__ float hw_exp_neg_abs(float x) { return __builtin_amdgcn_exp2f(-1.44269504088896340736f * fabsf(x)); }
+__device__ __forceinline__ float hw_log1p_of_exp(float t) { return 0.69314718055994530942f * __builtin_amdgcn_logf(1.0f + t); }  // log(1 + t), t in (0, 1]
+__device__ __forceinline__ float hw_softplus(float x) { return fmaxf(x, 0.f) + hw_log1p_of_exp(hw_exp_neg_abs(x)); }
+__device__ __forceinline__ float hw_sigmoid(float x) {
+  const float t = hw_exp_neg_abs(x), r = __builtin_amdgcn_rcpf(1.0f + t);
+  return x >= 0.f ? r : t * r;
+}
+__device__ __forceinline__ float vi_sigma(float rho) { return 1e-4f + hw_softplus(rho); }
 
 __global__ __launch_bounds__(256) void k_vi_sample(const float* __restrict__ mu,
                                                    const float* __restrict__ rho, int32_t P,
@@ -777,27 +787,28 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
         const int64_t gi = ((int64_t)e * a.S + s) * a.P + p;
         // Logistic(loc, 1) prior: d(-log p)/dz = tanh(z/2), log p = -z - 2 softplus(-z);
         // both from u = exp(-|z|)
-        const float u = expf(-fabsf(z));
-        const float g = gl[k] + copysignf((1.f - u) / (1.f + u), z);
+        const float u = hw_exp_neg_abs(z);
+        const float g = gl[k] + copysignf((1.f - u) * __builtin_amdgcn_rcpf(1.f + u), z);
         if (a.apply) a.grad[gi] = 0.f;
         gmu += g;
         grho += g * eps;
         e2 += eps * eps;
-        lpr += -z - 2.f * (fmaxf(-z, 0.f) + log1pf(u));
+        lpr += -fabsf(z) - 2.f * hw_log1p_of_exp(u);     // -z - 2 softplus(-z)
       }
     }
     const float invS = 1.f / (float)a.S;
     gmu *= invS;
-    grho = sigmoidf(rho) * (grho * invS - 1.f / sig);
+    grho = hw_sigmoid(rho) * (grho * invS - __builtin_amdgcn_rcpf(sig));
     // mean_s [ log q(z_s) - log p(z_s) ] for this coordinate
-    lterm = (-0.5f * e2 * invS - logf(sig) - 0.918938533204672742f) - lpr * invS;
+    lterm = (-0.5f * e2 * invS - 0.69314718055994530942f * __builtin_amdgcn_logf(sig) - 0.918938533204672742f) - lpr * invS;
     if (a.apply) {
+      const float ibc1 = 1.0f / a.bc1, ibc2 = 1.0f / a.bc2;
       float m = 0.9f * a.m_mu[i] + 0.1f * gmu, v = 0.999f * a.v_mu[i] + 0.001f * gmu * gmu;
       a.m_mu[i] = m; a.v_mu[i] = v;
-      a.mu[i] = mu - a.lr * (m / a.bc1) / (sqrtf(v / a.bc2) + 1e-8f);
+      a.mu[i] = mu - a.lr * (m * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + 1e-8f);
       m = 0.9f * a.m_rho[i] + 0.1f * grho; v = 0.999f * a.v_rho[i] + 0.001f * grho * grho;
       a.m_rho[i] = m; a.v_rho[i] = v;
-      a.rho[i] = rho - a.lr * (m / a.bc1) / (sqrtf(v / a.bc2) + 1e-8f);
+      a.rho[i] = rho - a.lr * (m * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + 1e-8f);
     } else {
       a.gmu_out[i] = gmu;
       a.grho_out[i] = grho;
