@@ -150,3 +150,23 @@ def test_estimator_with_reference_default_like_odd_width():
   means, qs = m.predict(df, quantiles=(0.5,))
   rmse = float(np.sqrt(np.mean((np.asarray(means).mean(axis=(0, 1)) - df.y.values) ** 2)))
   assert rmse < 0.5, rmse
+
+
+@pytest.mark.parametrize('n_rows,width,depth,E,dtype,pipeline', [
+    (1, 64, 1, 1, 'fp32', 'auto'), (2, 64, 2, 1, 'fp32', 'auto'), (3, 128, 2, 2, 'fp32', 'layers'),
+    (5, 512, 2, 1, 'bf16', 'auto'), (1, 256, 2, 3, 'bf16', 'auto'), (129, 512, 2, 1, 'bf16', 'panel'),
+    (257, 256, 2, 2, 'bf16', 'panel')])
+def test_tiny_and_ragged_batches(n_rows, width, depth, E, dtype, pipeline):
+  """Edge sizes: a single row, a single member, batches one row past a panel / tile boundary
+  (padded rows must contribute exactly nothing)."""
+  net, model, X, y = util.make_problem(n_rows=max(n_rows, 2), width=width, depth=depth)
+  X, y = X[:n_rows], y[:n_rows]
+  theta = util.random_theta(model, E, scale=0.3)
+  eng = _engine(net, X, y, members=E, compute_dtype=dtype, pipeline=pipeline)
+  eng.set_params(theta)
+  loss, g = eng.debug_loss_and_grad()
+  eng.close()
+  loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
+  np.testing.assert_allclose(loss, loss_o, rtol=2e-5 if dtype == 'fp32' else 5e-3)
+  bad = {k: v for k, v in util.per_leaf_rel_err(model, g, g_o).items() if v > (5e-4 if dtype == 'fp32' else 6e-2)}
+  assert not bad, bad
