@@ -114,6 +114,7 @@ struct bnf_handle {
   float* stab = nullptr;
   float* stab_pred = nullptr;
   void* H0 = nullptr; void* H0t = nullptr;
+  const float* ext_eps = nullptr;   // bnf_debug_vi_noise
   bool h0l = false;
   void* A[BNF_MAX_LAYERS]; void* H[BNF_MAX_LAYERS]; void* Ht[BNF_MAX_LAYERS];
   void* dZ[BNF_MAX_LAYERS]; void* dZt[BNF_MAX_LAYERS];
@@ -844,7 +845,7 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
     dim3 grid(cdiv(h->P, 256), (unsigned)E, (unsigned)((S + 3) / 4));
     hipLaunchKernelGGL(k_vi_sample, grid, dim3(256), 0, h->stream, mu, rho, h->P, S, h->cfg.seed,
                        h->cfg.member_offset, (uint64_t)step, (uint32_t)STREAM_VI_EPS, h->theta_c,
-                       (int64_t)S * h->P, (int64_t)h->P);
+                       (int64_t)S * h->P, (int64_t)h->P, h->ext_eps);
   }
   const float kl = h->cfg.kl_weight;
   const float c = (float)((double)h->N / (double)h->B / (double)kl);
@@ -869,7 +870,7 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   a.bc1 = (float)(1.0 - std::pow(0.9, (double)t));
   a.bc2 = (float)(1.0 - std::pow(0.999, (double)t));
   a.kl_weight = kl; a.loss = loss; a.loss_stride = loss_stride; a.apply = apply ? 1 : 0;
-  a.gmu_out = gmu_out; a.grho_out = grho_out;
+  a.gmu_out = gmu_out; a.grho_out = grho_out; a.ext_eps = h->ext_eps;
   {
     LaunchScope ls(h, KID_VIADAM);
     dim3 grid(cdiv(h->P, 256), (unsigned)E);
@@ -1411,6 +1412,13 @@ int bnf_debug_row_index(bnf_handle* h, int64_t epoch, int64_t step, int32_t* out
   dim3 grid(cdiv(h->B, 256), (unsigned)h->cfg.members);
   hipLaunchKernelGGL(k_row_index, grid, dim3(256), 0, h->stream, rs, h->B, out);
   HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
+int bnf_debug_vi_noise(bnf_handle* h, const float* eps) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "not bound");
+  if (h->cfg.mode != BNF_MODE_VI) return fail(BNF_ERR_STATE, "not a VI handle");
+  h->ext_eps = eps;
   return BNF_OK;
 }
 

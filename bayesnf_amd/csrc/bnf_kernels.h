@@ -735,14 +735,18 @@ __global__ __launch_bounds__(256) void k_vi_sample(const float* __restrict__ mu,
                                                    int32_t S, uint64_t seed, int64_t member_offset,
                                                    uint64_t step, uint32_t stream,
                                                    float* __restrict__ z, int64_t z_member_stride,
-                                                   int64_t z_sample_stride) {
+                                                   int64_t z_sample_stride, const float* __restrict__ ext_eps = nullptr) {
   // grid: (ceil(P/256), members, ceil(S/4)): one Philox call serves the four samples of a group
   const int e = blockIdx.y, s0 = blockIdx.z * 4;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const int64_t i = (int64_t)e * P + p;
   const float m = mu[i], sg = vi_sigma(rho[i]);
-  const Normal4 n4 = vi_eps4(seed, (uint32_t)(member_offset + e), (uint32_t)blockIdx.z, (uint32_t)p, step, stream);
+  Normal4 n4 = vi_eps4(seed, (uint32_t)(member_offset + e), (uint32_t)blockIdx.z, (uint32_t)p, step, stream);
+  if (ext_eps) {   // bnf_debug_vi_noise: the caller's standard normals, (members, S, P)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) n4.v[k] = ext_eps[((int64_t)e * S + min(s0 + k, S - 1)) * P + p];
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if (s0 + k < S)
@@ -758,6 +762,7 @@ struct ViAdamArgs {
   float* loss; int64_t loss_stride;
   int32_t apply;
   float* gmu_out; float* grho_out;  // debug: (members, P) each
+  const float* ext_eps;             // bnf_debug_vi_noise: (members, S, P) standard normals instead of the generator's
 };
 
 __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
@@ -772,8 +777,12 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
     const float loc = (p == a.off_shape) ? -1.5f : 0.f;
     float gmu = 0.f, grho = 0.f, e2 = 0.f, lpr = 0.f;
     for (int s0 = 0; s0 < a.S; s0 += 4) {
-      const Normal4 n4 = vi_eps4(a.seed, (uint32_t)(a.member_offset + e), (uint32_t)(s0 >> 2), (uint32_t)p,
-                                 a.step, STREAM_VI_EPS);
+      Normal4 n4 = vi_eps4(a.seed, (uint32_t)(a.member_offset + e), (uint32_t)(s0 >> 2), (uint32_t)p,
+                           a.step, STREAM_VI_EPS);
+      if (a.ext_eps) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) n4.v[k] = a.ext_eps[((int64_t)e * a.S + min(s0 + k, a.S - 1)) * a.P + p];
+      }
       float gl[4];   // the four likelihood gradients in flight together
 #pragma unroll
       for (int k = 0; k < 4; ++k)

@@ -220,6 +220,14 @@ class Engine:
     torch.cuda.synchronize(self.device)
     return out.cpu().numpy()
 
+  def debug_vi_noise(self, eps):
+    """Verification hook (include/bnf.h bnf_debug_vi_noise): every following VI step reads its
+    (members, S, P) standard normals from `eps` (device tensor, kept alive here); None restores
+    the engine's generator."""
+    self._ext_eps = None if eps is None else eps.contiguous().float().to(self.device)
+    _native.check(self.lib.bnf_debug_vi_noise(self.handle, None if eps is None else _ptr(self._ext_eps)),
+                  'bnf_debug_vi_noise')
+
   def debug_activation(self, what: int) -> np.ndarray:
     ev = self.members * self.S
     if what == 0 or what == 400:

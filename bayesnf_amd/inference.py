@@ -117,7 +117,7 @@ class MeanFieldSurrogate:
 
 def fit_vi(features, target, seed, observation_model, model_args, ensemble_size,
            learning_rate, num_epochs, sample_size_divergence,
-           sample_size_posterior, kl_weight, batch_size=None, compute_dtype=None):
+           sample_size_posterior, kl_weight, batch_size=None, compute_dtype=None, init_rng=None):
   """Fit mean-field surrogates.  Returns (surrogate, losses, predictions):
   losses (num_devices, E/num_devices, num_epochs) already multiplied by
   kl_weight; predictions = StructTuple of posterior draws with leaves
@@ -139,6 +139,13 @@ def fit_vi(features, target, seed, observation_model, model_args, ensemble_size,
                kl_weight=kl_weight, vi_samples=sample_size_divergence,
                compute_dtype=compute_dtype)
   eng.init_params(0.0)
+  if (init_rng or os.environ.get('BNF_INIT_RNG', 'jax')) == 'jax':
+    # the reference's own initial surrogate means for this seed (the optimisation noise and the
+    # posterior draws stay on the engine's counter-based generator: same law, other numbers)
+    mu0 = jaxseed.vi_initial_means(net, seed, world, per_device)[rank]
+    p0 = eng.get_params()
+    p0[0] = mu0
+    eng.set_params(p0)
   loss_dev = eng.train(0, num_epochs)
   draws = eng.vi_posterior_draws(sample_size_posterior)   # (n, E_local, P)
   mu_rho = eng.params.view(2, per_device, net.P)

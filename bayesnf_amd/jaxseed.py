@@ -118,3 +118,27 @@ def map_initial_params(net, keys: np.ndarray, log_noise_init: float) -> np.ndarr
       if len(lf.shape) == 2:
         theta[e, lf.offset:lf.offset + lf.size] = truncated_normal_std(sample_seed, lf.size)
   return theta
+
+
+_IID_SALT = int(__import__('hashlib').sha512(b'iid_sample_stateless').hexdigest(), 16) & 0xFFFFFFFF
+
+
+def vi_initial_means(net, seed, world: int, per_device: int) -> np.ndarray:
+  """(world, per_device, P) float32 initial surrogate means of ensemble_vi (inference.py:722-725 with
+  make_vi_init :203-231): `init_seed = split(seed)[0]`; the (devices, E) sample of the initialiser is a
+  vectorised JointDistribution sample -- keys = split(fold_in(init_seed, 'iid_sample_stateless'),
+  devices * E) -- and every key runs the JointDistribution chain over two yields per leaf (the mean,
+  then the deterministic inverse-softplus scale): TN(0, 1, [-2, 2]) for Dense kernels, 0 elsewhere.
+  Determined against the reference's VI golden (oracle/jax_rng.py, tests/test_jax_rng.py)."""
+  init_seed = split(as_key(seed), 2)[0]
+  keys = split(fold_in(init_seed, _IID_SALT), world * per_device)
+  mu = np.zeros((world * per_device, net.P), dtype=np.float32)
+  for e, key in enumerate(keys):
+    key = fold_in(key, _JD_SALT)
+    for lf in net.leaves:
+      pair = split(key, 2)
+      mean_seed, key = pair[0], pair[1]
+      key = split(key, 2)[1]            # the leaf's second yield (deterministic rho) consumes a split too
+      if len(lf.shape) == 2:
+        mu[e, lf.offset:lf.offset + lf.size] = truncated_normal_std(mean_seed, lf.size)
+  return mu.reshape(world, per_device, net.P)

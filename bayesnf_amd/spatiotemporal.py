@@ -191,7 +191,7 @@ class BayesianNeuralFieldEstimator:
     standardize: columns to z-score (never the time column).
   Extra (not in the reference): compute_dtype 'fp32' | 'bf16' selects the
     arithmetic of the dense contractions on the GPU (fp32 accumulate either
-    way); default from env BNF_DTYPE, else 'fp32'.  init_rng 'jax' | 'philox' (MAP / MLE): 'jax'
+    way); default from env BNF_DTYPE, else 'fp32'.  init_rng 'jax' | 'philox': 'jax'
     (default, env BNF_INIT_RNG) draws the initial Dense kernels from the reference's own streams
     for `seed` (jax threefry + TFP seed chain restated in `jaxseed`), so a full-batch fit follows
     the reference's trajectory; 'philox' uses the device generator.
@@ -407,5 +407,6 @@ class BayesianNeuralFieldVI(BayesianNeuralFieldEstimator):
         sample_size_divergence=sample_size_divergence,
         kl_weight=kl_weight,
         batch_size=batch_size,
-        compute_dtype=self.compute_dtype)
+        compute_dtype=self.compute_dtype,
+        init_rng=self.init_rng)
     return self

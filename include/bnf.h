@@ -207,6 +207,12 @@ int bnf_debug_loss_and_grad(bnf_handle* h, int64_t epoch, int64_t step,
 int bnf_debug_row_index(bnf_handle* h, int64_t epoch, int64_t step, int32_t* out);
 /* VI noise of a step: out DEVICE (members, S, P) f32. */
 int bnf_debug_vi_eps(bnf_handle* h, int64_t step, float* out);
+/* Verification hook: from now on every VI step takes its reparameterisation noise from `eps`
+ * (DEVICE, (members, S, P) f32 standard normals, caller-owned, read at each step; NULL = the
+ * engine's own counter-based generator again).  It lets a test feed the noise of
+ * tfp.vi.fit_surrogate_posterior_stateless (inference.py:727-738) and compare with the reference's
+ * golden predictions element-wise; not meant for production sizes. */
+int bnf_debug_vi_noise(bnf_handle* h, const float* eps);
 /* Copy of an internal activation buffer, as f32: what = 0 features H0 (E',B,F),
  * 1+l hidden output H_{l+1} (E',B,W) for l < depth-1 (the last hidden output is
  * never stored), 100+l pre-activation A_l (E',B,W), 200 network output (E',B),

@@ -189,3 +189,70 @@ def reference_map_init_matrices(model, seed, n_members: int, split_index=None):
       if len(lf.shape) == 2:
         mats[e, lf.offset:lf.offset + lf.size] = tfd_truncated_normal_std(seeds[i], lf.shape).ravel()
   return mats
+
+
+# --------------------------------------------------------------------------- the reference's VI chain
+# ensemble_vi (inference.py:626-764), determined against tests/test_data/bnf-vi.chickenpox.8.mini.pred.csv
+# the same way as the MAP chain (scripts/n1_vi_chain_search.py: of ~1,300 candidate chains exactly one
+# reproduces the golden, to 2.5e-6; the next best is off by 7e-3):
+#   init_seed, opt_seed   = split(seed)                                        :722
+#   fit_seed, sample_seed = split(opt_seed)                                    :747
+#   initial surrogate     : make_vi_init(prior)((devices, E), seed=init_seed)  :724 -- a vectorised
+#       JointDistribution sample: keys = split(fold_in(init_seed, 'iid_sample_stateless'), devices * E), each
+#       key runs the JointDistribution chain above over TWO yields per leaf (mean, then the Deterministic rho)
+#   optimisation          : per device s = fold_in(split(fit_seed, devices)[d], 'minimize'); before every step
+#       s = split(s)[0], and the step's S reparameterisation draws are a vectorised JointDistribution sample
+#       with seed s: keys = split(fold_in(s, 'iid_sample_stateless'), S), each -> fold_in 'JointDistribution',
+#       one split per leaf, jax.random.normal over the leaf's (E, ...) batch
+#   posterior draws       : the same vectorised sample with seed split(sample_seed, devices)[d], n = num_samples
+def _vec_jd_keys(seed, n):
+  return split(fold_in(seed, tfp_salt('iid_sample_stateless')), n)
+
+
+def _jd_leaf_normals(model, key, n_members):
+  """One execution of the surrogate JointDistribution: (n_members, P) standard normals."""
+  seeds = jdc_sample_seeds(key, len(model.leaves))
+  eps = np.zeros((n_members, model.P), dtype=np.float32)
+  for i, lf in enumerate(model.leaves):
+    eps[:, lf.offset:lf.offset + lf.size] = normal(seeds[i], (n_members * lf.size,)).reshape(n_members, lf.size)
+  return eps
+
+
+def reference_vi_seeds(seed):
+  """-> (init_seed, fit_seed of device 0, sample_seed of device 0) for a single-device run."""
+  init_seed, opt_seed = split(np.asarray(seed, dtype=U32), 2)
+  fit_seed, sample_seed = split(opt_seed, 2)
+  return init_seed, split(fit_seed, 1)[0], split(sample_seed, 1)[0]
+
+
+def reference_vi_init_means(model, seed, n_members: int):
+  """(n_members, P) initial surrogate means: TruncatedNormal kernels, zeros elsewhere (inference.py:203-231)."""
+  init_seed, _, _ = reference_vi_seeds(seed)
+  keys = _vec_jd_keys(init_seed, n_members)
+  mu = np.zeros((n_members, model.P), dtype=np.float64)
+  for e in range(n_members):
+    seeds = jdc_sample_seeds(keys[e], 2 * len(model.leaves))
+    for i, lf in enumerate(model.leaves):
+      if len(lf.shape) == 2:
+        mu[e, lf.offset:lf.offset + lf.size] = tfd_truncated_normal_std(seeds[2 * i], lf.shape).ravel()
+  return mu
+
+
+def reference_vi_step_noise(model, seed, num_steps: int, sample_size: int, n_members: int):
+  """List over steps of the (n_members, sample_size, P) reparameterisation noise of
+  tfp.vi.fit_surrogate_posterior_stateless (two steps are what the golden validates)."""
+  _, fit_seed, _ = reference_vi_seeds(seed)
+  s = fold_in(fit_seed, tfp_salt('minimize'))
+  out = []
+  for _ in range(num_steps):
+    s = split(s, 2)[0]
+    keys = _vec_jd_keys(s, sample_size)
+    out.append(np.stack([_jd_leaf_normals(model, keys[k], n_members) for k in range(sample_size)], axis=1))
+  return out
+
+
+def reference_vi_posterior_noise(model, seed, num_samples: int, n_members: int):
+  """(num_samples, n_members, P) standard normals of the posterior draws (inference.py:741-753)."""
+  _, _, sample_seed = reference_vi_seeds(seed)
+  keys = _vec_jd_keys(sample_seed, num_samples)
+  return np.stack([_jd_leaf_normals(model, keys[k], n_members) for k in range(num_samples)])

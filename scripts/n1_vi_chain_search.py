@@ -209,7 +209,61 @@ def stage3():
     print(r)
 
 
+def stage4():
+  """init and posterior-draw chains fixed to the standard vectorised-JD chain; wider family of how the
+  two optimisation steps get their seeds from fit_seed"""
+  seed = R.prng_key(0)
+  mu0 = init_means(seed, INIT)[None]
+  rho0 = np.full((1, model.P), np.log(np.expm1(0.3)))
+  V = (None, 'iid_sample_stateless', 'JointDistribution')
+  eps_draw = {d: posterior_draws(seed, V + (0, d)) for d in (1, 0)}
+  opt = R.split(seed, 2)[1]
+  fit = R.split(opt, 2)[0]
+  res = []
+  t0 = time.time()
+  def step_pairs(s):
+    a, b = R.split(s, 2)
+    t3 = R.split(s, 3)
+    return {'a,split(b)0': (a, R.split(b, 2)[0]), 'a,split(b)1': (a, R.split(b, 2)[1]),
+            'b,split(a)0': (b, R.split(a, 2)[0]), 'b,split(a)1': (b, R.split(a, 2)[1]),
+            's,a': (s, a), 's,b': (s, b), 'a,b': (a, b), 'b,a': (b, a), 'a,a': (a, a), 's,s': (s, s),
+            'fold0,fold1': (R.fold_in(s, 0), R.fold_in(s, 1)), 'fold1,fold2': (R.fold_in(s, 1), R.fold_in(s, 2)),
+            'split3_01': (t3[0], t3[1]), 'split3_12': (t3[1], t3[2]),
+            'a,split(a)0': (a, R.split(a, 2)[0]), 'b,split(b)0': (b, R.split(b, 2)[0]), 'b,split(b)1': (b, R.split(b, 2)[1])}
+  def mc_variants(q):
+    out = {'q': q, 'split0': R.split(q, 2)[0], 'split1': R.split(q, 2)[1]}
+    f = fold(q, 'monte_carlo_variational_loss')
+    out['salt'] = f; out['salt_split0'] = R.split(f, 2)[0]; out['salt_split1'] = R.split(f, 2)[1]
+    return out
+  def eps_for(q, S=5):
+    seeds = vec_seeds(q, S, V[0], V[1])
+    return np.stack([leaf_normals(jd_seeds(seeds[k], len(LEAVES), V[2], 0)) for k in range(S)])[None]
+  n = 0
+  for dev in (1, 0):
+    base = R.split(fit, 1)[0] if dev else fit
+    for ms in (None, 'minimize', 'minimize_stateless'):
+      s0 = fold(base, ms)
+      for pname, (q1, q2) in step_pairs(s0).items():
+        m1, m2 = mc_variants(q1), mc_variants(q2)
+        for mname in m1:
+          eps = [eps_for(m1[mname]), eps_for(m2[mname])]
+          mu, rho, _ = O.train_vi(model, mu0, rho0, X, y, lr=0.01, num_steps=2, sample_size=5, kl_weight=0.1,
+                                  eps_fn=lambda s_: eps[s_])
+          for d in (1, 0):
+            yh = yhat_from(mu[0], rho[0], eps_draw[d])
+            res.append((np.abs(yh - gy).max(), np.corrcoef(yh, gy)[0, 1], dev, ms, pname, mname, d))
+          n += 1
+          if n % 40 == 0:
+            print(n, min(res)[:2], f'{time.time() - t0:.0f}s', flush=True)
+  res.sort(key=lambda t: t[0])
+  for r in res[:15]:
+    print(r)
+
+
 if __name__ == '__main__':
+  if len(sys.argv) > 1 and sys.argv[1] == 'stage4':
+    stage4()
+    sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == 'stage3':
     stage3()
     sys.exit(0)

@@ -225,3 +225,52 @@ def test_likelihood_model_against_the_oracle(golden_dir, obs):
       np.testing.assert_array_equal(got, O.count_quantile_via_root(fc, q))
       # an integer quantile: cdf(k) >= q > cdf(k - 1) up to the root tolerance
       assert np.all(lik.mixture_cdf(got) >= q - 2e-5)
+
+
+def test_reference_vi_golden_reproduced_through_the_engine(golden_dir):
+  """N1, VI on the GPU: the fp32 engine, started from the reference's initial surrogate means
+  (bayesnf_amd/jaxseed.vi_initial_means = what BayesianNeuralFieldVI.fit uses) and fed the
+  reparameterisation noise of the reference's two optimisation steps and of its 30 posterior draws
+  (oracle/jax_rng.py, through the verification hook bnf_debug_vi_noise), reproduces column `yhat` of
+  bnf-vi.chickenpox.8.mini.pred.csv element-wise.  (In production the engine draws that noise from
+  its own counter-based generator: same law, other numbers.)"""
+  import torch
+  from bayesnf_amd import jaxseed
+  from bayesnf_amd.engine import Engine
+  from oracle import jax_rng as R
+  from tests.test_oracle_kat import _setup
+  from bayesnf_amd import spatiotemporal as st
+  model, X, y = _setup(golden_dir, st.BayesianNeuralFieldVI)
+  gold = pd.read_csv(os.path.join(golden_dir, 'bnf-vi.chickenpox.8.mini.pred.csv'), index_col=0).iloc[:100]
+  df = _train_frame(golden_dir)
+  est = BayesianNeuralFieldVI(**MODEL, compute_dtype='fp32')
+  Xe = est.data_handler.get_train(df)
+  from bayesnf_amd import inference as bnf_inference
+  net = bnf_inference._net_from_args(est._model_args(Xe.shape), 'NORMAL')
+  seed = R.prng_key(0)
+  E, S, steps, draws = 1, 5, 2, 30
+  mu0 = jaxseed.vi_initial_means(net, seed, 1, E)[0]
+  np.testing.assert_array_equal(mu0, R.reference_vi_init_means(model, seed, E).astype(np.float32))
+  eng = Engine(net, mode='vi', X=X, y=y, members=E, vi_samples=S, kl_weight=0.1, learning_rate=0.01,
+               seed=0, compute_dtype='fp32')
+  eng.init_params(0.0)
+  p0 = eng.get_params()
+  p0[0] = mu0
+  eng.set_params(p0)
+  noise = R.reference_vi_step_noise(model, seed, steps, S, E)
+  for s in range(steps):
+    eng.debug_vi_noise(torch.tensor(noise[s]))
+    eng.train(s, 1)
+    torch.cuda.synchronize()
+  eng.debug_vi_noise(None)
+  mu, rho = eng.get_params().astype(np.float64)
+  eng.close()
+  eps = R.reference_vi_posterior_noise(model, seed, draws, E)
+  theta = (mu[None] + O.vi_sigma(rho)[None] * eps).reshape(draws * E, model.P)
+  fwd = Engine(net, members=draws, forward_only=True, row_capacity=128, compute_dtype='fp32')
+  loc, aux = fwd.forward(torch.tensor(theta, dtype=torch.float32, device=fwd.device),
+                         torch.tensor(X, dtype=torch.float32, device=fwd.device))
+  torch.cuda.synchronize()
+  yhat = loc.cpu().numpy().mean(axis=0)
+  fwd.close()
+  assert np.abs(yhat - gold.yhat.values).max() < 1e-4, np.abs(yhat - gold.yhat.values).max()

@@ -74,3 +74,57 @@ def test_oracle_reproduces_reference_golden_elementwise(golden_dir, objective, p
                         prior_weight=pw, dtype=np.float32)
   mu_w, _ = O.predict_normal(model, th_w, X, dtype=np.float32)
   assert np.abs(mu_w.mean(axis=0) - gold.yhat.values).max() > 1e-2
+
+
+def test_oracle_reproduces_reference_vi_golden_elementwise(golden_dir):
+  """N1, VI: tests/golden/bnf-vi.chickenpox.8.mini.pred.csv (reference tests/test_evaluate_mini.py:81-91:
+  seed PRNGKey(0), 1 particle, 2 steps of tfp.vi.fit_surrogate_posterior_stateless at lr 0.01,
+  kl_weight 0.1, 5 divergence samples, 30 posterior draws).  With the restated seed chain of
+  ensemble_vi (oracle/jax_rng.py: initial surrogate means, the reparameterisation noise of both steps,
+  the 30 posterior draws) the oracle reproduces `yhat` of the 100 training rows to 2.5e-6 -- this pins
+  the VI arithmetic (ELBO with the likelihood scaled by 1 / kl_weight, reparameterisation gradients of
+  mu and rho, Adam on both, the posterior sampling and the mixture over draws) against the reference."""
+  model, X, y = _setup(golden_dir, st.BayesianNeuralFieldVI)
+  gold = _load(golden_dir, 'bnf-vi.chickenpox.8.mini.pred.csv').iloc[:100]
+  seed = R.prng_key(0)
+  E, S, steps, draws = 1, 5, 2, 30
+  mu0 = R.reference_vi_init_means(model, seed, E)
+  rho0 = np.full((E, model.P), np.log(np.expm1(0.3)))
+  noise = R.reference_vi_step_noise(model, seed, steps, S, E)
+  mu, rho, losses = O.train_vi(model, mu0, rho0, X, y, lr=0.01, num_steps=steps, sample_size=S, kl_weight=0.1,
+                               eps_fn=lambda s: noise[s])
+  eps = R.reference_vi_posterior_noise(model, seed, draws, E)          # (draws, E, P)
+  theta = (mu[None] + O.vi_sigma(rho)[None] * eps).reshape(draws * E, model.P)
+  means, sd = O.predict_normal(model, theta, X)
+  yhat = means.mean(axis=0)
+  err = np.abs(yhat - gold.yhat.values).max()
+  assert err < 1e-4, err
+  assert err < 2e-5, err                       # measured 2.5e-6
+  for col, q in [('yhat_p50', 0.5), ('yhat_lower', 0.025), ('yhat_upper', 0.975)]:
+    g = gold[col].values
+    resid = np.abs(O.mixture_cdf(means, sd, g) - q)
+    assert resid.max() < 1.5e-5, (col, resid.max())
+  # sharpness: the same chain with the optimisation noise of a neighbouring seed is off by ~1e-2
+  other = R.reference_vi_step_noise(model, R.prng_key(1), steps, S, E)
+  mu_w, rho_w, _ = O.train_vi(model, mu0, rho0, X, y, lr=0.01, num_steps=steps, sample_size=S, kl_weight=0.1,
+                              eps_fn=lambda s: other[s])
+  th_w = (mu_w[None] + O.vi_sigma(rho_w)[None] * eps).reshape(draws * E, model.P)
+  assert np.abs(O.predict_normal(model, th_w, X)[0].mean(axis=0) - gold.yhat.values).max() > 2e-3
+
+
+def test_product_vi_initial_means_equal_the_oracle_chain(golden_dir):
+  """bayesnf_amd/jaxseed.vi_initial_means (what BayesianNeuralFieldVI.fit starts from) is an independent
+  implementation of the chain in oracle/jax_rng.py: equal to the bit, also for several members / devices."""
+  from bayesnf_amd import jaxseed
+  from bayesnf_amd import inference as bnf_inference
+  model, X, y = _setup(golden_dir, st.BayesianNeuralFieldVI)
+  est = st.BayesianNeuralFieldVI(width=model.width, depth=model.depth, feature_cols=['datetime', 'latitude', 'longitude'],
+                                 target_col='chickenpox', timetype='index', freq='W',
+                                 seasonality_periods=np.asarray([4.0, 52.1775]),
+                                 num_seasonal_harmonics=np.asarray([2.0, 10]), standardize=['latitude', 'longitude'])
+  df = pd.read_csv(os.path.join(golden_dir, 'chickenpox.8.train.csv'), index_col=0, parse_dates=['datetime'])
+  net = bnf_inference._net_from_args(est._model_args(est.data_handler.get_train(df).shape), 'NORMAL')
+  for key in (R.prng_key(0), np.array([7, 99], dtype=np.uint32)):
+    got = jaxseed.vi_initial_means(net, key, 2, 3).reshape(6, -1)
+    ref = R.reference_vi_init_means(model, key, 6).astype(np.float32)
+    np.testing.assert_array_equal(got, ref)
