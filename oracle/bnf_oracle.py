@@ -33,14 +33,19 @@ here, so their published semantics are restated:
                      `sample_size`; trace = loss before each update
   find_root_chandrupatla   Chandrupatla (1997) bracketing root finder
 
-PARITY PIN STATUS: the reference's only golden files for this path
+PARITY PIN STATUS: PINNED.  The reference's golden files for this path
 (tests/test_data/bnf-{map,mle,vi}.chickenpox.8.mini.pred.csv, produced by the
 three *skipped* tests tests/test_evaluate_mini.py:58-91) are bit-exact functions
-of JAX threefry keys.  Their RNG-independent projections are checked in
-tests/test_oracle_kat.py (KAT K1-K4 of SURVEY.md section 8c); the forward /
-gradient arithmetic itself is pinned by finite-difference and torch-autograd
-checks (tests/test_oracle_grad.py).  Element-wise parity with the goldens is
-"parity unpinned" (needs threefry + TFP sampler restatement).
+of JAX threefry keys.  With the random streams restated in oracle/jax_rng.py
+(threefry2x32, jax.random split / fold_in / normal / truncated_normal, TFP's
+JointDistribution / vectorised-sample / minimize seed plumbing -- determined
+against these very files) this module reproduces column `yhat` of all three
+element-wise: MAP 1.9e-6, MLE 5.0e-6, VI 2.5e-6 max abs (tests/test_jax_rng.py),
+the quantile columns as roots of the mixture CDF within the reference's own
+tolerance.  RNG-independent projections: tests/test_oracle_kat.py (KAT K1-K4 of
+SURVEY.md section 8c); gradients additionally against finite differences and
+torch autograd (tests/test_oracle_grad.py); NB / ZINB closed forms against
+scipy.stats.nbinom (tests/test_oracle_counts.py; the reference has no count golden).
 
 The oracle is RNG-free: initial parameters, minibatch row indices and VI
 noise are *inputs* (the tests read them back from the device library).

@@ -36,7 +36,9 @@ published behaviour and then DETERMINED against the reference's own golden files
 variant tried (salt strings, split order, iid_sample pre-steps; scripts/n1_chain_search.py keeps
 the search) exactly this one reproduces tests/test_data/bnf-map.chickenpox.8.mini.pred.csv and
 bnf-mle...pred.csv element-wise (max |yhat - golden| = 1.9e-6 / 5.0e-6 over the 100 training
-rows; any other chain is off by ~0.1).  Further known answers in tests/test_jax_rng.py:
+rows; any other chain is off by ~0.1).  The VI chain (three streams: initial surrogate means,
+optimisation noise, posterior draws -- bottom of this file) was determined the same way against
+bnf-vi...pred.csv: 2.5e-6, the next best of ~1,300 candidates 7e-3 (scripts/n1_vi_chain_search.py).  Further known answers in tests/test_jax_rng.py:
 split(PRNGKey(0)) and normal(PRNGKey(0), (10,)) / normal(PRNGKey(42)) as printed in the JAX
 documentation.
 """
