@@ -26,7 +26,7 @@ MODE_MAP, MODE_VI = 0, 1
 EXPORTS = (
     'bnf_abi_version', 'bnf_last_error', 'bnf_create', 'bnf_destroy',
     'bnf_workspace_bytes', 'bnf_state_bytes', 'bnf_param_bytes', 'bnf_bind',
-    'bnf_init_params', 'bnf_train', 'bnf_vi_posterior_draws', 'bnf_forward',
+    'bnf_init_params', 'bnf_train', 'bnf_vi_posterior_draws', 'bnf_vi_noise_keys', 'bnf_forward',
     'bnf_normal_mixture_quantiles', 'bnf_count_mixture_quantiles', 'bnf_debug_loss_and_grad',
     'bnf_debug_row_index', 'bnf_debug_vi_eps', 'bnf_debug_vi_noise', 'bnf_debug_activation',
     'bnf_debug_gemm_nt', 'bnf_debug_gemm_tn', 'bnf_profile_enable', 'bnf_profile_read',
@@ -117,6 +117,7 @@ def load():
   lib.bnf_debug_row_index.argtypes = [vp, i64, i64, vp]
   lib.bnf_debug_vi_eps.argtypes = [vp, i64, vp]
   lib.bnf_debug_vi_noise.argtypes = [vp, vp]
+  lib.bnf_vi_noise_keys.argtypes = [vp, vp, i64, vp, i64, vp, C.c_int32]
   lib.bnf_debug_activation.argtypes = [vp, i32, vp]
   lib.bnf_debug_gemm_nt.argtypes = [vp, vp, vp, i32, i32, i32, vp]
   lib.bnf_debug_gemm_tn.argtypes = [vp, vp, vp, i32, i32, i32, vp]

@@ -115,6 +115,11 @@ struct bnf_handle {
   float* stab_pred = nullptr;
   void* H0 = nullptr; void* H0t = nullptr;
   const float* ext_eps = nullptr;   // bnf_debug_vi_noise
+  // the reference's VI noise stream (bnf_vi_noise_keys / bnf_vi_draw_keys): caller-owned key tables,
+  // leaf tables in the workspace
+  const uint32_t* vi_keys = nullptr; int64_t vi_key_rows = 0, vi_key_t0 = 0;
+  const uint32_t* vi_draw_keys = nullptr; int64_t vi_draw_rows = 0;
+  int32_t* leaf_off = nullptr; uint8_t* leaf_id = nullptr; int32_t n_leaves = 0;
   bool h0l = false;
   void* A[BNF_MAX_LAYERS]; void* H[BNF_MAX_LAYERS]; void* Ht[BNF_MAX_LAYERS];
   void* dZ[BNF_MAX_LAYERS]; void* dZt[BNF_MAX_LAYERS];
@@ -210,6 +215,10 @@ static size_t carve(bnf_handle* h, char* base) {
   h->dbg_a = (float*)take(256);
   h->is_matrix = (uint8_t*)take((size_t)P);
   h->fbmeta = h->fbmeta_h.empty() ? nullptr : (int32_t*)take(h->fbmeta_h.size() * 4);
+  if (h->cfg.mode == BNF_MODE_VI) {
+    h->leaf_off = (int32_t*)take(260 * 4);
+    h->leaf_id = (uint8_t*)take((size_t)P);
+  }
   return off;
 }
 
@@ -833,6 +842,15 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
   return BNF_OK;
 }
 
+static JaxNoise jax_noise_for_step(const bnf_handle* h) {
+  JaxNoise jn{};
+  if (!h->vi_keys) return jn;
+  jn.keys = h->vi_keys; jn.leaf_off = h->leaf_off; jn.leaf_id = h->leaf_id;
+  jn.n_leaves = h->n_leaves; jn.S = h->S; jn.members = h->cfg.members;
+  jn.row = h->adam_t - h->vi_key_t0;
+  return jn;
+}
+
 template <typename T>
 static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride, bool apply,
                    float* gmu_out, float* grho_out) {
@@ -840,12 +858,16 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   const int E = h->cfg.members, S = h->S;
   float* mu = h->params;
   float* rho = h->params + (int64_t)E * h->P;
+  const JaxNoise jn = jax_noise_for_step(h);
+  if (jn.keys && (jn.row < 0 || jn.row >= h->vi_key_rows))
+    return fail(BNF_ERR_STATE, "VI step %lld is outside the noise-key table (%lld rows from step %lld)",
+                (long long)h->adam_t, (long long)h->vi_key_rows, (long long)h->vi_key_t0);
   {
     LaunchScope ls(h, KID_VISAMPLE);
     dim3 grid(cdiv(h->P, 256), (unsigned)E, (unsigned)((S + 3) / 4));
     hipLaunchKernelGGL(k_vi_sample, grid, dim3(256), 0, h->stream, mu, rho, h->P, S, h->cfg.seed,
                        h->cfg.member_offset, (uint64_t)step, (uint32_t)STREAM_VI_EPS, h->theta_c,
-                       (int64_t)S * h->P, (int64_t)h->P, h->ext_eps);
+                       (int64_t)S * h->P, (int64_t)h->P, h->ext_eps, jn);
   }
   const float kl = h->cfg.kl_weight;
   const float c = (float)((double)h->N / (double)h->B / (double)kl);
@@ -870,7 +892,7 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   a.bc1 = (float)(1.0 - std::pow(0.9, (double)t));
   a.bc2 = (float)(1.0 - std::pow(0.999, (double)t));
   a.kl_weight = kl; a.loss = loss; a.loss_stride = loss_stride; a.apply = apply ? 1 : 0;
-  a.gmu_out = gmu_out; a.grho_out = grho_out; a.ext_eps = h->ext_eps;
+  a.gmu_out = gmu_out; a.grho_out = grho_out; a.ext_eps = h->ext_eps; a.jn = jn;
   {
     LaunchScope ls(h, KID_VIADAM);
     dim3 grid(cdiv(h->P, 256), (unsigned)E);
@@ -1273,11 +1295,17 @@ int bnf_vi_posterior_draws(bnf_handle* h, int32_t n_draws, float* out) {
   HIPCHK(hipSetDevice(h->cfg.device));
   const int E = h->cfg.members;
   dim3 grid(cdiv(h->P, 256), (unsigned)E, (unsigned)((n_draws + 3) / 4));
+  JaxNoise jn{};
+  if (h->vi_draw_keys) {
+    if (n_draws > h->vi_draw_rows) return fail(BNF_ERR_INVALID, "n_draws exceeds the draw-key table");
+    jn.keys = h->vi_draw_keys; jn.leaf_off = h->leaf_off; jn.leaf_id = h->leaf_id;
+    jn.n_leaves = h->n_leaves; jn.S = n_draws; jn.members = E; jn.row = 0;
+  }
   // out[d][e][p]: member stride P, sample stride E*P
   hipLaunchKernelGGL(k_vi_sample, grid, dim3(256), 0, h->stream, h->params,
                      h->params + (int64_t)E * h->P, h->P, n_draws, h->cfg.seed,
                      h->cfg.member_offset, (uint64_t)0, (uint32_t)STREAM_VI_DRAW, out, (int64_t)h->P,
-                     (int64_t)E * h->P);
+                     (int64_t)E * h->P, (const float*)nullptr, jn);
   HIPCHK(hipGetLastError());
   return BNF_OK;
 }
@@ -1415,6 +1443,32 @@ int bnf_debug_row_index(bnf_handle* h, int64_t epoch, int64_t step, int32_t* out
   return BNF_OK;
 }
 
+int bnf_vi_noise_keys(bnf_handle* h, const uint32_t* step_keys, int64_t n_steps, const uint32_t* draw_keys,
+                      int64_t n_draws, const int32_t* leaf_offsets, int32_t n_leaves) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "not bound");
+  if (h->cfg.mode != BNF_MODE_VI) return fail(BNF_ERR_STATE, "not a VI handle");
+  if (!step_keys && !draw_keys) {   // back to the engine's own generator
+    h->vi_keys = h->vi_draw_keys = nullptr; h->vi_key_rows = h->vi_draw_rows = 0;
+    return BNF_OK;
+  }
+  if (!leaf_offsets || n_leaves < 1 || n_leaves > 255 || leaf_offsets[0] != 0 || leaf_offsets[n_leaves] != h->P)
+    return fail(BNF_ERR_INVALID, "leaf_offsets must be n_leaves + 1 increasing offsets from 0 to P (n_leaves <= 255)");
+  if ((step_keys && n_steps < 1) || (draw_keys && n_draws < 1)) return fail(BNF_ERR_INVALID, "key-table rows");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  std::vector<uint8_t> ids((size_t)h->P);
+  for (int l = 0; l < n_leaves; ++l) {
+    if (leaf_offsets[l + 1] <= leaf_offsets[l]) return fail(BNF_ERR_INVALID, "leaf_offsets not increasing");
+    for (int32_t p = leaf_offsets[l]; p < leaf_offsets[l + 1]; ++p) ids[(size_t)p] = (uint8_t)l;
+  }
+  HIPCHK(hipMemcpyAsync(h->leaf_off, leaf_offsets, (size_t)(n_leaves + 1) * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->leaf_id, ids.data(), (size_t)h->P, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));   // ids is a stack-owned host buffer
+  h->n_leaves = n_leaves;
+  h->vi_keys = step_keys; h->vi_key_rows = step_keys ? n_steps : 0; h->vi_key_t0 = h->adam_t;
+  h->vi_draw_keys = draw_keys; h->vi_draw_rows = draw_keys ? n_draws : 0;
+  return BNF_OK;
+}
+
 int bnf_debug_vi_noise(bnf_handle* h, const float* eps) {
   if (!h || !h->bound) return fail(BNF_ERR_STATE, "not bound");
   if (h->cfg.mode != BNF_MODE_VI) return fail(BNF_ERR_STATE, "not a VI handle");
@@ -1426,8 +1480,13 @@ int bnf_debug_vi_eps(bnf_handle* h, int64_t step, float* out) {
   if (!h || !h->bound || !out) return fail(BNF_ERR_STATE, "not bound / null");
   HIPCHK(hipSetDevice(h->cfg.device));
   dim3 grid(cdiv(h->P, 256), (unsigned)h->cfg.members, (unsigned)h->S);
+  JaxNoise jn = jax_noise_for_step(h);
+  if (jn.keys) {
+    jn.row = step - h->vi_key_t0;
+    if (jn.row < 0 || jn.row >= h->vi_key_rows) return fail(BNF_ERR_INVALID, "step outside the noise-key table");
+  }
   hipLaunchKernelGGL(k_vi_eps_dump, grid, dim3(256), 0, h->stream, h->P, h->cfg.seed,
-                     h->cfg.member_offset, (uint64_t)step, out);
+                     h->cfg.member_offset, (uint64_t)step, out, jn);
   HIPCHK(hipGetLastError());
   return BNF_OK;
 }

@@ -501,6 +501,68 @@ __device__ __forceinline__ float vi_eps(uint64_t seed, uint32_t member_global, u
 }
 
 // ---------------------------------------------------------------------------
+// The reference's OWN VI noise (optional; full-batch fits started by BayesianNeuralFieldVI.fit):
+// jax.random.normal(key, (E, *leaf shape)) per leaf, with the per-(step, sample, leaf) keys of
+// tfp.vi.fit_surrogate_posterior_stateless's seed chain computed on the host once per fit
+// (bayesnf_amd/jaxseed.py: vi_noise_keys).  Restated here: threefry2x32 over iota(n) split in
+// halves (element i < ceil(n/2) is word 0 of the pair (i, i + h), element i >= h word 1 of (i - h, i);
+// odd n is padded with one zero count), uniform on [nextafter(-1, 0), 1), sqrt(2) erfinv (the
+// single-precision polynomial of Giles 2010 that XLA uses).
+// ---------------------------------------------------------------------------
+struct JaxNoise {
+  const uint32_t* keys;      // (rows, S, n_leaves, 2) ; null = not in use
+  const int32_t* leaf_off;   // (n_leaves + 1) offsets of the leaves in the packed parameter vector
+  const uint8_t* leaf_id;    // (P) leaf index of every packed parameter
+  int32_t n_leaves, S, members;
+  int64_t row;               // key-table row of this launch (optimisation step or posterior draw)
+};
+__device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t x0, uint32_t x1,
+                                             uint32_t* y0, uint32_t* y1) {
+  const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  x0 += k0; x1 += k1;
+#define BNF_TF(r) x0 += x1; x1 = ((x1 << (r)) | (x1 >> (32 - (r)))) ^ x0;
+  BNF_TF(13) BNF_TF(15) BNF_TF(26) BNF_TF(6)  x0 += k1; x1 += k2 + 1u;
+  BNF_TF(17) BNF_TF(29) BNF_TF(16) BNF_TF(24) x0 += k2; x1 += k0 + 2u;
+  BNF_TF(13) BNF_TF(15) BNF_TF(26) BNF_TF(6)  x0 += k0; x1 += k1 + 3u;
+  BNF_TF(17) BNF_TF(29) BNF_TF(16) BNF_TF(24) x0 += k1; x1 += k2 + 4u;
+  BNF_TF(13) BNF_TF(15) BNF_TF(26) BNF_TF(6)  x0 += k2; x1 += k0 + 5u;
+#undef BNF_TF
+  *y0 = x0; *y1 = x1;
+}
+__device__ __forceinline__ float erfinv_f32(float x) {
+  float w = -log1pf(-x * x), p;
+  if (w < 5.0f) {
+    w -= 2.5f;
+    p = 2.81022636e-08f;
+    p = fmaf(p, w, 3.43273939e-07f); p = fmaf(p, w, -3.5233877e-06f); p = fmaf(p, w, -4.39150654e-06f);
+    p = fmaf(p, w, 0.00021858087f); p = fmaf(p, w, -0.00125372503f); p = fmaf(p, w, -0.00417768164f);
+    p = fmaf(p, w, 0.246640727f); p = fmaf(p, w, 1.50140941f);
+  } else {
+    w = sqrtf(w) - 3.0f;
+    p = -0.000200214257f;
+    p = fmaf(p, w, 0.000100950558f); p = fmaf(p, w, 0.00134934322f); p = fmaf(p, w, -0.00367342844f);
+    p = fmaf(p, w, 0.00573950773f); p = fmaf(p, w, -0.0076224613f); p = fmaf(p, w, 0.00943887047f);
+    p = fmaf(p, w, 1.00167406f); p = fmaf(p, w, 2.83297682f);
+  }
+  return p * x;
+}
+// standard normal of (member e, sample s, packed parameter p) in the reference's stream
+__device__ __forceinline__ float jax_normal(const JaxNoise& jn, int e, int s, int p) {
+  const int lf = jn.leaf_id[p];
+  const int off = jn.leaf_off[lf], size = jn.leaf_off[lf + 1] - off;
+  const uint32_t n = (uint32_t)jn.members * (uint32_t)size, idx = (uint32_t)e * (uint32_t)size + (uint32_t)(p - off);
+  const uint32_t h = (n + 1u) >> 1;
+  const uint32_t* k = jn.keys + (((jn.row * jn.S + s) * jn.n_leaves + lf) << 1);
+  uint32_t y0, y1;
+  if (idx < h) threefry2x32(k[0], k[1], idx, idx + h < n ? idx + h : 0u, &y0, &y1);
+  else { threefry2x32(k[0], k[1], idx - h, idx, &y0, &y1); y0 = y1; }
+  const float f = __builtin_bit_cast(float, (y0 >> 9) | 0x3F800000u) - 1.0f;
+  const float lo = -0.99999994f;                       // nextafter(-1, 0)
+  const float u = fmaxf(lo, f * (1.0f - lo) + lo);
+  return 1.41421356237309504880f * erfinv_f32(u);
+}
+
+// ---------------------------------------------------------------------------
 // Keyed Feistel bijection on [0, n): a pseudo-random permutation evaluated
 // per element (no index array in HBM).  Replaces jax.random.permutation in
 // permute_dataset (inference.py:35-39) and in ensemble_vi (inference.py:706).

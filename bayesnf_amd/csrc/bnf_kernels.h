@@ -735,7 +735,8 @@ __global__ __launch_bounds__(256) void k_vi_sample(const float* __restrict__ mu,
                                                    int32_t S, uint64_t seed, int64_t member_offset,
                                                    uint64_t step, uint32_t stream,
                                                    float* __restrict__ z, int64_t z_member_stride,
-                                                   int64_t z_sample_stride, const float* __restrict__ ext_eps = nullptr) {
+                                                   int64_t z_sample_stride, const float* __restrict__ ext_eps = nullptr,
+                                                   JaxNoise jn = JaxNoise{}) {
   // grid: (ceil(P/256), members, ceil(S/4)): one Philox call serves the four samples of a group
   const int e = blockIdx.y, s0 = blockIdx.z * 4;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -746,6 +747,10 @@ __global__ __launch_bounds__(256) void k_vi_sample(const float* __restrict__ mu,
   if (ext_eps) {   // bnf_debug_vi_noise: the caller's standard normals, (members, S, P)
 #pragma unroll
     for (int k = 0; k < 4; ++k) n4.v[k] = ext_eps[((int64_t)e * S + min(s0 + k, S - 1)) * P + p];
+  } else if (jn.keys) {   // the reference's stream (jaxseed.vi_noise_keys)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (s0 + k < S) n4.v[k] = jax_normal(jn, e, s0 + k, p);
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k)
@@ -763,6 +768,7 @@ struct ViAdamArgs {
   int32_t apply;
   float* gmu_out; float* grho_out;  // debug: (members, P) each
   const float* ext_eps;             // bnf_debug_vi_noise: (members, S, P) standard normals instead of the generator's
+  JaxNoise jn;                      // the reference's stream when jn.keys != null
 };
 
 __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
@@ -782,6 +788,10 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
       if (a.ext_eps) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) n4.v[k] = a.ext_eps[((int64_t)e * a.S + min(s0 + k, a.S - 1)) * a.P + p];
+      } else if (a.jn.keys) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (s0 + k < a.S) n4.v[k] = jax_normal(a.jn, e, s0 + k, p);
       }
       float gl[4];   // the four likelihood gradients in flight together
 #pragma unroll
@@ -863,12 +873,13 @@ __global__ void k_row_index(RowSrc rs, int64_t B, int32_t* out) {
 }
 
 __global__ void k_vi_eps_dump(int32_t P, uint64_t seed, int64_t member_offset, uint64_t step,
-                              float* out) {
+                              float* out, JaxNoise jn) {
   const int e = blockIdx.y, s = blockIdx.z, S = gridDim.z;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < P)
     out[((int64_t)e * S + s) * P + p] =
-        vi_eps(seed, (uint32_t)(member_offset + e), (uint32_t)s, (uint32_t)p, step, STREAM_VI_EPS);
+        jn.keys ? jax_normal(jn, e, s, p)
+                : vi_eps(seed, (uint32_t)(member_offset + e), (uint32_t)s, (uint32_t)p, step, STREAM_VI_EPS);
 }
 
 // predict: aux[e] = {0.01 + exp(lns), softplus(shape), sigmoid(infl)}

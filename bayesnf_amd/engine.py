@@ -220,6 +220,22 @@ class Engine:
     torch.cuda.synchronize(self.device)
     return out.cpu().numpy()
 
+  def set_vi_noise_keys(self, step_keys, draw_keys, leaf_offsets):
+    """The reference's VI noise stream (include/bnf.h bnf_vi_noise_keys): key tables from
+    jaxseed.vi_noise_keys / vi_draw_keys (uint32 numpy), uploaded and kept alive here."""
+    if step_keys is None and draw_keys is None:
+      self._vi_keys = None
+      _native.check(self.lib.bnf_vi_noise_keys(self.handle, None, 0, None, 0, None, 0), 'bnf_vi_noise_keys')
+      return
+    up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint32).view(np.int32)).to(self.device)
+    sk, dk = up(step_keys), up(draw_keys)
+    lo = np.ascontiguousarray(leaf_offsets, dtype=np.int32)
+    self._vi_keys = (sk, dk)
+    _native.check(self.lib.bnf_vi_noise_keys(
+        self.handle, None if sk is None else _ptr(sk), 0 if sk is None else int(step_keys.shape[0]),
+        None if dk is None else _ptr(dk), 0 if dk is None else int(draw_keys.shape[0]),
+        lo.ctypes.data_as(C.c_void_p), int(len(lo) - 1)), 'bnf_vi_noise_keys')
+
   def debug_vi_noise(self, eps):
     """Verification hook (include/bnf.h bnf_debug_vi_noise): every following VI step reads its
     (members, S, P) standard normals from `eps` (device tensor, kept alive here); None restores

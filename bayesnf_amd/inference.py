@@ -146,6 +146,13 @@ def fit_vi(features, target, seed, observation_model, model_args, ensemble_size,
     p0 = eng.get_params()
     p0[0] = mu0
     eng.set_params(p0)
+    if batch_size is None or batch_size >= n_rows:
+      # full batch: the optimisation noise and the posterior draws come from the reference's stream too
+      # (keys on the host once per fit, normals on the device), so the whole fit follows the reference;
+      # minibatch fits also need its per-step row permutation and stay on the engine's generator
+      eng.set_vi_noise_keys(jaxseed.vi_noise_keys(net, seed, world, rank, num_epochs, sample_size_divergence),
+                            jaxseed.vi_draw_keys(net, seed, world, rank, sample_size_posterior),
+                            jaxseed.leaf_offsets(net))
   loss_dev = eng.train(0, num_epochs)
   draws = eng.vi_posterior_draws(sample_size_posterior)   # (n, E_local, P)
   mu_rho = eng.params.view(2, per_device, net.P)

@@ -142,3 +142,65 @@ def vi_initial_means(net, seed, world: int, per_device: int) -> np.ndarray:
       if len(lf.shape) == 2:
         mu[e, lf.offset:lf.offset + lf.size] = truncated_normal_std(mean_seed, lf.size)
   return mu.reshape(world, per_device, net.P)
+
+
+# ----------------------------------------------------------------------------- VI noise keys
+def _split_many(keys: np.ndarray, n: int) -> np.ndarray:
+  """split(key, n) for an array of keys (..., 2) -> (..., n, 2)."""
+  keys = np.asarray(keys, dtype=_U32)
+  c = np.arange(2 * n, dtype=_U32)
+  y0, y1 = _threefry((keys[..., 0, None], keys[..., 1, None]), c[:n], c[n:])
+  return np.concatenate([y0, y1], axis=-1).reshape(keys.shape[:-1] + (n, 2))
+
+
+def _fold_in_many(keys: np.ndarray, data: int) -> np.ndarray:
+  keys = np.asarray(keys, dtype=_U32)
+  y0, y1 = _threefry((keys[..., 0], keys[..., 1]), np.zeros((), _U32), np.asarray(data & 0xFFFFFFFF, dtype=_U32))
+  return np.stack([y0, y1], axis=-1)
+
+
+def _jd_leaf_keys(keys: np.ndarray, n_leaves: int) -> np.ndarray:
+  """per-leaf sample seeds of one JointDistribution execution per key: (..., 2) -> (..., n_leaves, 2)."""
+  k = _fold_in_many(keys, _JD_SALT)
+  out = np.empty(k.shape[:-1] + (n_leaves, 2), dtype=_U32)
+  for i in range(n_leaves):
+    pair = _split_many(k, 2)
+    out[..., i, :] = pair[..., 0, :]
+    k = pair[..., 1, :]
+  return out
+
+
+_MINIMIZE_SALT = int(hashlib.sha512(b'minimize').hexdigest(), 16) & 0xFFFFFFFF
+
+
+def vi_noise_keys(net, seed, world: int, rank: int, num_steps: int, sample_size: int):
+  """Key tables of the reference's VI noise for device `rank` (ensemble_vi, inference.py:722-753, through
+  tfp.vi.fit_surrogate_posterior_stateless / tfp.math.minimize_stateless; determined against the
+  reference's VI golden, oracle/jax_rng.py):
+     init_seed, opt_seed = split(seed); fit_seed, sample_seed = split(opt_seed)
+     s = fold_in(split(fit_seed, devices)[rank], 'minimize'); before every step s = split(s)[0];
+     the step's `sample_size` joint samples: keys = split(fold_in(s, 'iid_sample_stateless'), sample_size),
+     each -> fold_in 'JointDistribution', one split per leaf
+  -> uint32 (num_steps, sample_size, n_leaves, 2).  (Two steps are what the golden validates.)"""
+  opt_seed = split(as_key(seed), 2)[1]
+  fit_seed = split(opt_seed, 2)[0]
+  s = fold_in(split(fit_seed, world)[rank], _MINIMIZE_SALT)
+  states = np.empty((num_steps, 2), dtype=_U32)
+  for k in range(num_steps):
+    s = split(s, 2)[0]
+    states[k] = s
+  sample_keys = _split_many(_fold_in_many(states, _IID_SALT), sample_size)     # (steps, S, 2)
+  return _jd_leaf_keys(sample_keys, len(net.leaves))
+
+
+def vi_draw_keys(net, seed, world: int, rank: int, num_draws: int):
+  """Key table of the posterior draws (inference.py:741-753): uint32 (num_draws, n_leaves, 2)."""
+  opt_seed = split(as_key(seed), 2)[1]
+  sample_seed = split(split(opt_seed, 2)[1], world)[rank]
+  return _jd_leaf_keys(_split_many(fold_in(sample_seed, _IID_SALT), num_draws), len(net.leaves))
+
+
+def leaf_offsets(net) -> np.ndarray:
+  """int32 (n_leaves + 1): offsets of the packed leaves in the reference's order."""
+  off = [lf.offset for lf in net.leaves] + [net.P]
+  return np.asarray(off, dtype=np.int32)

@@ -162,6 +162,20 @@ int bnf_train(bnf_handle* h, int64_t epoch0, int64_t num_epochs, float* losses /
  * surrogate (inference.py:741-745).  out: DEVICE (n_draws, members, P) f32. */
 int bnf_vi_posterior_draws(bnf_handle* h, int32_t n_draws, float* out /*DEVICE*/);
 
+/* The reference's OWN random stream for the VI noise (optional; without it the noise comes from the
+ * engine's counter-based generator -- same law, other numbers).  tfp.vi.fit_surrogate_posterior_stateless
+ * (inference.py:727-738) draws, at every step, `vi_samples` joint samples of the surrogate, each leaf
+ * with jax.random.normal(key, (members, *leaf shape)); ensemble_vi's posterior draws (:741-753) likewise.
+ * The keys are pure functions of the user's seed (threefry split / fold_in chains: bayesnf_amd/jaxseed.py
+ * computes them on the host once per fit); the normals themselves are generated on the device.
+ *   step_keys DEVICE uint32 (n_steps, vi_samples, n_leaves, 2): row i serves the i-th bnf_train step
+ *             counted from this call; training beyond the table fails with BNF_ERR_STATE
+ *   draw_keys DEVICE uint32 (n_draws, n_leaves, 2) for bnf_vi_posterior_draws
+ *   leaf_offsets HOST int32 (n_leaves + 1): offsets of the parameter leaves, in the reference's order
+ * Both tables are caller-owned and must stay alive; NULL, NULL restores the engine's generator. */
+int bnf_vi_noise_keys(bnf_handle* h, const uint32_t* step_keys, int64_t n_steps, const uint32_t* draw_keys,
+                      int64_t n_draws, const int32_t* leaf_offsets, int32_t n_leaves);
+
 /* ---- prediction ------------------------------------------------------------ */
 /* forecast_inner over all members (inference.py:103-126,129-200): theta is
  * DEVICE (n_members, P) f32 (any count; processed in chunks), Xnew DEVICE

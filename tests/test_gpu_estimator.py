@@ -274,3 +274,45 @@ def test_reference_vi_golden_reproduced_through_the_engine(golden_dir):
   yhat = loc.cpu().numpy().mean(axis=0)
   fwd.close()
   assert np.abs(yhat - gold.yhat.values).max() < 1e-4, np.abs(yhat - gold.yhat.values).max()
+
+
+def test_vi_fit_reproduces_the_reference_golden(golden_dir):
+  """The product path, no hooks: BayesianNeuralFieldVI.fit(seed=PRNGKey(0)) with the reference's mini
+  configuration (tests/test_evaluate_mini.py:81-91) draws the reference's initial surrogate means, its
+  optimisation noise and its posterior draws (keys on the host -- jaxseed --, jax.random.normal restated on
+  the device: threefry2x32 + erfinv) and reproduces bnf-vi.chickenpox.8.mini.pred.csv element-wise."""
+  import torch
+  from oracle import jax_rng as R
+  from tests.test_oracle_kat import _setup
+  from bayesnf_amd import spatiotemporal as st
+  df = _train_frame(golden_dir)
+  gold = pd.read_csv(os.path.join(golden_dir, 'bnf-vi.chickenpox.8.mini.pred.csv'), index_col=0).iloc[:100]
+  est = BayesianNeuralFieldVI(**MODEL, compute_dtype='fp32').fit(
+      df, seed=np.array([0, 0], dtype=np.uint32), ensemble_size=1, num_epochs=2, learning_rate=0.01,
+      kl_weight=0.1, sample_size_divergence=5, sample_size_posterior=30)
+  means, qs = est.predict(df, quantiles=(0.5, 0.025, 0.975))
+  yhat = np.asarray(means).mean(axis=(0, 1, 2))
+  assert np.abs(yhat - gold.yhat.values).max() < 1e-4, np.abs(yhat - gold.yhat.values).max()
+  for col, got in [('yhat_p50', qs[0]), ('yhat_lower', qs[1]), ('yhat_upper', qs[2])]:
+    assert np.abs(got - gold[col].values).max() < 5e-3, col
+  # the device generator against the oracle's restatement of jax.random.normal, value by value
+  from bayesnf_amd import jaxseed, inference as bnf_inference
+  from bayesnf_amd.engine import Engine
+  model, X, y = _setup(golden_dir, st.BayesianNeuralFieldVI)
+  net = bnf_inference._net_from_args(est._model_args(est.data_handler.get_train(df).shape), 'NORMAL')
+  seed = R.prng_key(0)
+  for E in (1, 3):
+    eng = Engine(net, mode='vi', X=X, y=y, members=E, vi_samples=5, kl_weight=0.1, learning_rate=0.01, seed=0,
+                 compute_dtype='fp32')
+    eng.init_params(0.0)
+    eng.set_vi_noise_keys(jaxseed.vi_noise_keys(net, seed, 1, 0, 2, 5), jaxseed.vi_draw_keys(net, seed, 1, 0, 7),
+                          jaxseed.leaf_offsets(net))
+    ref = R.reference_vi_step_noise(model, seed, 2, 5, E)
+    for s in range(2):
+      # (float32 erfinv polynomial on the device vs scipy's erfinv in the oracle: relative 6e-6 in the tails)
+      np.testing.assert_allclose(eng.debug_vi_eps(s), ref[s], rtol=2e-5, atol=3e-6)
+    p = eng.get_params().astype(np.float64)
+    draws = eng.vi_posterior_draws(7).cpu().numpy()
+    eps = R.reference_vi_posterior_noise(model, seed, 7, E)
+    np.testing.assert_allclose(draws, p[0][None] + O.vi_sigma(p[1])[None] * eps, rtol=2e-5, atol=2e-5)
+    eng.close()

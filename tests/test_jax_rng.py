@@ -128,3 +128,27 @@ def test_product_vi_initial_means_equal_the_oracle_chain(golden_dir):
     got = jaxseed.vi_initial_means(net, key, 2, 3).reshape(6, -1)
     ref = R.reference_vi_init_means(model, key, 6).astype(np.float32)
     np.testing.assert_array_equal(got, ref)
+
+
+def test_product_vi_noise_keys_equal_the_oracle_chain(golden_dir):
+  """jaxseed.vi_noise_keys / vi_draw_keys (host part of the product's reference-compatible VI noise; the
+  normals are generated on the device from these keys) against the oracle's noise arrays."""
+  from bayesnf_amd import jaxseed
+  model, X, y = _setup(golden_dir, st.BayesianNeuralFieldVI)
+  class _Net:   # the two attributes jaxseed reads
+    leaves = model.leaves
+    P = model.P
+  seed = R.prng_key(0)
+  keys = jaxseed.vi_noise_keys(_Net, seed, 1, 0, 2, 5)
+  assert keys.shape == (2, 5, len(model.leaves), 2) and keys.dtype == np.uint32
+  noise = R.reference_vi_step_noise(model, seed, 2, 5, 1)
+  dk = jaxseed.vi_draw_keys(_Net, seed, 1, 0, 4)
+  draws = R.reference_vi_posterior_noise(model, seed, 4, 1)
+  for i, lf in enumerate(model.leaves):
+    if lf.size > 4000:
+      continue
+    for k in range(2):
+      for j in (0, 4):
+        np.testing.assert_array_equal(R.normal(keys[k, j, i], (lf.size,)), noise[k][0, j, lf.offset:lf.offset + lf.size])
+    np.testing.assert_array_equal(R.normal(dk[3, i], (lf.size,)), draws[3, 0, lf.offset:lf.offset + lf.size])
+  np.testing.assert_array_equal(jaxseed.leaf_offsets(_Net), [lf.offset for lf in model.leaves] + [model.P])
