@@ -11,7 +11,9 @@
 //   dH0 = dZ0 K0^T /sqrt F                                                   -> HBM (f32, transposed)
 //
 // What leaves the chip is exactly what the weight-gradient contractions (gemm_tn) and the feature
-// backward kernel read afterwards: H1, dZ1, dZ0 (bf16, row-major) and dH0^T.  It replaces
+// backward kernel read afterwards: H1, dZ1, dZ0 (bf16, row-major) and dH0^T -- the latter only for
+// the variants that still run k_feat_bwd: <8, 4, true> (C2) finishes the featurisation backward
+// itself from the dH0 tiles in registers and the feature panel in LDS (phase 9).  It replaces
 // gemm_fwd_l0 + gemm_fwd_last + gemm_dgrad + gemm_dgrad0 of the layer pipeline (and their HBM
 // round trips of H1 / dZ1 / dZ0 as contraction operands: 2.0 GB of the 8.0 GB per C2 step).
 //
