@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-echo "== probe"; timeout 300 scripts/probes/panel_probe > "$OUT/panel_probe.txt" 2>&1; echo "probe rc=$?"; cat "$OUT/panel_probe.txt"
+echo "== probe"; [ -x scripts/probes/panel_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/probes/panel_probe scripts/probes/panel_probe.hip; timeout 300 scripts/probes/panel_probe > "$OUT/panel_probe.txt" 2>&1; echo "probe rc=$?"; cat "$OUT/panel_probe.txt"
 echo "== pytest configs"; timeout 1500 python -m pytest tests/test_gpu_configs.py -m gpu -q -p no:cacheprovider -x > "$OUT/pytest_configs.txt" 2>&1; echo "pytest rc=$?"
 tail -15 "$OUT/pytest_configs.txt"
 cd /tmp && export TMPDIR=/tmp
