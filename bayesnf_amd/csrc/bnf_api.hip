@@ -672,7 +672,7 @@ static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
   jb.tile0[2] = tiles;
   if (h->L == 1) jb.tile0[1] = tiles;
   hipLaunchKernelGGL((k_pack_layers<T>), dim3((unsigned)tiles, (unsigned)nmem), dim3(256), 0, h->stream,
-                     theta, (int64_t)h->Pf, jb);
+                     theta, (int64_t)h->Pf, jb, h->nd, h->scal);
 }
 
 // ---------------------------------------------------------------------------
@@ -703,8 +703,7 @@ static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
 static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs, float c,
                       const LossSink& sink) {
   const int64_t Bp = h->Bp;
-  hipLaunchKernelGGL(k_member_scalars, dim3(cdiv(nmem, 64)), dim3(64), 0, h->stream, h->nd, theta,
-                     (int64_t)h->Pf, (int32_t)nmem, h->scal);
+  run_pack_fragments<bf16_t>(h, theta, nmem);     // also fills the member scalar table the next kernels read
   {
     LaunchScope ls(h, KID_FEAT);
     dim3 grid(cdiv(h->B, kFeatRows), (unsigned)nmem);
@@ -715,7 +714,6 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
                        h->y, h->scal, h->B, (bf16_t*)h->H0, Bp * h->Fp, (bf16_t*)h->H0t,
                        (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp);
   }
-  run_pack_fragments<bf16_t>(h, theta, nmem);
   bool feat_bwd_fused = false;
   PanelArgs pa{};
   pa.F = h->F; pa.Fp = h->Fp; pa.B = (int32_t)h->B; pa.members = nmem; pa.Wt = h->Wt;

@@ -356,17 +356,18 @@ __global__ __launch_bounds__(256) void k_feat_bwd(
 // them instead of re-deriving them in every lane): softplus(layer scale_l), sigmoid(activation
 // weight), softplus(output scale)         models.py:256-273
 // ---------------------------------------------------------------------------
-__global__ void k_member_scalars(NetDev nd, const float* __restrict__ theta, int64_t stride, int32_t n,
-                                 float* __restrict__ scal) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const float* th = theta + (int64_t)e * stride;
-  float* o = scal + (int64_t)e * kScalStride;
+__device__ __forceinline__ void member_scalars_row(const NetDev& nd, const float* __restrict__ th, float* __restrict__ o) {
   for (int l = 0; l < nd.depth; ++l) o[l] = softplusf(th[nd.off_ls[l]]);
   o[BNF_MAX_LAYERS] = sigmoidf(th[nd.off_law]);
   o[BNF_MAX_LAYERS + 1] = softplusf(th[nd.off_os]);
   for (int g = 0; g < nd.n_groups; ++g) o[kScalGroup + g] = softplusf(th[nd.group_scale_off[g]]);
   for (int d = 0; d < nd.D; ++d) o[kScalInput + d] = nd.in_scale[d] * expf(th[nd.off_lsa + d]);
+}
+__global__ void k_member_scalars(NetDev nd, const float* __restrict__ theta, int64_t stride, int32_t n,
+                                 float* __restrict__ scal) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  member_scalars_row(nd, theta + (int64_t)e * stride, scal + (int64_t)e * kScalStride);
 }
 
 // ---------------------------------------------------------------------------

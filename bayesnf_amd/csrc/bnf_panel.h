@@ -97,11 +97,14 @@ struct PackJobs {
   void* wf[2]; void* wb[2];
   int64_t batch[2];
 };
+// Workgroup 0 of a member also fills the member's row of the transformed-scalar table
+// (k_member_scalars folded in: one launch and one dependent-launch gap less per step).
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ theta, int64_t theta_stride,
-                                                     PackJobs jb) {
+                                                     PackJobs jb, NetDev nd, float* __restrict__ scal) {
   __shared__ float tile[64][65];
   const int e = blockIdx.y;
+  if (scal && blockIdx.x == 0 && threadIdx.x == 0) member_scalars_row(nd, theta + (int64_t)e * theta_stride, scal + (int64_t)e * kScalStride);
   const int l = ((int)blockIdx.x >= jb.tile0[1] && jb.n_layers > 1) ? 1 : 0;
   const int t = (int)blockIdx.x - jb.tile0[l];
   const int W = jb.W, tn = W / 64;
