@@ -124,7 +124,7 @@ def _cpu_worker(args):
   ts = TorchStep(model, X, y, lr=0.005)
   ts.train(theta0, 1)                                    # warm-up
   if _CPU_BARRIER is not None:
-    _CPU_BARRIER.wait()                                  # every process starts its timed steps together
+    _CPU_BARRIER.wait(timeout=300)                       # every process starts its timed steps together
   t0 = time.time()
   _, losses = ts.train(theta0, steps)
   t1 = time.time()
@@ -149,19 +149,23 @@ def cpu_baseline(X, y, input_scales, members=8, steps=3):
   tried = {}
   with ctx.Pool(1) as pool:
     for nt in sorted({n_max, max(1, n_max // 2), max(1, n_max // 4), min(n_max, 16), min(n_max, 8)}, reverse=True):
-      t0, t1 = pool.map(_cpu_worker, [(X, y, input_scales, members, steps, nt, 0)])[0]
+      t0, t1 = pool.map_async(_cpu_worker, [(X, y, input_scales, members, steps, nt, 0)]).get(timeout=900)[0]
       tried[nt] = round(members * steps / (t1 - t0), 3)
   nt = max(tried, key=tried.get)
   procs = max(1, n_max // nt)
   value, cores = tried[nt], nt
   if procs > 1:
-    with ctx.Pool(procs, initializer=_cpu_pool_init, initargs=(ctx.Barrier(procs),)) as pool:
-      spans = pool.map(_cpu_worker, [(X, y, input_scales, members, steps, nt, k) for k in range(procs)], chunksize=1)
-    span = max(t for _, t in spans) - min(t for t, _ in spans)
-    v = procs * members * steps / span
-    tried[f'{procs}x{nt}'] = round(v, 3)
-    if v > value:
-      value, cores = v, procs * nt
+    try:   # (a worker that dies must not hang the bench: bounded waits, and the single-process figure stands)
+      with ctx.Pool(procs, initializer=_cpu_pool_init, initargs=(ctx.Barrier(procs),)) as pool:
+        spans = pool.map_async(_cpu_worker, [(X, y, input_scales, members, steps, nt, k) for k in range(procs)],
+                               chunksize=1).get(timeout=900)
+      span = max(t for _, t in spans) - min(t for t, _ in spans)
+      v = procs * members * steps / span
+      tried[f'{procs}x{nt}'] = round(v, 3)
+      if v > value:
+        value, cores = v, procs * nt
+    except Exception as exc:  # pylint: disable=broad-except
+      tried[f'{procs}x{nt}'] = f'failed: {type(exc).__name__}'
   cpu = 'unknown'
   try:
     with open('/proc/cpuinfo') as f:
