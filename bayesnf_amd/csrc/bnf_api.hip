@@ -120,6 +120,7 @@ struct bnf_handle {
   const uint32_t* vi_keys = nullptr; int64_t vi_key_rows = 0, vi_key_t0 = 0;
   const uint32_t* vi_draw_keys = nullptr; int64_t vi_draw_rows = 0;
   int32_t* leaf_off = nullptr; uint8_t* leaf_id = nullptr; int32_t n_leaves = 0;
+  bool adam_clear_all = false;   // env BNF_ADAM_CLEAR_ALL (A/B of the kept gradient range)
   bool h0l = false;
   void* A[BNF_MAX_LAYERS]; void* H[BNF_MAX_LAYERS]; void* Ht[BNF_MAX_LAYERS];
   void* dZ[BNF_MAX_LAYERS]; void* dZt[BNF_MAX_LAYERS];
@@ -820,7 +821,7 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
   a.apply = apply ? 1 : 0; a.loss_raw = sink.raw; a.st = sink.st;
   // the largest hidden-layer kernel whose gradient the next step stores (no split-K) is not cleared
   a.keep_lo = a.keep_hi = 0;
-  if (!h->pad && h->P % 4 == 0 && !getenv("BNF_ADAM_CLEAR_ALL"))
+  if (!h->pad && h->P % 4 == 0 && !h->adam_clear_all)
     for (int l = 1; l < h->L; ++l)
       if (wgrad_splitk(h, E, l) == 1 && a.keep_hi == 0) {
         a.keep_lo = (h->nd.off_kernel[l] + 3) / 4 * 4;
@@ -1039,6 +1040,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   if (const char* ab = getenv("BNF_ABLATE")) h->ablate = atoi(ab);
   if (const char* bt = getenv("BNF_BIG_TILES")) h->big_tiles = atoi(bt);
   if (const char* gm = getenv("BNF_GRAPH")) h->graph_mode = atoi(gm);
+  h->adam_clear_all = getenv("BNF_ADAM_CLEAR_ALL") != nullptr;
   {
     int want = cfg->pipeline;  // 0 auto, 1 layer kernels with every activation materialised, 3 row-panel kernel
     if (const char* pf = getenv("BNF_PIPELINE")) want = atoi(pf);
