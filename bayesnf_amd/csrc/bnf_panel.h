@@ -709,6 +709,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       }
       block_to_global(L, a.dZ0, i);
     }
+    BNF_MARK(a, 9);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float c = cs2[j].x + cs2[j].y;
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       for (int u = 0; u < KS1; ++u) fb[u] = *reinterpret_cast<const bf16x8*>(bp + (size_t)u * 1024);
     };
     if (wave < n_t) load_b(wave);
-    BNF_MARK(a, 9);
+    BNF_MARK(a, 10);
     lds_barrier();
     for (int t = wave; t < n_t; t += 8) {
       const int mi = t / ct, ni = t - mi * ct;
@@ -794,6 +795,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
                (c0[rg * 4 + 2] + c1[rg * 4 + 2]) * inv_sf, (c0[rg * 4 + 3] + c1[rg * 4 + 3]) * inv_sf);
     }
   }
+  BNF_MARK(a, 11);
   if constexpr (H0L) {
     if (a.fbmeta) {
       static_assert(!H0L || (BM == 128 && W >= 512), "fused featurisation backward: 4 row tiles x 64 columns in s_col[W..2W)");
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       }
     }
   }
-  BNF_MARK(a, 10);
+  BNF_MARK(a, 12);
   for (int c = tid; c < W; c += 512) {
     float b = 0.f;
 #pragma unroll
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     atomicAdd(&gr[a.off_law], alpha * (1.f - alpha) * ta);
     atomicAdd(&gr[a.off_ls0], dgam0 * tg);
   }
-  BNF_MARK(a, 11);
+  BNF_MARK(a, 13);
 }
 
 }  // namespace bnf
