@@ -136,6 +136,9 @@ struct bnf_handle {
   int prof_threads = 0;
   bool recompute_a0 = false;  // layer-0 pre-activation recomputed in the backward pass (DGRAD TAG 2)
   bool fuse_last = false;     // last layer + likelihood + its backward in one kernel (EPI_LAST)
+  int num_cus = 256;          // multiProcessorCount of the device
+  int tn_ring = 1;            // env BNF_TN_RING=0: gemm_tn's two-stage K loop for the 256 x 256 weight-gradient tile
+  int skinny = 1;             // env BNF_WGRAD_SKINNY=0: layer-0 weight gradient through gemm_tn's 128 x 128 tiles
   int big_tiles = 1;          // env BNF_BIG_TILES: 0 = 128 x 128 tiles everywhere, 1 = auto, 2 = 256 x 256
                               // wherever the shape divides (tests of the large-tile kernels at small sizes)
   float* scal = nullptr;      // (Ev, kScalStride) transformed scalar leaves (k_member_scalars)
@@ -392,11 +395,51 @@ static void launch_gemm_tn_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs&
   LaunchScope ls(h, kid, st, true);
   hipLaunchKernelGGL((gemm_tn<T, TAG, WG>), dim3(blocks), dim3(64 * WG * WG), kLds, st, g, ep);
 }
+// layer-0 weight gradient as a 64 x 512 row stream (gemm_tn_skinny): Fp = 64, W a multiple of 512
+static void launch_gemm_tn_skinny(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep, hipStream_t st) {
+  g.tiles_m = 1;
+  g.tiles_n = g.N / 512;
+  // one workgroup per CU (144 KiB of LDS): split K until the chip is full; split-K = 1 stores
+  const int64_t base = (int64_t)g.members * g.tiles_n;
+  const int nk = g.K / kSkRows;
+  g.splitk = (int)std::max<int64_t>(1, std::min<int64_t>((h->num_cus + base - 1) / base, std::max(1, nk / 8)));
+  if (const char* d = getenv("BNF_SK_SPLITK")) g.splitk = atoi(d);   // (perf experiments)
+  if (getenv("BNF_SK_NOEPI")) g.M = 0;
+  static uint64_t attr_done = 0;
+  allow_lds(h, &gemm_tn_skinny, kSkLds, &attr_done);
+  const unsigned blocks = (unsigned)(base * g.splitk);
+  {
+    LaunchScope ls(h, kid, st, true);
+    hipLaunchKernelGGL(gemm_tn_skinny, dim3(blocks), dim3(512), kSkLds, st, g, ep);
+  }
+  if (getenv("BNF_SK_TWICE")) {
+    LaunchScope ls(h, KID_FEATBWD, st, true);
+    hipLaunchKernelGGL(gemm_tn_skinny, dim3(blocks), dim3(512), kSkLds, st, g, ep);
+  }
+}
 template <typename T, int TAG>
 static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep, hipStream_t st) {
+  if constexpr (sizeof(T) == 2 && TAG == 0) {
+    if (h->skinny && g.a_ld == 64 && g.N % 512 == 0 && g.K % 64 == 0) {
+      launch_gemm_tn_skinny(h, kid, g, ep, st);
+      return;
+    }
+  }
   // 256 x 256 tiles when they still fill the chip (members x tiles >= half the CUs)
   if (h->big_tiles && g.M % 256 == 0 && g.N % 256 == 0 &&
       ((int64_t)g.members * (g.M / 256) * (g.N / 256) >= 128 || h->big_tiles == 2)) {
+    if constexpr (sizeof(T) == 2) {
+      if (h->tn_ring && g.K % 64 == 0) {   // the same tile with the K loop as a four-stage ring
+        g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
+        if (g.splitk < 1) g.splitk = 1;
+        static uint64_t attr_done = 0;
+        allow_lds(h, &gemm_tn_ring<TAG>, kRgLds, &attr_done);
+        const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
+        LaunchScope ls(h, kid, st, true);
+        hipLaunchKernelGGL((gemm_tn_ring<TAG>), dim3(blocks), dim3(1024), kRgLds, st, g, ep);
+        return;
+      }
+    }
     launch_gemm_tn_wg<T, TAG, 4>(h, kid, g, ep, st);
     return;
   }
@@ -1038,7 +1081,10 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   }
   for (int k = 0; k < KID_COUNT; ++k) { h->acc_ms[k] = 0; h->acc_calls[k] = 0; }
   if (const char* ab = getenv("BNF_ABLATE")) h->ablate = atoi(ab);
+  h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* bt = getenv("BNF_BIG_TILES")) h->big_tiles = atoi(bt);
+  if (const char* sk = getenv("BNF_WGRAD_SKINNY")) h->skinny = atoi(sk);
+  if (const char* rg = getenv("BNF_TN_RING")) h->tn_ring = atoi(rg);
   if (const char* gm = getenv("BNF_GRAPH")) h->graph_mode = atoi(gm);
   h->adam_clear_all = getenv("BNF_ADAM_CLEAR_ALL") != nullptr;
   {

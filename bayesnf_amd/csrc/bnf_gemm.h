@@ -173,6 +173,12 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total) {
 // Bytes of LDS an epilogue needs beyond the (rows x cols) output tile of `esz`-byte elements.
 // EPI_LAST: row-dot partials (rows x wgn), dv (rows), column sums 2 x (wgm x cols), scalars;
 // they sit behind max(output tile, row-dot scratch = 64 rows x 36 floats per wave).
+#ifndef BNF_TN_AUX
+#define BNF_TN_AUX 0   // cache-policy bits of gemm_tn's operand loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
+#ifndef BNF_SK_AUX
+#define BNF_SK_AUX 2   // gemm_tn_skinny reads every byte once: non-temporal
+#endif
 constexpr int kRowDotPitch = 36;   // floats: 16 lanes x ds_read_b128 at this pitch hit 64 distinct banks
 __host__ __device__ constexpr int epi_extra_lds(int epi, int wgm, int wgn, int esz) {
   if (epi != EPI_LAST) return 0;
@@ -983,8 +989,8 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 2 ? 2 : 4) void gemm_tn(const G
     const char* pb = pin(Bb + rb);
 #pragma unroll
     for (int i = 0; i < kPerWave; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + (uint32_t)src_off_a[i]), (lds_void_t*)(sA + lds_base[i]), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + (uint32_t)src_off_b[i]), (lds_void_t*)(sB + lds_base[i]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + (uint32_t)src_off_a[i]), (lds_void_t*)(sA + lds_base[i]), 16, 0, BNF_TN_AUX);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + (uint32_t)src_off_b[i]), (lds_void_t*)(sB + lds_base[i]), 16, 0, BNF_TN_AUX);
     }
   };
 
@@ -1095,5 +1101,332 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 2 ? 2 : 4) void gemm_tn(const G
       }
   }
 }
+
+// ===========================================================================
+// gemm_tn_skinny -- the layer-0 weight gradient dK_0 = H0^T dZ_0 / sqrt F when the feature
+// panel is 64 columns wide (Fp = 64) and W is a multiple of 512: 2 flops per byte of dZ_0, i.e. a
+// pure HBM stream.  gemm_tn's 128 x 128 tile reads quarter rows of dZ_0 (256 bytes) one stage
+// ahead -- ~40 KiB in flight per CU in bursts, 3.9 TB/s at C2.  Here one 8-wave workgroup per CU
+// owns 64 x 512 outputs (whole 1 KiB rows of dZ_0, H0 read once), K advances through a ring of
+// FOUR 32-row stages (36 KiB each) filled three stages ahead by LDS-DMA with counted
+// `s_waitcnt vmcnt` and one raw s_barrier per stage (gemm_nt's scheme): ~108 KiB in flight per
+// CU all the time.  Fragments by ds_read_b64_tr_b16 exactly as in gemm_tn (64-byte segments of a
+// row XOR-swizzled with the row index: two segments for H0's 128-byte rows, four for dZ_0's).
+// ===========================================================================
+// Transpose reads issued as inline asm: hipcc treats the ds_read_tr builtin as an LDS load that may
+// alias every LDS-DMA in flight and puts `s_waitcnt vmcnt(0)` in front of it -- which turns a ring of
+// prefetched stages into load -> wait -> compute (seen in the ISA; plain ds_read_b128 loads in gemm_nt
+// do not get that wait).  The caller orders them itself: counted vmcnt + s_barrier before, lds_tr_fence after.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ u32x2_t lds_tr16_b64(uint32_t addr) {
+  u32x2_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_tr_fence(u32x2_t (&a)[2][2], u32x2_t (&b)[2][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[0][0]), "+v"(b[0][1]),
+                 "+v"(b[1][0]), "+v"(b[1][1]));
+}
+constexpr int kSkRows = 32, kSkStages = 4, kSkA = kSkRows * 128, kSkB = kSkRows * 1024, kSkStage = kSkA + kSkB;
+constexpr int kSkLds = kSkStages * kSkStage;
+__global__ __launch_bounds__(512, 2) void gemm_tn_skinny(const GemmArgs g, const EpiArgs ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const uint32_t per_member = (uint32_t)(g.tiles_n * g.splitk);
+  uint32_t w = xcd_remap(blockIdx.x, gridDim.x);
+  const int e = (int)(w / per_member);
+  w -= (uint32_t)e * per_member;
+  const int split = (int)(w / (uint32_t)g.tiles_n), tn = (int)(w % (uint32_t)g.tiles_n);
+  const int n0 = tn * 512;
+
+  const int nk_total = g.K / kSkRows;         // g.K = padded batch rows, a multiple of 64
+  const int nk_per = (nk_total + g.splitk - 1) / g.splitk;
+  const int kt0 = split * nk_per;
+  const int kt1 = min(nk_total, kt0 + nk_per);
+
+  const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)e * g.a_batch * 2;
+  const char* Bb = reinterpret_cast<const char*>(g.B) + (int64_t)e * g.b_batch * 2 + n0 * 2;
+
+  // ---- LDS-DMA staging: per stage and wave 1 instruction of H0 (8 rows of 128 bytes; waves 4-7
+  // repeat those of waves 0-3, which keeps the vmcnt bookkeeping uniform) + 4 rows of dZ_0
+  const int qa = wave & 3;
+  const int a_row = qa * 8 + (lane >> 3);
+  const uint32_t src_a = (uint32_t)a_row * 128u + (uint32_t)(((lane & 7) ^ ((a_row & 1) << 2)) * 16);
+  uint32_t src_b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)   // row wave * 4 + i: (row & 3) == i
+    src_b[i] = (uint32_t)(wave * 4 + i) * (uint32_t)g.b_ld * 2u + (uint32_t)((lane ^ (i << 2)) * 16);
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef __attribute__((address_space(1))) const void glb_void_t;
+  auto pin = [](const char* p) {
+    const uint64_t b = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  };
+  auto stage = [&](int buf, int kt) {
+    char* sA = smem + buf * kSkStage;
+    char* sB = sA + kSkA;
+    const char* pa = pin(Ab + (int64_t)kt * kSkRows * 128);
+    const char* pb = pin(Bb + (int64_t)kt * kSkRows * g.b_ld * 2);
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + src_a), (lds_void_t*)(sA + qa * 1024), 16, 0, BNF_SK_AUX);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + src_b[i]), (lds_void_t*)(sB + (wave * 4 + i) * 1024), 16, 0, BNF_SK_AUX);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, kg = lane >> 5;
+  const int p = lane & 15, half = (lane >> 4) & 1;
+  const int prow = p >> 2, pcol = half * 16 + (p & 3) * 4;
+  // per-lane byte offsets of the transpose reads inside a stage, k step 0: [t][i]
+  typedef __attribute__((address_space(3))) char lds_char_t;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char_t*)smem;
+  uint32_t off_a[2][2], off_b[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = kg * 8 + t * 4 + prow;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ba = (i * 32 + pcol) * 2, bb = (wave * 64 + i * 32 + pcol) * 2;
+      off_a[t][i] = lds0 + (uint32_t)(row * 128 + ((ba & ~63) ^ ((row & 1) << 6)) + (ba & 63));
+      off_b[t][i] = lds0 + (uint32_t)(kSkA + row * 1024 + ((bb & ~63) ^ ((row & 3) << 6)) + (bb & 63));
+    }
+  }
+
+  constexpr int kPerWave = 5;
+  constexpr int kAhead = (kSkStages - 2) * kPerWave;            // this wave's younger DMA instructions
+  constexpr int kWait = (kAhead & 15) | ((kAhead >> 4) << 14) | 0x0F70;
+  constexpr int kWaitAll = 0x0F70;
+#pragma unroll
+  for (int s = 0; s < kSkStages - 1; ++s)
+    if (kt0 + s < kt1) stage(s, kt0 + s);
+  for (int ktb = kt0; ktb < kt1; ktb += kSkStages) {
+#pragma unroll
+    for (int sb = 0; sb < kSkStages; ++sb) {
+      const int kt = ktb + sb;
+      if (kt >= kt1) break;
+      if (kt + kSkStages - 2 >= kt1) __builtin_amdgcn_s_waitcnt(kWaitAll);
+      else __builtin_amdgcn_s_waitcnt(kWait);
+      __builtin_amdgcn_s_barrier();
+      if (kt + kSkStages - 1 < kt1) stage((sb + kSkStages - 1) % kSkStages, kt + kSkStages - 1);
+      u32x2_t ra_[2][2][2], rb_[2][2][2];   // [ks][t][i]
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint32_t aa = off_a[t][i] + sb * kSkStage, ab = off_b[t][i] + sb * kSkStage;
+          ra_[0][t][i] = lds_tr16_b64<0>(aa);
+          rb_[0][t][i] = lds_tr16_b64<0>(ab);
+          ra_[1][t][i] = lds_tr16_b64<16 * 128>(aa);
+          rb_[1][t][i] = lds_tr16_b64<16 * 1024>(ab);
+        }
+#pragma unroll
+      for (int ks = 0; ks < kSkRows / 16; ++ks) {
+        if (ks == 0) lds_tr_fence(ra_[0], rb_[0]);     // (both k steps were issued above: one wait covers them)
+        else asm volatile("" : "+v"(ra_[1][0][0]), "+v"(ra_[1][0][1]), "+v"(ra_[1][1][0]), "+v"(ra_[1][1][1]),
+                               "+v"(rb_[1][0][0]), "+v"(rb_[1][0][1]), "+v"(rb_[1][1][0]), "+v"(rb_[1][1][1]));
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const u32x4 wa = {ra_[ks][0][i].x, ra_[ks][0][i].y, ra_[ks][1][i].x, ra_[ks][1][i].y};
+          const u32x4 wb = {rb_[ks][0][i].x, rb_[ks][0][i].y, rb_[ks][1][i].x, rb_[ks][1][i].y};
+          fa[i] = __builtin_bit_cast(bf16x8, wa);
+          fb[i] = __builtin_bit_cast(bf16x8, wb);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: scaled f32 store / atomic accumulate into the gradient vector ----
+  const int mw = 4 * kg;
+  const int nw = n0 + wave * 64 + frow;
+  float* out = ep.out_f32 ? ep.out_f32 + (int64_t)e * ep.f32_batch
+                          : ep.grad + (int64_t)e * ep.grad_stride + ep.off_out;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = nw + j * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + i * 32 + 8 * (r >> 2) + (r & 3);
+        if (m < g.M) {
+          const float v = acc[i][j][r] * ep.scale;
+          if (g.splitk > 1) atomicAdd(&out[(int64_t)m * ep.ld_f32 + n], v);
+          else out[(int64_t)m * ep.ld_f32 + n] = v;
+        }
+      }
+  }
+}
+
+
+// ===========================================================================
+// gemm_tn_ring -- gemm_tn's 256 x 256 tile (16 waves, bf16) with the K loop as a RING: four
+// 32-row stages (32 KiB each), filled three stages ahead by LDS-DMA, counted `s_waitcnt vmcnt`
+// and one raw s_barrier per stage, transpose reads as inline asm (lds_tr16_b64: the builtin gets
+// a compiler-inserted vmcnt(0) that serialises any ring).  gemm_tn's two 64-row stages
+// under __syncthreads leave the memory pipe idle between "stage landed" and "next stage issued":
+// at C2 a stage took 5.1k cycles for 2.0k cycles of MFMA work.
+// ===========================================================================
+constexpr int kRgRows = 32, kRgStages = 4, kRgOp = kRgRows * 512, kRgStage = 2 * kRgOp;
+constexpr int kRgLds = kRgStages * kRgStage;
+template <int TAG>
+__global__ __launch_bounds__(1024, 4) void gemm_tn_ring(const GemmArgs g, const EpiArgs ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const uint32_t per_member = (uint32_t)(g.tiles_m * g.tiles_n * g.splitk);
+  uint32_t w = xcd_remap(blockIdx.x, gridDim.x);
+  const int e = (int)(w / per_member);
+  w -= (uint32_t)e * per_member;
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int split = (int)(w / (uint32_t)tiles);
+  w -= (uint32_t)split * tiles;
+  const int tm = (int)(w / (uint32_t)g.tiles_n), tn = (int)(w % (uint32_t)g.tiles_n);
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  const int nk_total = g.K / kRgRows;         // g.K = padded batch rows, a multiple of 64
+  const int nk_per = (nk_total + g.splitk - 1) / g.splitk;
+  const int kt0 = split * nk_per;
+  const int kt1 = min(nk_total, kt0 + nk_per);
+
+  const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)e * g.a_batch * 2 + m0 * 2;
+  const char* Bb = reinterpret_cast<const char*>(g.B) + (int64_t)e * g.b_batch * 2 + n0 * 2;
+
+  // ---- LDS-DMA staging: per stage and wave one instruction (two 512-byte rows) of each operand
+  const int srow = wave * 2 + (lane >> 5);
+  const uint32_t schunk = (uint32_t)(((lane & 31) ^ ((srow & 3) << 2)) * 16);
+  const uint32_t src_a = (uint32_t)srow * (uint32_t)g.a_ld * 2u + schunk;
+  const uint32_t src_b = (uint32_t)srow * (uint32_t)g.b_ld * 2u + schunk;
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef __attribute__((address_space(1))) const void glb_void_t;
+  auto pin = [](const char* p) {
+    const uint64_t b = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  };
+  auto stage = [&](int buf, int kt) {
+    char* sA = smem + buf * kRgStage;
+    char* sB = sA + kRgOp;
+    const char* pa = pin(Ab + (int64_t)kt * kRgRows * g.a_ld * 2);
+    const char* pb = pin(Bb + (int64_t)kt * kRgRows * g.b_ld * 2);
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + src_a), (lds_void_t*)(sA + wave * 1024), 16, 0, BNF_TN_AUX);
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + src_b), (lds_void_t*)(sB + wave * 1024), 16, 0, BNF_TN_AUX);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, kg = lane >> 5;
+  const int p = lane & 15, half = (lane >> 4) & 1;
+  const int prow = p >> 2, pcol = half * 16 + (p & 3) * 4;
+  typedef __attribute__((address_space(3))) char lds_char_t;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char_t*)smem;
+  uint32_t off_a[2][2], off_b[2][2];   // [t][i]: byte offsets of the transpose reads in a stage, k step 0
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = kg * 8 + t * 4 + prow;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ba = (wr * 64 + i * 32 + pcol) * 2, bb = (wc * 64 + i * 32 + pcol) * 2;
+      off_a[t][i] = lds0 + (uint32_t)(row * 512 + ((ba & ~63) ^ ((row & 3) << 6)) + (ba & 63));
+      off_b[t][i] = lds0 + (uint32_t)(kRgOp + row * 512 + ((bb & ~63) ^ ((row & 3) << 6)) + (bb & 63));
+    }
+  }
+
+  constexpr int kPerWave = 2;
+  constexpr int kAhead = (kRgStages - 2) * kPerWave;
+  constexpr int kWait = (kAhead & 15) | ((kAhead >> 4) << 14) | 0x0F70;
+  constexpr int kWaitAll = 0x0F70;
+#pragma unroll
+  for (int s = 0; s < kRgStages - 1; ++s)
+    if (kt0 + s < kt1) stage(s, kt0 + s);
+  for (int ktb = kt0; ktb < kt1; ktb += kRgStages) {
+#pragma unroll
+    for (int sb = 0; sb < kRgStages; ++sb) {
+      const int kt = ktb + sb;
+      if (kt >= kt1) break;
+      if (kt + kRgStages - 2 >= kt1) __builtin_amdgcn_s_waitcnt(kWaitAll);
+      else __builtin_amdgcn_s_waitcnt(kWait);
+      __builtin_amdgcn_s_barrier();
+      if (kt + kRgStages - 1 < kt1) stage((sb + kRgStages - 1) % kRgStages, kt + kRgStages - 1);
+      u32x2_t ra_[2][2][2], rb_[2][2][2];   // [ks][t][i]
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint32_t aa = off_a[t][i] + sb * kRgStage, ab = off_b[t][i] + sb * kRgStage;
+          ra_[0][t][i] = lds_tr16_b64<0>(aa);
+          rb_[0][t][i] = lds_tr16_b64<0>(ab);
+          ra_[1][t][i] = lds_tr16_b64<16 * 512>(aa);
+          rb_[1][t][i] = lds_tr16_b64<16 * 512>(ab);
+        }
+#pragma unroll
+      for (int ks = 0; ks < kRgRows / 16; ++ks) {
+        if (ks == 0) lds_tr_fence(ra_[0], rb_[0]);     // (both k steps were issued above: one wait covers them)
+        else asm volatile("" : "+v"(ra_[1][0][0]), "+v"(ra_[1][0][1]), "+v"(ra_[1][1][0]), "+v"(ra_[1][1][1]),
+                               "+v"(rb_[1][0][0]), "+v"(rb_[1][0][1]), "+v"(rb_[1][1][0]), "+v"(rb_[1][1][1]));
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const u32x4 wa = {ra_[ks][0][i].x, ra_[ks][0][i].y, ra_[ks][1][i].x, ra_[ks][1][i].y};
+          const u32x4 wb = {rb_[ks][0][i].x, rb_[ks][0][i].y, rb_[ks][1][i].x, rb_[ks][1][i].y};
+          fa[i] = __builtin_bit_cast(bf16x8, wa);
+          fb[i] = __builtin_bit_cast(bf16x8, wb);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: scaled f32 store / atomic accumulate into the gradient vector ----
+  const int mw = m0 + wr * 64 + 4 * kg;
+  const int nw = n0 + wc * 64 + frow;
+  float* out = ep.out_f32 ? ep.out_f32 + (int64_t)e * ep.f32_batch
+                          : ep.grad + (int64_t)e * ep.grad_stride + ep.off_out;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = nw + j * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + i * 32 + 8 * (r >> 2) + (r & 3);
+        const float v = acc[i][j][r] * ep.scale;
+        if (g.splitk > 1) atomicAdd(&out[(int64_t)m * ep.ld_f32 + n], v);
+        else out[(int64_t)m * ep.ld_f32 + n] = v;
+      }
+  }
+}
+
 
 }  // namespace bnf

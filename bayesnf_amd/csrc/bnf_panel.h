@@ -142,6 +142,9 @@ __global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ t
   }
 }
 
+#ifndef BNF_PANEL_NT
+#define BNF_PANEL_NT 1   // H1 / dZ1 / dZ0 leave with non-temporal stores (they are read once, by the weight-gradient kernels)
+#endif
 constexpr int kPanelPD = 4;       // weight fragments in flight per stream
 
 // RT = 32-row tiles per wave (4: one workgroup per CU, 256 registers; 2: two workgroups per CU, 128)
@@ -335,7 +338,11 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = L.lane + 64 * u;
+#if BNF_PANEL_NT
+      __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(d + (int64_t)(idx >> 3) * W + (idx & 7) * 8));
+#else
       *reinterpret_cast<u32x4*>(d + (int64_t)(idx >> 3) * W + (idx & 7) * 8) = v[u];
+#endif
     }
   };
 
