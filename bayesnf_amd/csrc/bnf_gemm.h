@@ -1359,22 +1359,28 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_ring(const GemmArgs g, const 
     }
   }
 
+  // Stage kt is certified (landed for every wave) by the barrier of iteration kt - 1, so its
+  // transpose reads are issued BEFORE this iteration's barrier and fly while the wave waits there;
+  // the barrier of iteration kt certifies stage kt + 1 and frees the buffer of stage kt - 1
+  // (every wave has consumed its fragments) for the prefetch of stage kt + 3.
   constexpr int kPerWave = 2;
-  constexpr int kAhead = (kRgStages - 2) * kPerWave;
-  constexpr int kWait = (kAhead & 15) | ((kAhead >> 4) << 14) | 0x0F70;
+  constexpr int kWait1 = (kPerWave & 15) | 0x0F70;     // one younger stage of this wave may stay in flight
   constexpr int kWaitAll = 0x0F70;
 #pragma unroll
   for (int s = 0; s < kRgStages - 1; ++s)
     if (kt0 + s < kt1) stage(s, kt0 + s);
+  if (kt0 + 1 < kt1) {
+    if (kt0 + 2 < kt1) __builtin_amdgcn_s_waitcnt((2 * kPerWave & 15) | 0x0F70);
+    else __builtin_amdgcn_s_waitcnt(kWait1);
+  } else {
+    __builtin_amdgcn_s_waitcnt(kWaitAll);
+  }
+  __builtin_amdgcn_s_barrier();
   for (int ktb = kt0; ktb < kt1; ktb += kRgStages) {
 #pragma unroll
     for (int sb = 0; sb < kRgStages; ++sb) {
       const int kt = ktb + sb;
       if (kt >= kt1) break;
-      if (kt + kRgStages - 2 >= kt1) __builtin_amdgcn_s_waitcnt(kWaitAll);
-      else __builtin_amdgcn_s_waitcnt(kWait);
-      __builtin_amdgcn_s_barrier();
-      if (kt + kRgStages - 1 < kt1) stage((sb + kRgStages - 1) % kRgStages, kt + kRgStages - 1);
       u32x2_t ra_[2][2][2], rb_[2][2][2];   // [ks][t][i]
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -1386,6 +1392,10 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_ring(const GemmArgs g, const 
           ra_[1][t][i] = lds_tr16_b64<16 * 512>(aa);
           rb_[1][t][i] = lds_tr16_b64<16 * 512>(ab);
         }
+      if (kt + 2 < kt1) __builtin_amdgcn_s_waitcnt(kWait1);
+      else __builtin_amdgcn_s_waitcnt(kWaitAll);
+      __builtin_amdgcn_s_barrier();
+      if (kt + kRgStages - 1 < kt1) stage((sb + kRgStages - 1) % kRgStages, kt + kRgStages - 1);
 #pragma unroll
       for (int ks = 0; ks < kRgRows / 16; ++ks) {
         if (ks == 0) lds_tr_fence(ra_[0], rb_[0]);     // (both k steps were issued above: one wait covers them)
