@@ -403,19 +403,11 @@ static void launch_gemm_tn_skinny(bnf_handle* h, int kid, GemmArgs g, const EpiA
   const int64_t base = (int64_t)g.members * g.tiles_n;
   const int nk = g.K / kSkRows;
   g.splitk = (int)std::max<int64_t>(1, std::min<int64_t>((h->num_cus + base - 1) / base, std::max(1, nk / 8)));
-  if (const char* d = getenv("BNF_SK_SPLITK")) g.splitk = atoi(d);   // (perf experiments)
-  if (getenv("BNF_SK_NOEPI")) g.M = 0;
   static uint64_t attr_done = 0;
   allow_lds(h, &gemm_tn_skinny, kSkLds, &attr_done);
   const unsigned blocks = (unsigned)(base * g.splitk);
-  {
-    LaunchScope ls(h, kid, st, true);
-    hipLaunchKernelGGL(gemm_tn_skinny, dim3(blocks), dim3(512), kSkLds, st, g, ep);
-  }
-  if (getenv("BNF_SK_TWICE")) {
-    LaunchScope ls(h, KID_FEATBWD, st, true);
-    hipLaunchKernelGGL(gemm_tn_skinny, dim3(blocks), dim3(512), kSkLds, st, g, ep);
-  }
+  LaunchScope ls(h, kid, st, true);
+  hipLaunchKernelGGL(gemm_tn_skinny, dim3(blocks), dim3(512), kSkLds, st, g, ep);
 }
 template <typename T, int TAG>
 static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep, hipStream_t st) {
@@ -435,8 +427,10 @@ static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep
         static uint64_t attr_done = 0;
         allow_lds(h, &gemm_tn_ring<TAG>, kRgLds, &attr_done);
         const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
+        EpiArgs ep2 = ep;
+        ep2.ablate = h->ablate;
         LaunchScope ls(h, kid, st, true);
-        hipLaunchKernelGGL((gemm_tn_ring<TAG>), dim3(blocks), dim3(1024), kRgLds, st, g, ep);
+        hipLaunchKernelGGL((gemm_tn_ring<TAG>), dim3(blocks), dim3(1024), kRgLds, st, g, ep2);
         return;
       }
     }
