@@ -132,3 +132,27 @@ def test_fused_featurisation_backward_matches_the_separate_kernel(monkeypatch):
   assert not bad, bad
   rest = {k: v for k, v in errs.items() if k not in names and v > 2e-3}   # nothing else changes
   assert not rest, rest
+
+
+@pytest.mark.parametrize('n_rows', [300, 1000, 2333])
+def test_weight_gradient_stream_kernels_match_the_two_stage_kernel(n_rows, monkeypatch):
+  """gemm_tn_skinny (layer 0 as a 64 x 512 row stream) and gemm_tn_ring (256 x 256 tile, four-stage
+  ring, software-pipelined transpose reads) against gemm_tn's two-stage loop on the same activations:
+  the same bf16 products, only the f32 summation order differs (split-K, stage size).  Row counts
+  give K loops of 10 / 32 / 74 stages: ring fill, drain and the not-a-multiple-of-four tail."""
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=512, depth=2)
+  E = 3
+  theta = util.random_theta(model, E, scale=0.3)
+  grads = {}
+  for name, env in (('stream', {}), ('two_stage', {'BNF_WGRAD_SKINNY': '0', 'BNF_TN_RING': '0'})):
+    for k in ('BNF_WGRAD_SKINNY', 'BNF_TN_RING'):
+      monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)    # read at bnf_create
+    eng = _engine(net, X, y, members=E, compute_dtype='bf16', pipeline='panel')
+    eng.set_params(theta)
+    grads[name] = eng.debug_loss_and_grad()[1]
+    eng.close()
+  errs = _leaf_errs(model, grads['stream'], grads['two_stage'])
+  bad = {k: v for k, v in errs.items() if v > 2e-4}
+  assert not bad, bad
