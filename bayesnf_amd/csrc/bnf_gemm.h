@@ -7,6 +7,9 @@
 //   gemm_tn   C[i][j] = sum_r A[r][i] B[r][j]          both operands row-major (r slow)
 //     wgrad     dK = H_l^T dZ_l                        (transpose reads in LDS; no transposed
 //                                                       copy of any activation exists in HBM)
+//   gemm_tn_ring / gemm_tn_skinny: the same contraction for the row-panel pipeline's bf16 shapes
+//     (256 x 256 tile; 64 x 512 row stream of layer 0) with the K loop as a four-stage LDS-DMA ring
+//     and the transpose reads as inline asm -- an HBM stream first
 //
 // Tiling (gfx950): a workgroup is a WGM x WGN grid of waves, each wave a 64x64 sub-tile =
 // 2x2 MFMA 32x32 accumulators (64 f32 VGPRs); 2x2 waves (128x128) by default, 4x4 (256x256) and
