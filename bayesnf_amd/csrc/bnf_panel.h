@@ -467,17 +467,6 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     panel_contract<kPitchB, RT>(acc, L.prow, wf1, 2 * cs, KS1, L.lane, [](int) {});
   }
   BNF_MARK(a, 3);
-  // per-column parameters of the next epilogues, requested BEFORE the barrier (an L2 round trip
-  // right after it was exposed at the head of every phase); k_o stays in registers for the dZ1 epilogue
-  float pre_b1[2], pre_ko[2];
-  {
-    const int fr = lane_ctx().frow;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      pre_b1[j] = th[a.off_bias1 + cbase + j * 32 + fr];
-      pre_ko[j] = th[a.off_ko + cbase + j * 32 + fr];
-    }
-  }
   lds_barrier();     // every wave is done reading H1: the panel doubles as row-dot scratch below
 
   // ---- A1 = gamma1 (acc / sqrt W + b1) kept in the accumulators; row dots act(A1) . k_o ----
@@ -488,8 +477,8 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     float gb[2], kov[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      gb[j] = gamma1 * pre_b1[j];
-      kov[j] = pre_ko[j];
+      gb[j] = gamma1 * th[a.off_bias1 + cbase + j * 32 + frow];
+      kov[j] = th[a.off_ko + cbase + j * 32 + frow];
     }
     float* s_dot = reinterpret_cast<float*>(smem) + wave * (64 * kRowDotPitch);   // [64 rows][32 lanes]
 #pragma unroll
@@ -590,7 +579,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     f32x2 sa[2], sg[2], cp[2], ck[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) sa[j] = sg[j] = cp[j] = ck[j] = f32x2{0.f, 0.f};
-    const float kvn[2] = {pre_ko[0] * inv_sw, pre_ko[1] * inv_sw};
+    const float kvn[2] = {th[a.off_ko + cbase + frow] * inv_sw, th[a.off_ko + cbase + 32 + frow] * inv_sw};
     const float gk[2] = {gamma1 * kvn[0], gamma1 * kvn[1]};
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -673,9 +662,6 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   BNF_MARK(a, 8);
   const LaneCtx L2 = lane_ctx();
   l0_weights(L2);                         // first operands of the A0 recomputation, in flight across the barrier
-  float pre_b0[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) pre_b0[j] = th[a.off_bias0 + cbase + j * 32 + L2.frow];
   lds_barrier();     // every wave is done reading dZ1: the panel is overwritten with dZ0 (and s_col / s_sc reused)
 
   // ---- dZ0 = gamma0 (dH1 / sqrt W) act'(A0), A0 recomputed per 32-row block ----------------
@@ -685,7 +671,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     const float gs0 = gamma0 * inv_sf;
     float gb0[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) gb0[j] = gamma0 * pre_b0[j];
+    for (int j = 0; j < 2; ++j) gb0[j] = gamma0 * th[a.off_bias0 + cbase + j * 32 + frow];
     f32x2 sa2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, cs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
     f32x16 a0b[2];
     if constexpr (H0L) l0_tile(L, a0b[0], 0, 0);
