@@ -430,7 +430,7 @@ static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep
         EpiArgs ep2 = ep;
         ep2.ablate = h->ablate;
         LaunchScope ls(h, kid, st, true);
-        hipLaunchKernelGGL((gemm_tn_ring<TAG>), dim3(blocks), dim3(1024), kRgLds, st, g, ep2);
+        hipLaunchKernelGGL((gemm_tn_ring<TAG>), dim3(blocks), dim3(512), kRgLds, st, g, ep2);
         return;
       }
     }

@@ -1281,17 +1281,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_skinny(const GemmArgs g, const
 
 
 // ===========================================================================
-// gemm_tn_ring -- gemm_tn's 256 x 256 tile (16 waves, bf16) with the K loop as a RING: four
-// 32-row stages (32 KiB each), filled three stages ahead by LDS-DMA, counted `s_waitcnt vmcnt`
-// and one raw s_barrier per stage, transpose reads as inline asm (lds_tr16_b64: the builtin gets
-// a compiler-inserted vmcnt(0) that serialises any ring).  gemm_tn's two 64-row stages
-// under __syncthreads leave the memory pipe idle between "stage landed" and "next stage issued":
-// at C2 a stage took 5.1k cycles for 2.0k cycles of MFMA work.
+// gemm_tn_ring -- gemm_tn's 256 x 256 bf16 tile with the K loop as a RING: four 32-row stages
+// (32 KiB each), filled three stages ahead by LDS-DMA, counted `s_waitcnt vmcnt` and one raw
+// s_barrier per stage, transpose reads as inline asm (lds_tr16_b64: the builtin gets a
+// compiler-inserted vmcnt(0) that serialises any ring).  gemm_tn's two 64-row stages under
+// __syncthreads leave the memory pipe idle between "stage landed" and "next stage issued": at C2 a
+// stage took 5.1k cycles for 2.0k cycles of MFMA work.
+// EIGHT waves of 128 x 64 (4 x 2 accumulators, two waves per SIMD, 212 registers): 12 transpose reads
+// per 8 MFMAs (sixteen waves of 64 x 64 need 8 per 4) and a barrier among 8 waves -- 350 -> 340 us at C2.
+// Software pipeline: the barrier of iteration kt certifies stage kt + 1 (landed for every wave) and
+// frees the buffer of stage kt - 1 for the prefetch of stage kt + 3.  The fragments of stage kt were
+// read during iteration kt - 1; those of stage kt + 1 are requested BETWEEN the two MFMA groups of
+// stage kt, each fragment set refilled right after the MFMAs that consumed it were issued, so that
+// the LDS serves them while the matrix pipe works (ablation of the read-then-multiply version:
+// 172 us of a 295 us compute-only run were the reads and the barrier; MFMA floor 164 us).
 // ===========================================================================
 constexpr int kRgRows = 32, kRgStages = 4, kRgOp = kRgRows * 512, kRgStage = 2 * kRgOp;
 constexpr int kRgLds = kRgStages * kRgStage;
 template <int TAG>
-__global__ __launch_bounds__(1024, 4) void gemm_tn_ring(const GemmArgs g, const EpiArgs ep) {
+__global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const EpiArgs ep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1307,7 +1315,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_ring(const GemmArgs g, const 
   const int tm = (int)(w / (uint32_t)g.tiles_n), tn = (int)(w % (uint32_t)g.tiles_n);
   const int m0 = tm * 256, n0 = tn * 256;
 
-  const int nk_total = g.K / kRgRows;         // g.K = padded batch rows, a multiple of 64
+  const int nk_total = g.K / kRgRows;
   const int nk_per = (nk_total + g.splitk - 1) / g.splitk;
   const int kt0 = split * nk_per;
   const int kt1 = min(nk_total, kt0 + nk_per);
@@ -1315,11 +1323,14 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_ring(const GemmArgs g, const 
   const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)e * g.a_batch * 2 + m0 * 2;
   const char* Bb = reinterpret_cast<const char*>(g.B) + (int64_t)e * g.b_batch * 2 + n0 * 2;
 
-  // ---- LDS-DMA staging: per stage and wave one instruction (two 512-byte rows) of each operand
-  const int srow = wave * 2 + (lane >> 5);
-  const uint32_t schunk = (uint32_t)(((lane & 31) ^ ((srow & 3) << 2)) * 16);
-  const uint32_t src_a = (uint32_t)srow * (uint32_t)g.a_ld * 2u + schunk;
-  const uint32_t src_b = (uint32_t)srow * (uint32_t)g.b_ld * 2u + schunk;
+  uint32_t src_a[2], src_b[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int srow = (wave * 2 + q) * 2 + (lane >> 5);
+    const uint32_t schunk = (uint32_t)(((lane & 31) ^ ((srow & 3) << 2)) * 16);
+    src_a[q] = (uint32_t)srow * (uint32_t)g.a_ld * 2u + schunk;
+    src_b[q] = (uint32_t)srow * (uint32_t)g.b_ld * 2u + schunk;
+  }
   typedef __attribute__((address_space(3))) void lds_void_t;
   typedef __attribute__((address_space(1))) const void glb_void_t;
   auto pin = [](const char* p) {
@@ -1333,13 +1344,16 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_ring(const GemmArgs g, const 
     char* sB = sA + kRgOp;
     const char* pa = pin(Ab + (int64_t)kt * kRgRows * g.a_ld * 2);
     const char* pb = pin(Bb + (int64_t)kt * kRgRows * g.b_ld * 2);
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + src_a), (lds_void_t*)(sA + wave * 1024), 16, 0, BNF_TN_AUX);
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + src_b), (lds_void_t*)(sB + wave * 1024), 16, 0, BNF_TN_AUX);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + src_a[q]), (lds_void_t*)(sA + (wave * 2 + q) * 1024), 16, 0, BNF_TN_AUX);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + src_b[q]), (lds_void_t*)(sB + (wave * 2 + q) * 1024), 16, 0, BNF_TN_AUX);
+    }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[4][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1350,54 +1364,70 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_ring(const GemmArgs g, const 
   const int prow = p >> 2, pcol = half * 16 + (p & 3) * 4;
   typedef __attribute__((address_space(3))) char lds_char_t;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char_t*)smem;
-  uint32_t off_a[2][2], off_b[2][2];   // [t][i]: byte offsets of the transpose reads in a stage, k step 0
+  // byte offsets of the transpose reads in a stage for t = 0, k step 0 (t = 1: + 4 rows, k step 1: + 16 rows)
+  uint32_t off_a[4], off_b[2];
+  {
+    const int row = kg * 8 + prow;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int row = kg * 8 + t * 4 + prow;
+    for (int i = 0; i < 4; ++i) {
+      const int ba = (wr * 128 + i * 32 + pcol) * 2;
+      off_a[i] = lds0 + (uint32_t)(row * 512 + ((ba & ~63) ^ ((row & 3) << 6)) + (ba & 63));
+    }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ba = (wr * 64 + i * 32 + pcol) * 2, bb = (wc * 64 + i * 32 + pcol) * 2;
-      off_a[t][i] = lds0 + (uint32_t)(row * 512 + ((ba & ~63) ^ ((row & 3) << 6)) + (ba & 63));
-      off_b[t][i] = lds0 + (uint32_t)(kRgOp + row * 512 + ((bb & ~63) ^ ((row & 3) << 6)) + (bb & 63));
+    for (int j = 0; j < 2; ++j) {
+      const int bb = (wc * 64 + j * 32 + pcol) * 2;
+      off_b[j] = lds0 + (uint32_t)(kRgOp + row * 512 + ((bb & ~63) ^ ((row & 3) << 6)) + (bb & 63));
     }
   }
-
-  // Software pipeline: the barrier of iteration kt certifies stage kt + 1 (landed for every wave) and
-  // frees the buffer of stage kt - 1 for the prefetch of stage kt + 3.  The fragments of stage kt were
-  // read during iteration kt - 1; the transpose reads of stage kt + 1 are issued BETWEEN the MFMA groups
-  // of stage kt, so that the LDS serves them while the
-  // matrix pipe works (two fragment sets: each is refilled right after its MFMAs were issued) -- read-then-multiply per stage cost 1.8k cycles per stage for 1.0k of MFMA work
-  // (ablation: 172 us of a 295 us compute-only run were the reads and the barrier).
-  constexpr int kPerWave = 2;
-  constexpr int kWait1 = (kPerWave & 15) | 0x0F70;     // one younger stage of this wave may stay in flight
-  constexpr int kWaitAll = 0x0F70;
-  auto read_k = [&](u32x2_t (&fa)[2][2], u32x2_t (&fb)[2][2], int sb, auto ks_tag) {
+  struct Frags {
+    u32x2_t a[2][4], b[2][2];   // [t][tile]
+  };
+  auto read_k = [&](Frags& f, int sb, auto ks_tag) {
     constexpr int ks = decltype(ks_tag)::value;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[t][i] = lds_tr16_b64<ks * 16 * 512>(off_a[t][i] + sb * kRgStage);
-        fb[t][i] = lds_tr16_b64<ks * 16 * 512>(off_b[t][i] + sb * kRgStage);
-      }
-  };
-  auto mma_k = [&](const u32x2_t (&ra)[2][2], const u32x2_t (&rb)[2][2]) {
-    bf16x8 fa[2], fb[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const u32x4 wa = {ra[0][i].x, ra[0][i].y, ra[1][i].x, ra[1][i].y};
-      const u32x4 wb = {rb[0][i].x, rb[0][i].y, rb[1][i].x, rb[1][i].y};
-      fa[i] = __builtin_bit_cast(bf16x8, wa);
-      fb[i] = __builtin_bit_cast(bf16x8, wb);
+    for (int i = 0; i < 4; ++i) {
+      f.a[0][i] = lds_tr16_b64<ks * 16 * 512>(off_a[i] + sb * kRgStage);
+      f.a[1][i] = lds_tr16_b64<ks * 16 * 512 + 4 * 512>(off_a[i] + sb * kRgStage);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+      f.b[0][j] = lds_tr16_b64<ks * 16 * 512>(off_b[j] + sb * kRgStage);
+      f.b[1][j] = lds_tr16_b64<ks * 16 * 512 + 4 * 512>(off_b[j] + sb * kRgStage);
+    }
+  };
+  auto fence = [&](Frags& f) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[0][2]), "+v"(f.a[0][3]), "+v"(f.a[1][0]), "+v"(f.a[1][1]),
+                   "+v"(f.a[1][2]), "+v"(f.a[1][3]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1]));
+  };
+  auto touch = [&](Frags& f) {
+    asm volatile("" : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[0][2]), "+v"(f.a[0][3]), "+v"(f.a[1][0]), "+v"(f.a[1][1]),
+                      "+v"(f.a[1][2]), "+v"(f.a[1][3]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1]));
+  };
+  auto mma_k = [&](const Frags& f) {
+    bf16x8 fa[4], fb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4 wa = {f.a[0][i].x, f.a[0][i].y, f.a[1][i].x, f.a[1][i].y};
+      fa[i] = __builtin_bit_cast(bf16x8, wa);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const u32x4 wb = {f.b[0][j].x, f.b[0][j].y, f.b[1][j].x, f.b[1][j].y};
+      fb[j] = __builtin_bit_cast(bf16x8, wb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
   };
   using K0 = std::integral_constant<int, 0>;
   using K1 = std::integral_constant<int, 1>;
+
+  constexpr int kPerWave = 4;
+  constexpr int kWait1 = (kPerWave & 15) | 0x0F70;
+  constexpr int kWaitAll = 0x0F70;
 #pragma unroll
   for (int s = 0; s < kRgStages - 1; ++s)
     if (kt0 + s < kt1) stage(s, kt0 + s);
@@ -1408,10 +1438,10 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_ring(const GemmArgs g, const 
     __builtin_amdgcn_s_waitcnt(kWaitAll);
   }
   __builtin_amdgcn_s_barrier();
-  u32x2_t fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];
+  Frags f0, f1;
   if (kt0 < kt1) {
-    read_k(fa0, fb0, 0, K0{});
-    read_k(fa1, fb1, 0, K1{});
+    read_k(f0, 0, K0{});
+    read_k(f1, 0, K1{});
   }
   for (int ktb = kt0; ktb < kt1; ktb += kRgStages) {
 #pragma unroll
@@ -1421,22 +1451,19 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_ring(const GemmArgs g, const 
       if (kt + 2 < kt1) __builtin_amdgcn_s_waitcnt(kWait1);
       else __builtin_amdgcn_s_waitcnt(kWaitAll);
       __builtin_amdgcn_s_barrier();
-      if (kt + kRgStages - 1 < kt1 && !BNF_ABL(ep, 8)) stage((sb + kRgStages - 1) % kRgStages, kt + kRgStages - 1);
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(fa0[0][0]), "+v"(fa0[0][1]), "+v"(fa0[1][0]), "+v"(fa0[1][1]), "+v"(fb0[0][0]), "+v"(fb0[0][1]),
-                     "+v"(fb0[1][0]), "+v"(fb0[1][1]), "+v"(fa1[0][0]), "+v"(fa1[0][1]), "+v"(fa1[1][0]), "+v"(fa1[1][1]),
-                     "+v"(fb1[0][0]), "+v"(fb1[0][1]), "+v"(fb1[1][0]), "+v"(fb1[1][1]));
+      if (kt + kRgStages - 1 < kt1) stage((sb + kRgStages - 1) % kRgStages, kt + kRgStages - 1);
+      fence(f0);
+      touch(f1);
       const bool more = kt + 1 < kt1;
       const int sn = (sb + 1) % kRgStages;
-      if (!BNF_ABL(ep, 16)) mma_k(fa0, fb0);
-      if (more) read_k(fa0, fb0, sn, K0{});     // (into the registers the MFMAs above have just consumed)
-      if (!BNF_ABL(ep, 16)) mma_k(fa1, fb1);
-      if (more) read_k(fa1, fb1, sn, K1{});
+      mma_k(f0);
+      if (more) read_k(f0, sn, K0{});
+      mma_k(f1);
+      if (more) read_k(f1, sn, K1{});
     }
   }
 
-  // ---- epilogue: scaled f32 store / atomic accumulate into the gradient vector ----
-  const int mw = m0 + wr * 64 + 4 * kg;
+  const int mw = m0 + wr * 128 + 4 * kg;
   const int nw = n0 + wc * 64 + frow;
   float* out = ep.out_f32 ? ep.out_f32 + (int64_t)e * ep.f32_batch
                           : ep.grad + (int64_t)e * ep.grad_stride + ep.off_out;
@@ -1444,7 +1471,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn_ring(const GemmArgs g, const 
   for (int j = 0; j < 2; ++j) {
     const int n = nw + j * 32;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mw + i * 32 + 8 * (r >> 2) + (r & 3);
