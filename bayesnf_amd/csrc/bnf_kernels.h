@@ -655,6 +655,9 @@ __global__ void k_step_advance(StepState* st) {
   }
 }
 
+#ifndef BNF_ADAM_NT
+#define BNF_ADAM_NT 1
+#endif
 template <int VEC>
 __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
   __shared__ float red[4];
@@ -698,8 +701,15 @@ __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
       if (!(a.apply && p0 >= a.keep_lo && p0 < a.keep_hi)) store4(a.grad + i0, g[0], g[1], g[2], g[3]);
       if (a.apply) {
         store4(a.theta + i0, th[0], th[1], th[2], th[3]);
+#if BNF_ADAM_NT
+        // the moments are touched once per step: written through, they do not sit dirty in the memory-side
+        // cache while the next kernels stream
+        __builtin_nontemporal_store(f32x4{m[0], m[1], m[2], m[3]}, reinterpret_cast<f32x4*>(a.m + i0));
+        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(a.v + i0));
+#else
         store4(a.m + i0, m[0], m[1], m[2], m[3]);
         store4(a.v + i0, v[0], v[1], v[2], v[3]);
+#endif
       }
     } else {
       a.grad[i0] = g[0];
