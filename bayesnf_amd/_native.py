@@ -17,11 +17,12 @@ from . import spec as _spec
 _LIB_NAME = 'libbnf_hip.so'
 _lib = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_INPUTS, MAX_GROUPS, MAX_LAYERS, MAX_FREQS, MAX_INTERACT = 8, 12, 8, 96, 16
 DTYPE = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
 OBS = {'NORMAL': 0, 'NB': 1, 'ZINB': 2}
 MODE_MAP, MODE_VI = 0, 1
+PIPELINE = {'auto': 0, 'layers': 1, 'panel': 3}
 
 EXPORTS = (
     'bnf_abi_version', 'bnf_last_error', 'bnf_create', 'bnf_destroy',
@@ -29,7 +30,7 @@ EXPORTS = (
     'bnf_init_params', 'bnf_train', 'bnf_vi_posterior_draws', 'bnf_vi_noise_keys', 'bnf_forward',
     'bnf_normal_mixture_quantiles', 'bnf_count_mixture_quantiles', 'bnf_debug_loss_and_grad',
     'bnf_debug_row_index', 'bnf_debug_vi_eps', 'bnf_debug_vi_noise', 'bnf_debug_activation',
-    'bnf_debug_gemm_nt', 'bnf_debug_gemm_tn', 'bnf_profile_enable', 'bnf_profile_read',
+    'bnf_debug_gemm_nt', 'bnf_debug_gemm_tn', 'bnf_debug_poison_lds', 'bnf_profile_enable', 'bnf_profile_read',
     'bnf_kernel_flops', 'bnf_comm_unique_id', 'bnf_comm_create', 'bnf_allgather', 'bnf_comm_destroy')
 
 
@@ -117,6 +118,7 @@ def load():
   lib.bnf_debug_row_index.argtypes = [vp, i64, i64, vp]
   lib.bnf_debug_vi_eps.argtypes = [vp, i64, vp]
   lib.bnf_debug_vi_noise.argtypes = [vp, vp]
+  lib.bnf_debug_poison_lds.argtypes = [vp, C.c_uint32]
   lib.bnf_vi_noise_keys.argtypes = [vp, vp, i64, vp, i64, vp, C.c_int32]
   lib.bnf_debug_activation.argtypes = [vp, i32, vp]
   lib.bnf_debug_gemm_nt.argtypes = [vp, vp, vp, i32, i32, i32, vp]
@@ -203,7 +205,7 @@ def fold_in(seed_u64: int, data: int) -> int:
 def make_config(net: _spec.NetSpec, *, device, dtype, mode, n_rows, batch,
                 members, member_offset, seed, learning_rate=0.005,
                 prior_weight=1.0, kl_weight=1.0, vi_samples=1, forward_only=False,
-                pipeline=0) -> BnfConfig:
+                pipeline='auto') -> BnfConfig:
   """Serialise a NetSpec + run arguments into the C struct."""
   if net.D > MAX_INPUTS:
     raise ValueError(f'at most {MAX_INPUTS} input columns are supported')
@@ -255,7 +257,9 @@ def make_config(net: _spec.NetSpec, *, device, dtype, mode, n_rows, batch,
   c.members, c.member_offset = int(members), int(member_offset)
   c.vi_samples = int(vi_samples)
   c.forward_only = 1 if forward_only else 0
-  c.pipeline = {'auto': 0, 'layers': 1, 'panel': 3}.get(pipeline, pipeline)
+  if pipeline not in PIPELINE and pipeline not in PIPELINE.values():
+    raise ValueError(f'pipeline must be one of {sorted(PIPELINE)} (got {pipeline!r})')
+  c.pipeline = PIPELINE.get(pipeline, pipeline)
   c.learning_rate = float(learning_rate)
   c.prior_weight = float(prior_weight)
   c.kl_weight = float(kl_weight)

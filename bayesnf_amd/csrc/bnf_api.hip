@@ -1230,6 +1230,8 @@ int bnf_bind(bnf_handle* h, void* params, void* opt_state, void* workspace, cons
   }
   h->bound = true;
   h->adam_t = 0;
+  // key tables address rows by (adam_t - vi_key_t0): a re-bound handle starts again without them
+  h->vi_keys = h->vi_draw_keys = nullptr; h->vi_key_rows = h->vi_draw_rows = 0; h->vi_key_t0 = 0;
   return BNF_OK;
 }
 
@@ -1250,6 +1252,8 @@ int bnf_init_params(bnf_handle* h, float log_noise_init) {
   HIPCHK(hipMemsetAsync(h->state, 0, bnf_state_bytes(h), h->stream));
   HIPCHK(hipGetLastError());
   h->adam_t = 0;
+  // the VI noise-key tables are indexed from the step they were installed at: drop them (install after init)
+  h->vi_keys = h->vi_draw_keys = nullptr; h->vi_key_rows = h->vi_draw_rows = 0; h->vi_key_t0 = 0;
   return BNF_OK;
 }
 
@@ -1622,6 +1626,25 @@ int bnf_debug_gemm_tn(bnf_handle* h, const float* A, const float* B, int32_t R, 
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipFree(dA));
   HIPCHK(hipFree(dB));
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
+}
+
+__global__ __launch_bounds__(1024) void k_poison_lds(uint32_t pattern, uint32_t* sink) {
+  extern __shared__ uint32_t poison_sm[];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 1024) poison_sm[i] = pattern ^ ((uint32_t)i & 0xffu);   // (0x7fc00000: quiet NaNs with varying payloads)
+  __syncthreads();
+  if (sink && poison_sm[(threadIdx.x * 37) % (160 * 1024 / 4)] == 0x0badf00du) *sink = 1;   // keeps the stores alive
+}
+
+int bnf_debug_poison_lds(bnf_handle* h, uint32_t pattern) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "not bound");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  static uint64_t attr_done = 0;
+  allow_lds(h, &k_poison_lds, 160 * 1024, &attr_done);
+  // one workgroup per CU at a time (all of its LDS): several rounds so that every CU is visited
+  hipLaunchKernelGGL(k_poison_lds, dim3((unsigned)h->num_cus * 4), dim3(1024), 160 * 1024, h->stream, pattern,
+                     (uint32_t*)h->dbg_a);
   HIPCHK(hipGetLastError());
   return BNF_OK;
 }

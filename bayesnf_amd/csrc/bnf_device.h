@@ -384,6 +384,55 @@ __device__ __forceinline__ ActOut2 act_eval2(f32x2 a, float alpha) {
 }
 
 // ---------------------------------------------------------------------------
+// Lean form of the same activation for the VALU-bound epilogues of the bf16 kernels (the epilogues
+// cost one issue slot per instruction, two per transcendental: the instruction count IS the time).
+// Everything is expressed in t = a log2(e), the pre-activation already scaled for v_exp_f32 -- the
+// caller folds log2(e) into the scale / bias it applies to the accumulator anyway -- and in
+//     e = 2^t = e^a,   r = 1 / (1 + e^2)   (tanh a = 1 - 2 r,  1 - tanh^2 a = 4 (r - r^2)),
+//     dl = min(e, 1) = d elu / da,   mxt = max(t, 0),   s = ln2 mxt + dl = elu(a) + 1:
+//     act(a)            = c0 + c1 r + alpha s          c0 = 1 - 2 alpha,  c1 = -2 (1 - alpha)
+//     act'(a)           = alpha dl + c2 (r - r^2)      c2 = 4 (1 - alpha)
+//     elu(a) - tanh(a)  = s + 2 r - 2
+// No |a|, no sign transfer, no selects; callers fold their own row / column factors into the
+// constants and take constant terms out of the sums (the "- 2" above, "c0" in a row dot).
+// e^2 overflows to inf for a > 44: r = 0, tanh = 1, act' = alpha -- the right limits; a -> -inf gives
+// e = 0, r = 1.  Same accuracy class as act_parts2 (1 - 2 r near 0 is absolute-accurate to ~2e-7).
+// ---------------------------------------------------------------------------
+constexpr float kLog2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f;
+struct ActCore2 {
+  f32x2 r, dl, mxt;
+};
+__device__ __forceinline__ ActCore2 act_core2(f32x2 t) {
+  ActCore2 c;
+  const f32x2 e = {BNF_EXP2(t.x), BNF_EXP2(t.y)};
+  const f32x2 den = e * e + 1.f;
+  f32x2 r = {BNF_RCP(den.x), BNF_RCP(den.y)};
+  asm volatile("" : "+v"(r));   // see act_eval: keeps hipcc 7.2 from mis-optimising the consumers of both builtins
+  c.r = r;
+  c.dl = f32x2{vminf(e.x, 1.f), vminf(e.y, 1.f)};
+  c.mxt = f32x2{vmaxf(t.x, 0.f), vmaxf(t.y, 0.f)};
+  return c;
+}
+struct ActConst {
+  float alpha, c0, c1, c2;
+};
+__device__ __forceinline__ ActConst act_const(float alpha) {
+  return ActConst{alpha, 1.f - 2.f * alpha, -2.f * (1.f - alpha), 4.f * (1.f - alpha)};
+}
+// two bf16 values rounded by ONE v_cvt_pk_bf16_f32 (hipcc splits a bf16x2 whose halves are stored
+// separately into two conversions); the halves then leave as ds_write_b16 / ds_write_b16_d16_hi
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ void store_pair_pk(bf16_t* p0, bf16_t* p1, float a, float b) {
+  const uint32_t pk = cvt_pk_bf16(a, b);
+  p0->bits = (uint16_t)(pk & 0xffffu);
+  p1->bits = (uint16_t)(pk >> 16);
+}
+
+// ---------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   const float* th = a.theta + (int64_t)e * a.theta_stride;
   const float* sc = a.scal + (int64_t)e * kScalStride;
   const float gamma0 = sc[0], gamma1 = sc[1], alpha = sc[BNF_MAX_LAYERS];
+  const ActConst ak = act_const(alpha);
   const float inv_sw = 1.0f / sqrtf((float)a.Wt), inv_sf = 1.0f / sqrtf((float)a.F);
   float* gr = a.grad + (int64_t)e * a.grad_stride;
   // per-member scalars of the row phase and of the serial tails, fetched and transformed now (uniform):
@@ -417,10 +418,10 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   {
     const LaneCtx L = lane_ctx();
     const int frow = L.frow, kg = L.kg;
-    const float gs = gamma0 * inv_sf;
+    const float gs = gamma0 * inv_sf * kLog2e;     // t = A0 log2(e): the activation core works on it (act_core2)
     float gb[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) gb[j] = gamma0 * th[a.off_bias0 + cbase + j * 32 + frow];
+    for (int j = 0; j < 2; ++j) gb[j] = gamma0 * kLog2e * th[a.off_bias0 + cbase + j * 32 + frow];
     l0_weights(L);
     if constexpr (H0L) lds_barrier();     // the staged feature panel is complete
 #pragma unroll 1
@@ -447,9 +448,14 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
           const int lr = rbase + i * 32 + 8 * rg + 4 * kg;
 #pragma unroll
           for (int q = 0; q < 4; q += 2) {
-            const f32x2 av = f32x2{a0[rg * 4 + q], a0[rg * 4 + q + 1]} * gs + gbj;
-            const f32x2 h = BNF_ABL(a, 2) ? av : act_fwd2(av, alpha);
-            if (!BNF_ABL(a, 4)) store_pair(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, h.x, h.y);
+            const f32x2 tv = f32x2{a0[rg * 4 + q], a0[rg * 4 + q + 1]} * gs + gbj;
+            f32x2 h = tv;
+            if (!BNF_ABL(a, 2)) {
+              const ActCore2 c = act_core2(tv);
+              const f32x2 s = kLn2 * c.mxt + c.dl;
+              h = ak.c1 * c.r + (ak.alpha * s + ak.c0);
+            }
+            if (!BNF_ABL(a, 4)) store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, h.x, h.y);
           }
         }
       }
@@ -473,13 +479,21 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   {
     const LaneCtx L = lane_ctx();
     const int lane = L.lane, frow = L.frow, kg = L.kg;
-    const float gs = gamma1 * inv_sw;
-    float gb[2], kov[2];
+    // the accumulators keep t1 = A1 log2(e) from here on; row dot of act(A1) = c0 + c1 r + alpha s with k_o:
+    // the constant term c0 sum_c k_o[c] is added once per row below
+    const float gs = gamma1 * inv_sw * kLog2e;
+    float gb[2], ka[2], kc1[2];
+    float ksum = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      gb[j] = gamma1 * th[a.off_bias1 + cbase + j * 32 + frow];
-      kov[j] = th[a.off_ko + cbase + j * 32 + frow];
+      gb[j] = gamma1 * kLog2e * th[a.off_bias1 + cbase + j * 32 + frow];
+      const float kov = th[a.off_ko + cbase + j * 32 + frow];
+      ka[j] = kov * ak.alpha; kc1[j] = kov * ak.c1;
+      ksum += kov;
     }
+    ksum = wave_sum(kg == 0 ? ksum : 0.f);           // sum of k_o over this wave's 64 columns
+    if (lane == 0) s_sc[48 + wave] = ksum;           // (read by thread 0 after the barriers below)
+    ksum *= ak.c0;
     float* s_dot = reinterpret_cast<float*>(smem) + wave * (64 * kRowDotPitch);   // [64 rows][32 lanes]
 #pragma unroll
     for (int half = 0; half < kHalves; ++half) {   // (unrolled: a runtime index would push acc to scratch)
@@ -494,12 +508,16 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
 #pragma unroll
             for (int q = 0; q < 4; q += 2) {
               const f32x2 raw = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
-              const f32x2 av = raw * gs + gb[j];
-              acc[i][j][rg * 4 + q] = av.x;
-              acc[i][j][rg * 4 + q + 1] = av.y;
-              const f32x2 hk = act_fwd2(av, alpha) * kov[j];
-              pd[q] += hk.x;
-              pd[q + 1] += hk.y;
+              const f32x2 tv = raw * gs + gb[j];
+              acc[i][j][rg * 4 + q] = tv.x;
+              acc[i][j][rg * 4 + q + 1] = tv.y;
+              const ActCore2 c = act_core2(tv);
+              const f32x2 s = kLn2 * c.mxt + c.dl;
+              f32x2 pq = {pd[q], pd[q + 1]};
+              pq = ka[j] * s + pq;
+              pq = kc1[j] * c.r + pq;
+              pd[q] = pq.x;
+              pd[q + 1] = pq.y;
             }
           }
           float* dst = s_dot + (ii * 32 + 8 * rg + 4 * kg) * kRowDotPitch + frow;
@@ -513,7 +531,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       f32x4 t4 = rp[0];
 #pragma unroll
       for (int c = 1; c < 8; ++c) t4 += rp[c];
-      s_part[(rbase + half * 64 + lane) * WN + cs] = (t4.x + t4.y) + (t4.z + t4.w);
+      s_part[(rbase + half * 64 + lane) * WN + cs] = ((t4.x + t4.y) + (t4.z + t4.w)) + ksum;
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -558,12 +576,14 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   }
   lds_barrier();
   BNF_MARK(a, 5);
+  float dv_all = 0.f;   // thread 0: sum of d loss / d v over the panel's rows
   if (tid == 0) {
     float u[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w2 = 0; w2 < (BM + 63) / 64; ++w2)
 #pragma unroll
       for (int i = 0; i < 5; ++i) u[i] += s_sc[w2 * 5 + i];
+    dv_all = u[2];
     const float step_loss = -a.lik_c * u[0];
     atomicAdd(&a.loss[(int64_t)(e / a.S) * a.loss_stride + (a.st ? a.st->col : 0)], a.loss_scale * step_loss);
     if (a.loss_raw) atomicAdd(&a.loss_raw[e], step_loss);
@@ -579,8 +599,14 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     f32x2 sa[2], sg[2], cp[2], ck[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) sa[j] = sg[j] = cp[j] = ck[j] = f32x2{0.f, 0.f};
+    // With dZ1 = z = dv (gamma1 k_o / sqrt W) act'(A1) formed directly (the column factor folded into the
+    // constants of act'), the sums kept per column half are
+    //   sa = sum dv (elu - tanh + 2)   (the "+ 2" leaves as  -2 (sum_c k_o / sqrt W)(sum_r dv)  by thread 0)
+    //   sg = sum z t1                  (d gamma1 ~ sum dA A = (ln 2 / gamma1) sum z t1)
+    //   cp = sum z  (= d bias1),       ck = sum act(A1) dv  (= d k_o sqrt W)
     const float kvn[2] = {th[a.off_ko + cbase + frow] * inv_sw, th[a.off_ko + cbase + 32 + frow] * inv_sw};
-    const float gk[2] = {gamma1 * kvn[0], gamma1 * kvn[1]};
+    const float gka[2] = {gamma1 * kvn[0] * ak.alpha, gamma1 * kvn[1] * ak.alpha};
+    const float gkc[2] = {gamma1 * kvn[0] * ak.c2, gamma1 * kvn[1] * ak.c2};
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -592,17 +618,19 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
           const int lc = cbase + j * 32 + frow;
 #pragma unroll
           for (int q = 0; q < 4; q += 2) {
-            f32x2 av = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
-            asm volatile("" : "+v"(av));
+            f32x2 tv = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
+            asm volatile("" : "+v"(tv));
             const f32x2 dv2 = {dv4[q], dv4[q + 1]};
-            const ActOut2 o = act_eval2(av, alpha);
-            const f32x2 p = dv2 * o.dact;
-            sa[j] += dv2 * o.ediff;
-            sg[j] += p * av;
-            cp[j] += p;
-            ck[j] += o.h * dv2;
-            const f32x2 z = gk[j] * p;
-            store_pair(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, z.x, z.y);
+            const ActCore2 c = act_core2(tv);
+            const f32x2 s = kLn2 * c.mxt + c.dl;
+            const f32x2 h = ak.c1 * c.r + (ak.alpha * s + ak.c0);
+            const f32x2 dg = gkc[j] * (c.r - c.r * c.r) + gka[j] * c.dl;
+            const f32x2 z = dv2 * dg;
+            sa[j] += dv2 * (2.f * c.r + s);
+            sg[j] += z * tv;
+            cp[j] += z;
+            ck[j] += h * dv2;
+            store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, z.x, z.y);
           }
         }
         asm volatile("" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sg[0]), "+v"(sg[1]), "+v"(cp[0]), "+v"(cp[1]),
@@ -611,10 +639,10 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
         if (rg == 3) block_to_global(L, a.dZ1, i);
       }
     float wsa = kvn[0] * (sa[0].x + sa[0].y) + kvn[1] * (sa[1].x + sa[1].y);
-    float wsg = kvn[0] * (sg[0].x + sg[0].y) + kvn[1] * (sg[1].x + sg[1].y);
+    float wsg = (kLn2 / gamma1) * ((sg[0].x + sg[0].y) + (sg[1].x + sg[1].y));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      float b = gk[j] * (cp[j].x + cp[j].y), k = ck[j].x + ck[j].y;
+      float b = cp[j].x + cp[j].y, k = ck[j].x + ck[j].y;
       b += __shfl_xor(b, 32, 64);
       k += __shfl_xor(k, 32, 64);
       if (lane < 32) {
@@ -649,6 +677,10 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       ta1 += s_sc[32 + w2 * 2];
       tg += s_sc[33 + w2 * 2];
     }
+    float ko_all = 0.f;     // sum of k_o over all columns: the waves of row block 0 hold one slab each
+#pragma unroll
+    for (int w2 = 0; w2 < WN; ++w2) ko_all += s_sc[48 + w2];
+    ta1 -= 2.f * inv_sw * ko_all * dv_all;   // the "+ 2" of the sa sums
     atomicAdd(&gr[a.off_ls1], dgam1 * tg);
   }
 
@@ -668,11 +700,15 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   {
     const LaneCtx& L = L2;
     const int lane = L.lane, frow = L.frow, kg = L.kg;
-    const float gs0 = gamma0 * inv_sf;
+    // as in the dZ1 epilogue: dZ0 = z = dH1 (gamma0 / sqrt W) act'(A0) formed directly from the raw
+    // accumulator; sa2 = sum raw (elu - tanh + 2) with sacc = sum raw taking the "+ 2" back out,
+    // sg2 = sum z t0 (d gamma0 ~ (ln 2 / gamma0) sum z t0), cs2 = sum z (= d bias0)
+    const float gs0 = gamma0 * inv_sf * kLog2e;
     float gb0[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) gb0[j] = gamma0 * th[a.off_bias0 + cbase + j * 32 + frow];
-    f32x2 sa2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, cs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int j = 0; j < 2; ++j) gb0[j] = gamma0 * kLog2e * th[a.off_bias0 + cbase + j * 32 + frow];
+    const float gza = gamma0 * inv_sw * ak.alpha, gzc = gamma0 * inv_sw * ak.c2;
+    f32x2 sa2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, sacc = {0.f, 0.f}, cs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
     f32x16 a0b[2];
     if constexpr (H0L) l0_tile(L, a0b[0], 0, 0);
 #pragma unroll
@@ -698,19 +734,22 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
           const int lr = rbase + i * 32 + 8 * rg + 4 * kg;
 #pragma unroll
           for (int q = 0; q < 4; q += 2) {
-            const f32x2 dh = f32x2{acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]} * inv_sw;
-            const f32x2 a2 = f32x2{a0[rg * 4 + q], a0[rg * 4 + q + 1]} * gs0 + gb0[j];
-            ActOut2 o;
-            if (BNF_ABL(a, 2)) { o.h = a2; o.dact = f32x2{1.f, 1.f}; o.ediff = a2; }
-            else o = act_eval2(a2, alpha);
-            sa2 += dh * o.ediff;
-            const f32x2 da = dh * o.dact;
-            sg2 += da * a2;
-            const f32x2 z = gamma0 * da;
+            const f32x2 raw = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
+            const f32x2 tv = f32x2{a0[rg * 4 + q], a0[rg * 4 + q + 1]} * gs0 + gb0[j];
+            f32x2 z = raw;
+            if (!BNF_ABL(a, 2)) {
+              const ActCore2 c = act_core2(tv);
+              const f32x2 s = kLn2 * c.mxt + c.dl;
+              const f32x2 dg = gzc * (c.r - c.r * c.r) + gza * c.dl;
+              z = raw * dg;
+              sa2 += raw * (2.f * c.r + s);
+            }
+            sacc += raw;
+            sg2 += z * tv;
             cs2[j] += z;
-            if (!BNF_ABL(a, 4)) store_pair(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, z.x, z.y);
+            if (!BNF_ABL(a, 4)) store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, z.x, z.y);
           }
-          asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(cs2[0]), "+v"(cs2[1]));
+          asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(sacc), "+v"(cs2[0]), "+v"(cs2[1]));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -723,7 +762,8 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       c += __shfl_xor(c, 32, 64);
       if (lane < 32) s_col[rb * W + cbase + j * 32 + lane] = c;
     }
-    const float sa = wave_sum(sa2.x + sa2.y), sg = wave_sum(sg2.x + sg2.y);
+    const float sa = wave_sum(inv_sw * ((sa2.x + sa2.y) - 2.f * (sacc.x + sacc.y)));
+    const float sg = wave_sum((kLn2 / gamma0) * (sg2.x + sg2.y));
     if (lane == 0) {
       s_sc[32 + wave * 2] = sa;
       s_sc[33 + wave * 2] = sg;

@@ -1,16 +1,24 @@
-"""One process per GPU.  Ensemble members are the unit of parallelism.
+"""Ensemble members are the unit of parallelism; a device never exchanges data while it trains.
 
-The reference shards members with `jax.pmap` over local devices and never
-communicates during training (/root/reference/src/bayesnf/inference.py:573-579,
-members per device = ensemble_size // device_count, :365,:445).  Here every
-rank (launched by `torch.distributed.run`, backend "nccl" == RCCL over xGMI)
-owns the members `[rank * E/G, (rank + 1) * E/G)`; the only collective is the
-final gather of fitted parameters / predictive means.
+The reference shards members with `jax.pmap` over `jax.local_devices()` of ONE process and never
+communicates during training (/root/reference/src/bayesnf/inference.py:573-579, members per device
+= ensemble_size // device_count, :365,:445).  Two ways to drive several GPUs here:
+
+  * one process, every visible GPU (the reference's own shape; no launcher): `fit()` / `predict()`
+    open one engine handle per device -- `BNF_DEVICES=0,1,...` selects / orders them, default all
+    visible -- device g owns the members `[g * E/G, (g + 1) * E/G)`, every device's whole
+    optimisation is enqueued from its own host thread before anything is waited for, and the results
+    are assembled with the leading dims `(G, E/G)` by peer copies to the first device;
+  * one process per GPU under `torch.distributed.run` (backend "nccl" == RCCL over xGMI): rank r
+    owns device LOCAL_RANK and the members of global device index r; the only collective is the
+    final all-gather of fitted parameters / predictive means.
 """
 
 from __future__ import annotations
 
 import os
+import threading
+from typing import Callable, NamedTuple
 
 import numpy as np
 import torch
@@ -20,13 +28,82 @@ def is_distributed() -> bool:
   return torch.distributed.is_available() and torch.distributed.is_initialized()
 
 
+def local_devices() -> list[int]:
+  """HIP device ordinals this process drives.  Under torch.distributed: the one of LOCAL_RANK.
+  Otherwise `BNF_DEVICES` (comma separated ordinals; repeats allowed -- "0,0" runs two handles on
+  one GPU) or every visible device, like `jax.local_devices()`."""
+  if is_distributed():
+    return [local_device_index()]
+  env = os.environ.get('BNF_DEVICES', '').strip()
+  if env:
+    devs = [int(x) for x in env.split(',') if x.strip()]
+    if not devs:
+      raise ValueError(f'BNF_DEVICES={env!r} names no device')
+    return devs
+  return list(range(max(1, torch.cuda.device_count())))
+
+
 def device_count() -> int:
-  """Number of GPUs (= ranks) in the job; the `jax.device_count()` analogue."""
-  return torch.distributed.get_world_size() if is_distributed() else 1
+  """Number of devices in the job -- the `jax.device_count()` analogue and the leading dim of every
+  fitted array: the world size under torch.distributed, else the devices of this process."""
+  return torch.distributed.get_world_size() if is_distributed() else len(local_devices())
 
 
 def rank() -> int:
   return torch.distributed.get_rank() if is_distributed() else 0
+
+
+class Shard(NamedTuple):
+  index: int     # global device index: owns members [index * E/G, (index + 1) * E/G)
+  device: int    # HIP ordinal in this process
+
+
+def local_shards() -> list[Shard]:
+  """The (global device index, local ordinal) pairs this process is responsible for."""
+  if is_distributed():
+    return [Shard(rank(), local_device_index())]
+  return [Shard(i, d) for i, d in enumerate(local_devices())]
+
+
+def run_shards(fn: Callable[[Shard], object], shards: list[Shard] | None = None) -> list:
+  """fn(shard) for every local shard -> results in shard order.  Several shards run from one host
+  thread each: `bnf_train` enqueues a whole optimisation (minutes of kernels) and the launch queue
+  throttles the enqueuing thread, so devices only overlap when each has its own thread (ctypes
+  releases the GIL for the duration of the call)."""
+  shards = local_shards() if shards is None else shards
+  if len(shards) == 1:
+    return [fn(shards[0])]
+  out: list = [None] * len(shards)
+  err: list = [None] * len(shards)
+
+  def work(i, sh):
+    try:
+      if torch.cuda.is_available():
+        torch.cuda.set_device(sh.device)
+      out[i] = fn(sh)
+    except BaseException as e:   # pylint: disable=broad-except
+      err[i] = e
+
+  threads = [threading.Thread(target=work, args=(i, sh), name=f'bnf-dev{sh.device}') for i, sh in enumerate(shards)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join()
+  for e in err:
+    if e is not None:
+      raise e
+  return out
+
+
+def gather_shards(parts: list[torch.Tensor]) -> torch.Tensor:
+  """One tensor (...) per local shard -> (device_count, ...) : the reference's implicit pmap output
+  gather.  In-process devices: peer copies to the first shard's device.  torch.distributed: one
+  all-gather (`all_gather_stack`)."""
+  if is_distributed():
+    assert len(parts) == 1
+    return all_gather_stack(parts[0])
+  dev0 = parts[0].device
+  return torch.stack([p if p.device == dev0 else p.to(dev0) for p in parts])
 
 
 def local_device_index() -> int:

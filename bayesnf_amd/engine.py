@@ -244,6 +244,10 @@ class Engine:
     _native.check(self.lib.bnf_debug_vi_noise(self.handle, None if eps is None else _ptr(self._ext_eps)),
                   'bnf_debug_vi_noise')
 
+  def debug_poison_lds(self, pattern=0x7fc00000):
+    """Test hook (include/bnf.h bnf_debug_poison_lds): garbage in every CU's LDS before the next kernels."""
+    _native.check(self.lib.bnf_debug_poison_lds(self.handle, int(pattern) & 0xffffffff), 'bnf_debug_poison_lds')
+
   def debug_activation(self, what: int) -> np.ndarray:
     ev = self.members * self.S
     if what == 0 or what == 400:

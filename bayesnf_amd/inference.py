@@ -7,8 +7,10 @@
 with identical argument names / meaning / return structure, so the estimator
 layer (spatiotemporal.py) reads like the reference's.  Underneath, every member
 lives on one GPU (`engine.Engine` -> libbnf_hip.so); ranks hold disjoint member
-shards and the fitted parameters / predictive means are all-gathered once at
-the end (the reference's implicit pmap output gather, inference.py:452,486-492).
+shards and the fitted parameters / predictive means are gathered once at the end (the
+reference's implicit pmap output gather, inference.py:452,486-492).  Which devices a
+process drives -- every visible GPU from one process like the reference's pmap, or one
+per torchrun rank -- is `distributed.local_shards()`.
 """
 
 from __future__ import annotations
@@ -65,7 +67,7 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
   n_rows = target.shape[0]
   if batch_size is None:
     batch_size = n_rows
-  world, rank = distributed.device_count(), distributed.rank()
+  world = distributed.device_count()
   seed64 = _native.seed_to_u64(seed)
   per_device = (num_particles // num_splits) // world
   if per_device < 1:
@@ -77,20 +79,27 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
   thetas, losses = [], []
   for i in range(num_splits):
     seed_i = _native.fold_in(seed64, i) if num_splits > 1 else seed64
-    eng = Engine(net, mode='map', X=features, y=target, batch=batch_size,
-                 members=per_device, member_offset=rank * per_device, seed=seed_i,
-                 learning_rate=learning_rate, prior_weight=prior_weight,
-                 compute_dtype=compute_dtype)
-    if init_rng == 'jax':
-      keys = jaxseed.member_keys(seed, world, per_device, i if num_splits > 1 else None)[rank]
-      eng.set_params(jaxseed.map_initial_params(net, keys, log_noise_init))
-    else:
-      eng.init_params(log_noise_init)
-    loss_dev = eng.train(0, num_epochs)
-    theta_dev = eng.params.view(per_device, net.P)
-    thetas.append(distributed.all_gather_stack(theta_dev).cpu().numpy())
-    losses.append(distributed.all_gather_stack(loss_dev).cpu().numpy())
-    eng.close()
+    keys = (jaxseed.member_keys(seed, world, per_device, i if num_splits > 1 else None)
+            if init_rng == 'jax' else None)
+
+    def train_shard(sh):
+      # device sh.index of the job owns the members [index * per_device, (index + 1) * per_device): the
+      # whole optimisation is enqueued on that device's stream; nothing is waited for here
+      eng = Engine(net, mode='map', X=features, y=target, batch=batch_size,
+                   members=per_device, member_offset=sh.index * per_device, seed=seed_i,
+                   learning_rate=learning_rate, prior_weight=prior_weight,
+                   compute_dtype=compute_dtype, device_index=sh.device)
+      if keys is not None:
+        eng.set_params(jaxseed.map_initial_params(net, keys[sh.index], log_noise_init))
+      else:
+        eng.init_params(log_noise_init)
+      return eng, eng.train(0, num_epochs)
+
+    runs = distributed.run_shards(train_shard)
+    thetas.append(distributed.gather_shards([e.params.view(per_device, net.P) for e, _ in runs]).cpu().numpy())
+    losses.append(distributed.gather_shards([l for _, l in runs]).cpu().numpy())
+    for e, _ in runs:
+      e.close()
   theta = np.concatenate(thetas, axis=1)          # (world, E/world, P)
   return _struct_tuple(net, theta), np.concatenate(losses, axis=1)
 
@@ -123,44 +132,51 @@ def fit_vi(features, target, seed, observation_model, model_args, ensemble_size,
   kl_weight; predictions = StructTuple of posterior draws with leaves
   (num_devices, sample_size_posterior, E/num_devices, *leaf_shape)."""
   net = _net_from_args(model_args, observation_model)
+  init_rng = init_rng or os.environ.get('BNF_INIT_RNG', 'jax')
+  if init_rng not in ('jax', 'philox'):
+    raise ValueError("init_rng must be 'jax' or 'philox'")
   features = np.asarray(features, dtype=np.float64)
   target = np.asarray(target, dtype=np.float64)
   n_rows = target.shape[0]
   if batch_size is not None and n_rows < batch_size:
     raise AssertionError(f'batch_size={batch_size} exceeds target.shape[0]={n_rows}')
-  world, rank = distributed.device_count(), distributed.rank()
+  world = distributed.device_count()
   per_device = ensemble_size // world
   if per_device < 1:
     raise ValueError('fewer than one surrogate per device')
-  eng = Engine(net, mode='vi', X=features, y=target,
-               batch=n_rows if batch_size is None else batch_size,
-               members=per_device, member_offset=rank * per_device,
-               seed=_native.seed_to_u64(seed), learning_rate=learning_rate,
-               kl_weight=kl_weight, vi_samples=sample_size_divergence,
-               compute_dtype=compute_dtype)
-  eng.init_params(0.0)
-  if (init_rng or os.environ.get('BNF_INIT_RNG', 'jax')) == 'jax':
-    # the reference's own initial surrogate means for this seed (the optimisation noise and the
-    # posterior draws stay on the engine's counter-based generator: same law, other numbers)
-    mu0 = jaxseed.vi_initial_means(net, seed, world, per_device)[rank]
-    p0 = eng.get_params()
-    p0[0] = mu0
-    eng.set_params(p0)
-    if batch_size is None or batch_size >= n_rows:
-      # full batch: the optimisation noise and the posterior draws come from the reference's stream too
-      # (keys on the host once per fit, normals on the device), so the whole fit follows the reference;
-      # minibatch fits also need its per-step row permutation and stay on the engine's generator
-      eng.set_vi_noise_keys(jaxseed.vi_noise_keys(net, seed, world, rank, num_epochs, sample_size_divergence),
-                            jaxseed.vi_draw_keys(net, seed, world, rank, sample_size_posterior),
-                            jaxseed.leaf_offsets(net))
-  loss_dev = eng.train(0, num_epochs)
-  draws = eng.vi_posterior_draws(sample_size_posterior)   # (n, E_local, P)
-  mu_rho = eng.params.view(2, per_device, net.P)
-  mu = distributed.all_gather_stack(mu_rho[0]).cpu().numpy()
-  rho = distributed.all_gather_stack(mu_rho[1]).cpu().numpy()
-  losses = distributed.all_gather_stack(loss_dev).cpu().numpy()
-  preds = distributed.all_gather_stack(draws).cpu().numpy()   # (world, n, E/world, P)
-  eng.close()
+  full_batch = batch_size is None or batch_size >= n_rows
+  mu0_all = jaxseed.vi_initial_means(net, seed, world, per_device) if init_rng == 'jax' else None
+
+  def train_shard(sh):
+    eng = Engine(net, mode='vi', X=features, y=target,
+                 batch=n_rows if batch_size is None else batch_size,
+                 members=per_device, member_offset=sh.index * per_device,
+                 seed=_native.seed_to_u64(seed), learning_rate=learning_rate,
+                 kl_weight=kl_weight, vi_samples=sample_size_divergence,
+                 compute_dtype=compute_dtype, device_index=sh.device)
+    eng.init_params(0.0)
+    if mu0_all is not None:
+      # the reference's own initial surrogate means for this seed
+      p0 = eng.get_params()
+      p0[0] = mu0_all[sh.index]
+      eng.set_params(p0)
+      if full_batch:
+        # full batch: the optimisation noise and the posterior draws come from the reference's stream too
+        # (keys on the host once per fit, normals on the device), so the whole fit follows the reference;
+        # minibatch fits also need its per-step row permutation and stay on the engine's generator
+        eng.set_vi_noise_keys(jaxseed.vi_noise_keys(net, seed, world, sh.index, num_epochs, sample_size_divergence),
+                              jaxseed.vi_draw_keys(net, seed, world, sh.index, sample_size_posterior),
+                              jaxseed.leaf_offsets(net))
+    loss_dev = eng.train(0, num_epochs)
+    return eng, loss_dev, eng.vi_posterior_draws(sample_size_posterior)   # draws (n, E_local, P)
+
+  runs = distributed.run_shards(train_shard)
+  mu = distributed.gather_shards([e.params.view(2, per_device, net.P)[0] for e, _, _ in runs]).cpu().numpy()
+  rho = distributed.gather_shards([e.params.view(2, per_device, net.P)[1] for e, _, _ in runs]).cpu().numpy()
+  losses = distributed.gather_shards([l for _, l, _ in runs]).cpu().numpy()
+  preds = distributed.gather_shards([d for _, _, d in runs]).cpu().numpy()   # (world, n, E/world, P)
+  for e, _, _ in runs:
+    e.close()
   return MeanFieldSurrogate(net, mu, rho), losses, _struct_tuple(net, preds)
 
 
@@ -170,8 +186,8 @@ def fit_vi(features, target, seed, observation_model, model_args, ensemble_size,
 _ROW_CHUNK = 8192
 
 
-def _forward_local(net, theta_local, features, compute_dtype):
-  """theta_local (M, P) numpy: members owned by this rank -> loc (M, R), aux (M, 3)
+def _forward_local(net, theta_local, features, compute_dtype, device_index=None):
+  """theta_local (M, P) numpy: members handled by one device -> loc (M, R), aux (M, 3)
   as device tensors, plus the engine (kept alive for the quantile kernels)."""
   n_rows = features.shape[0]
   M = theta_local.shape[0]
@@ -180,7 +196,7 @@ def _forward_local(net, theta_local, features, compute_dtype):
   row_cap = int(min(n_rows, _ROW_CHUNK))
   mem_cap = int(max(1, min(M, cells // row_cap)))
   eng = Engine(net, mode='map', members=mem_cap, forward_only=True,
-               row_capacity=row_cap, compute_dtype=compute_dtype)
+               row_capacity=row_cap, compute_dtype=compute_dtype, device_index=device_index)
   theta = torch.from_numpy(np.ascontiguousarray(theta_local, dtype=np.float32)).to(eng.device)
   X = torch.from_numpy(np.ascontiguousarray(
       np.asarray(features, dtype=np.float64), dtype=np.float32)).to(eng.device)
@@ -190,19 +206,35 @@ def _forward_local(net, theta_local, features, compute_dtype):
 
 def _ensemble_forecast(features, observation_model, params, model_args,
                        ensemble_dims, compute_dtype):
+  """Forward pass of every member on the new rows -> (net, engine, lead dims, loc (M, R), aux (M, 3))
+  with all M members on the first local device.  The members are dealt out over the devices of the
+  job in equal contiguous blocks whatever device count the parameters were fitted on (the leading
+  dims of `params` only shape the result)."""
   net = _net_from_args(model_args, observation_model)
-  theta_all = _flatten_struct(net, params)            # (world, [S,] E/world, P)
+  theta_all = _flatten_struct(net, params)            # ([devices,] [S,] E/devices, P)
   lead = theta_all.shape[:-1]
   if len(lead) != ensemble_dims:
     raise ValueError(f'params have {len(lead)} ensemble dims, expected {ensemble_dims}')
-  world, rank = distributed.device_count(), distributed.rank()
-  if lead[0] != world:
-    raise ValueError(f'params were fitted on {lead[0]} devices, job has {world}')
-  theta_local = theta_all[rank].reshape(-1, net.P)
-  eng, loc, aux = _forward_local(net, theta_local, features, compute_dtype)
-  loc_all = distributed.all_gather_stack(loc)          # (world, M_local, R)
-  aux_all = distributed.all_gather_stack(aux)
-  return net, eng, lead, loc_all, aux_all
+  theta_flat = theta_all.reshape(-1, net.P)
+  M = theta_flat.shape[0]
+  world = distributed.device_count()
+  per = -(-M // world)                                # ceil: the last block may be short
+
+  def block(index):                                   # rows of theta_flat device `index` handles, padded to `per`
+    lo = min(index * per, M - 1)
+    idx = np.minimum(np.arange(lo, lo + per), M - 1)
+    return theta_flat[idx]
+
+  runs = distributed.run_shards(
+      lambda sh: _forward_local(net, block(sh.index), features, compute_dtype, device_index=sh.device))
+  loc_all = distributed.gather_shards([r[1] for r in runs])      # (world, per, R)
+  aux_all = distributed.gather_shards([r[2] for r in runs])
+  for r in runs[1:]:
+    r[0].close()
+  n_rows = features.shape[0]
+  loc_all = loc_all.reshape(-1, n_rows)[:M]
+  aux_all = aux_all.reshape(-1, 3)[:M]
+  return net, runs[0][0], lead, loc_all, aux_all
 
 
 def predict_bnf(features, observation_model, params, model_args, quantiles,

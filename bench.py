@@ -49,8 +49,9 @@ KERNEL_SYMBOL = {   # gemm_nt<T, epilogue, tag, wave rows, wave cols>
     'gemm_fwd_last': 'void bnf::gemm_nt<{T}, 5, 3, 1, 8>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_dgrad': 'void bnf::gemm_nt<{T}, 1, 2, 2, 2>(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_dgrad0': 'void bnf::gemm_nt<{T}, 2, 0, 2, 2>(bnf::GemmArgs, bnf::EpiArgs)',
-    'gemm_wgrad_l0': 'void bnf::gemm_tn<{T}, 0, 2>(bnf::GemmArgs, bnf::EpiArgs)',
-    'gemm_wgrad': 'void bnf::gemm_tn<{T}, 1, 4>(bnf::GemmArgs, bnf::EpiArgs)',
+    # the benchmark shape (bf16, W = 512, Fp = 64) runs the HBM-stream forms of the weight gradients
+    'gemm_wgrad_l0': 'bnf::gemm_tn_skinny(bnf::GemmArgs, bnf::EpiArgs)',
+    'gemm_wgrad': 'void bnf::gemm_tn_ring<1>(bnf::GemmArgs, bnf::EpiArgs)',
     'last_bwd': 'void bnf::k_last_bwd<{T}>',
     'panel_fwd_bwd': 'void bnf::k_panel_fwd_bwd<8, 4, true>(bnf::PanelArgs)',
 }

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BNF_ABI_VERSION 1
+#define BNF_ABI_VERSION 2
 
 /* limits of the static network description */
 #define BNF_MAX_INPUTS   8    /* D  : time + spatial covariates              */
@@ -172,7 +172,8 @@ int bnf_vi_posterior_draws(bnf_handle* h, int32_t n_draws, float* out /*DEVICE*/
  *             counted from this call; training beyond the table fails with BNF_ERR_STATE
  *   draw_keys DEVICE uint32 (n_draws, n_leaves, 2) for bnf_vi_posterior_draws
  *   leaf_offsets HOST int32 (n_leaves + 1): offsets of the parameter leaves, in the reference's order
- * Both tables are caller-owned and must stay alive; NULL, NULL restores the engine's generator. */
+ * Both tables are caller-owned and must stay alive; NULL, NULL restores the engine's generator.
+ * Install them AFTER bnf_init_params / bnf_bind: both reset the step counter and drop installed tables. */
 int bnf_vi_noise_keys(bnf_handle* h, const uint32_t* step_keys, int64_t n_steps, const uint32_t* draw_keys,
                       int64_t n_draws, const int32_t* leaf_offsets, int32_t n_leaves);
 
@@ -242,6 +243,11 @@ int bnf_debug_gemm_nt(bnf_handle* h, const float* A, const float* Bt, int32_t M,
  * -> C (M,N) f32. */
 int bnf_debug_gemm_tn(bnf_handle* h, const float* A, const float* B, int32_t R, int32_t M,
                       int32_t N, float* C);
+
+/* Test hook: fills all 160 KiB of LDS of every CU with `pattern`-derived garbage (NaN bit patterns
+ * for pattern = 0x7fc00000).  LDS is not cleared between kernels: a kernel that reads LDS it has not
+ * written sees whatever the previous kernel left there, so parity tests run with poisoned LDS. */
+int bnf_debug_poison_lds(bnf_handle* h, uint32_t pattern);
 
 /* Per-kernel HIP-event timing on the handle's stream.  kernel = "*" brackets
  * every launch with an event pair, a kernel name (as reported by
