@@ -27,7 +27,7 @@ PIPELINE = {'auto': 0, 'layers': 1, 'panel': 3}
 EXPORTS = (
     'bnf_abi_version', 'bnf_last_error', 'bnf_create', 'bnf_destroy',
     'bnf_workspace_bytes', 'bnf_state_bytes', 'bnf_param_bytes', 'bnf_bind',
-    'bnf_init_params', 'bnf_train', 'bnf_vi_posterior_draws', 'bnf_vi_noise_keys', 'bnf_forward',
+    'bnf_init_params', 'bnf_train', 'bnf_row_tables', 'bnf_vi_posterior_draws', 'bnf_vi_noise_keys', 'bnf_forward',
     'bnf_normal_mixture_quantiles', 'bnf_count_mixture_quantiles', 'bnf_debug_loss_and_grad',
     'bnf_debug_row_index', 'bnf_debug_vi_eps', 'bnf_debug_vi_noise', 'bnf_debug_activation',
     'bnf_debug_gemm_nt', 'bnf_debug_gemm_tn', 'bnf_debug_poison_lds', 'bnf_profile_enable', 'bnf_profile_read',
@@ -119,6 +119,7 @@ def load():
   lib.bnf_debug_vi_eps.argtypes = [vp, i64, vp]
   lib.bnf_debug_vi_noise.argtypes = [vp, vp]
   lib.bnf_debug_poison_lds.argtypes = [vp, C.c_uint32]
+  lib.bnf_row_tables.argtypes = [vp, vp, i64, i64]
   lib.bnf_vi_noise_keys.argtypes = [vp, vp, i64, vp, i64, vp, C.c_int32]
   lib.bnf_debug_activation.argtypes = [vp, i32, vp]
   lib.bnf_debug_gemm_nt.argtypes = [vp, vp, vp, i32, i32, i32, vp]
@@ -153,15 +154,17 @@ def check(rc: int, what: str):
 _comm_cache = {}
 
 
-def allgather(send, recv, world: int, rank: int):
+def allgather(send, recv, world: int, rank: int, lib=None):
   """RCCL all-gather through the engine library's own entry point (include/bnf.h:
   bnf_allgather): `send` (…) and `recv` (world, …) are contiguous device tensors.  The
   communicator is created once per (world, rank, device): rank 0 makes the id, the existing
-  torch.distributed process group only carries those 128 bytes to the other ranks."""
+  torch.distributed process group only carries those 128 bytes to the other ranks.
+  (`lib`: the loaded library; bench.py's CPU self-test passes a stand-in with the same three
+  entry points to exercise this plumbing without a GPU.)"""
   import torch
-  lib = load()
-  dev = send.device.index
-  key = (world, rank, dev)
+  lib = load() if lib is None else lib
+  dev = send.device.index if send.is_cuda else -1
+  key = (world, rank, dev, id(lib))
   if key not in _comm_cache:
     ident = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
@@ -169,14 +172,14 @@ def allgather(send, recv, world: int, rank: int):
       check(lib.bnf_comm_unique_id(buf), 'bnf_comm_unique_id')
       ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
     if world > 1:
-      carrier = ident.to(send.device) if torch.distributed.get_backend() == 'nccl' else ident
+      carrier = ident.to(send.device) if send.is_cuda and torch.distributed.get_backend() == 'nccl' else ident
       torch.distributed.broadcast(carrier, src=0)
       ident = carrier.cpu()
     comm = C.c_void_p()
     raw = (C.c_char * 128).from_buffer_copy(bytes(ident.numpy().tobytes()))
-    check(lib.bnf_comm_create(raw, world, rank, dev, C.byref(comm)), 'bnf_comm_create')
+    check(lib.bnf_comm_create(raw, world, rank, max(dev, 0), C.byref(comm)), 'bnf_comm_create')
     _comm_cache[key] = comm
-  stream = torch.cuda.current_stream(send.device).cuda_stream
+  stream = torch.cuda.current_stream(send.device).cuda_stream if send.is_cuda else 0
   check(lib.bnf_allgather(_comm_cache[key], C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
                           C.c_size_t(send.numel() * send.element_size()), C.c_void_p(stream)), 'bnf_allgather')
 

@@ -119,6 +119,8 @@ struct bnf_handle {
   // leaf tables in the workspace
   const uint32_t* vi_keys = nullptr; int64_t vi_key_rows = 0, vi_key_t0 = 0;
   const uint32_t* vi_draw_keys = nullptr; int64_t vi_draw_rows = 0;
+  // caller's epoch shuffles (bnf_row_tables): (n_epochs, members, steps * B) int32 row ids from epoch row_tab_e0 on
+  const int32_t* row_tab = nullptr; int64_t row_tab_epochs = 0, row_tab_e0 = 0;
   int32_t* leaf_off = nullptr; uint8_t* leaf_id = nullptr; int32_t n_leaves = 0;
   bool adam_clear_all = false;   // env BNF_ADAM_CLEAR_ALL (A/B of the kept gradient range)
   bool h0l = false;
@@ -826,6 +828,11 @@ static RowSrc make_rowsrc(const bnf_handle* h, int64_t epoch, int64_t step) {
     rs.mode = 1;
     rs.epoch = (uint64_t)epoch;
     rs.pos0 = step * h->B;
+    if (h->row_tab && epoch >= h->row_tab_e0 && epoch < h->row_tab_e0 + h->row_tab_epochs) {
+      rs.mode = 3;
+      rs.table_ld = (h->N / h->B) * h->B;
+      rs.table = h->row_tab + (epoch - h->row_tab_e0) * (int64_t)h->cfg.members * rs.table_ld;
+    }
   }
   return rs;
 }
@@ -1232,6 +1239,7 @@ int bnf_bind(bnf_handle* h, void* params, void* opt_state, void* workspace, cons
   h->adam_t = 0;
   // key tables address rows by (adam_t - vi_key_t0): a re-bound handle starts again without them
   h->vi_keys = h->vi_draw_keys = nullptr; h->vi_key_rows = h->vi_draw_rows = 0; h->vi_key_t0 = 0;
+  h->row_tab = nullptr; h->row_tab_epochs = 0;
   return BNF_OK;
 }
 
@@ -1510,6 +1518,15 @@ int bnf_vi_noise_keys(bnf_handle* h, const uint32_t* step_keys, int64_t n_steps,
   h->n_leaves = n_leaves;
   h->vi_keys = step_keys; h->vi_key_rows = step_keys ? n_steps : 0; h->vi_key_t0 = h->adam_t;
   h->vi_draw_keys = draw_keys; h->vi_draw_rows = draw_keys ? n_draws : 0;
+  return BNF_OK;
+}
+
+int bnf_row_tables(bnf_handle* h, const int32_t* tables, int64_t epoch0, int64_t n_epochs) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "not bound");
+  if (h->cfg.mode != BNF_MODE_MAP) return fail(BNF_ERR_STATE, "row tables serve MAP / MLE epochs");
+  if (!tables) { h->row_tab = nullptr; h->row_tab_epochs = 0; return BNF_OK; }
+  if (n_epochs < 1 || epoch0 < 0) return fail(BNF_ERR_INVALID, "epoch0 / n_epochs");
+  h->row_tab = tables; h->row_tab_e0 = epoch0; h->row_tab_epochs = n_epochs;
   return BNF_OK;
 }
 

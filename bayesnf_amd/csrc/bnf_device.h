@@ -269,19 +269,15 @@ __device__ __forceinline__ RowLoss row_loss_eval(int obs, const float* __restric
   return o;
 }
 
-// max / min without the canonicalising self-max the compiler adds in IEEE mode when it cannot
-// prove an operand is already quiet (values unpacked from bf16 bits, MFMA results made opaque):
-// the operands here are ordinary finite numbers.
-__device__ __forceinline__ float vmaxf(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float vminf(float a, float b) {
-  float r;
-  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+// min(e, 1) for e >= 0 and max(t, 0) as v_med3_f32: one instruction each, no canonicalising self-max in
+// front (which __builtin_fmaxf gets in IEEE mode when the compiler cannot prove its operand quiet, e.g.
+// an accumulator made opaque) -- and, unlike an inline-asm v_min / v_max, VISIBLE to hipcc's hazard
+// recogniser: an asm statement gets no wait states (cdna_hip_programming.md 5.7), and a VALU instruction
+// that reads the result of the v_exp_f32 / v_rcp_f32 issued just before it needs one (measured: the asm
+// form of these two gave wrong activation gradients in the kernels where hipcc scheduled it right behind
+// the v_exp_f32, and right ones where other instructions happened to sit in between).
+__device__ __forceinline__ float min_with_one(float e) { return __builtin_amdgcn_fmed3f(e, 1.0f, -1.0f); }
+__device__ __forceinline__ float max_with_zero(float t) { return __builtin_amdgcn_fmed3f(t, 0.0f, 3.0e38f); }
 
 struct ActOut {
   float h, dact, ediff;
@@ -297,91 +293,6 @@ struct ActOut {
 #else
 #define BNF_RCP(x) __builtin_amdgcn_rcpf(x)
 #endif
-
-template <bool FAST>
-__device__ __forceinline__ ActOut act_eval(float a, float alpha) {
-  ActOut o;
-  float th, el, dexp;
-  if constexpr (FAST) {
-    // one v_exp_f32 + one v_rcp_f32:  e1 = exp(-|a|), r = 1 / (1 + e1^2)
-    //   tanh|a| = (1 - e1^2) r = 2 r - 1        1 - tanh^2 = 4 r (1 - r)
-    //   elu(a)  = max(a, e1 - 1)                 (a < 0: e^a - 1 >= a;  a > 0: e^-a - 1 < 0 < a)
-    // (bf16 pipeline only: 2 r - 1 loses relative accuracy for |a| << 1, far below bf16's 2^-8)
-    const float e1 = BNF_EXP2(fabsf(a) * -1.44269504088896340736f);
-    float r = BNF_RCP(__builtin_fmaf(e1, e1, 1.f));
-    // Keep the reciprocal opaque: with both raw transcendental builtins visible, hipcc 7.2
-    // mis-optimises the column reductions that consume this value inside the fused kernel
-    // (wrong d bias / d k_o; every variant that hides either builtin is correct -- measured).
-    asm volatile("" : "+v"(r));
-    th = copysignf(__builtin_fmaf(2.f, r, -1.f), a);
-    el = fmaxf(a, e1 - 1.f);
-    o.ediff = el - th;
-    o.h = __builtin_fmaf(alpha, o.ediff, th);
-    o.dact = __builtin_fmaf(4.f * (1.f - alpha), __builtin_fmaf(-r, r, r),
-                            __builtin_fmaf(alpha, fminf(el, 0.f), alpha));   // alpha (1 + min(elu, 0))
-    return o;
-  } else {
-    th = tanhf(a);
-    el = a > 0.f ? a : expm1f(a);
-    dexp = a > 0.f ? 1.f : expf(a);
-  }
-  o.h = th + alpha * (el - th);
-  o.dact = alpha * dexp + (1.f - alpha) * (1.f - th * th);
-  o.ediff = el - th;
-  return o;
-}
-
-template <bool FAST>
-__device__ __forceinline__ float act_fwd(float a, float alpha) {
-  float th, el;
-  if constexpr (FAST) {
-    const float e1 = BNF_EXP2(fabsf(a) * -1.44269504088896340736f);
-    float r = BNF_RCP(__builtin_fmaf(e1, e1, 1.f));
-    asm volatile("" : "+v"(r));
-    th = copysignf(__builtin_fmaf(2.f, r, -1.f), a);
-    el = fmaxf(a, e1 - 1.f);
-  } else {
-    th = tanhf(a);
-    el = a > 0.f ? a : expm1f(a);
-  }
-  return th + alpha * (el - th);
-}
-
-// Two-element versions for the epilogues: identical formulas, written on float2 so that the
-// adds / multiplies / fmas issue as packed v_pk_*_f32 (two elements per VALU slot; the
-// epilogues are VALU-bound).  exp2 / rcp / sign transfer / selects stay per element.
-struct ActOut2 {
-  f32x2 h, dact, ediff;
-};
-__device__ __forceinline__ f32x2 act_parts2(f32x2 a, f32x2& r_out, f32x2& el_out) {
-  // exp(-|a|) as exp2(-|a log2 e|): the |.| and the sign are source modifiers of v_exp_f32
-  const f32x2 t = a * 1.44269504088896340736f;
-  const f32x2 e1 = {BNF_EXP2(-fabsf(t.x)), BNF_EXP2(-fabsf(t.y))};
-  const f32x2 den = e1 * e1 + 1.f;
-  f32x2 r = {BNF_RCP(den.x), BNF_RCP(den.y)};
-  asm volatile("" : "+v"(r));   // see act_eval
-  const f32x2 tha = 2.f * r - 1.f;
-  const f32x2 em1 = e1 - 1.f;
-  el_out = f32x2{vmaxf(a.x, em1.x), vmaxf(a.y, em1.y)};
-  r_out = r;
-  return f32x2{copysignf(tha.x, a.x), copysignf(tha.y, a.y)};
-}
-__device__ __forceinline__ f32x2 act_fwd2(f32x2 a, float alpha) {
-  f32x2 r, el;
-  const f32x2 th = act_parts2(a, r, el);
-  return th + alpha * (el - th);
-}
-__device__ __forceinline__ ActOut2 act_eval2(f32x2 a, float alpha) {
-  ActOut2 o;
-  f32x2 r, el;
-  const f32x2 th = act_parts2(a, r, el);
-  // d elu / da = (a > 0 ? 1 : e^a) = 1 + min(elu(a), 0): no compare / select
-  const f32x2 mn = {vminf(el.x, 0.f), vminf(el.y, 0.f)};
-  o.ediff = el - th;
-  o.h = th + alpha * o.ediff;
-  o.dact = (4.f * (1.f - alpha)) * (r - r * r) + (alpha * mn + alpha);
-  return o;
-}
 
 // ---------------------------------------------------------------------------
 // Lean form of the same activation for the VALU-bound epilogues of the bf16 kernels (the epilogues
@@ -409,8 +320,8 @@ __device__ __forceinline__ ActCore2 act_core2(f32x2 t) {
   f32x2 r = {BNF_RCP(den.x), BNF_RCP(den.y)};
   asm volatile("" : "+v"(r));   // see act_eval: keeps hipcc 7.2 from mis-optimising the consumers of both builtins
   c.r = r;
-  c.dl = f32x2{vminf(e.x, 1.f), vminf(e.y, 1.f)};
-  c.mxt = f32x2{vmaxf(t.x, 0.f), vmaxf(t.y, 0.f)};
+  c.dl = f32x2{min_with_one(e.x), min_with_one(e.y)};
+  c.mxt = f32x2{max_with_zero(t.x), max_with_zero(t.y)};
   return c;
 }
 struct ActConst {
@@ -419,17 +330,88 @@ struct ActConst {
 __device__ __forceinline__ ActConst act_const(float alpha) {
   return ActConst{alpha, 1.f - 2.f * alpha, -2.f * (1.f - alpha), 4.f * (1.f - alpha)};
 }
-// two bf16 values rounded by ONE v_cvt_pk_bf16_f32 (hipcc splits a bf16x2 whose halves are stored
-// separately into two conversions); the halves then leave as ds_write_b16 / ds_write_b16_d16_hi
+// two bf16 values rounded by ONE v_cvt_pk_bf16_f32: hipcc splits a bf16x2 whose halves are stored
+// separately into two conversions (each with a zero partner); made opaque as ONE dword, the pair is
+// converted together and the halves leave as ds_write_b16 / ds_write_b16_d16_hi.  (The empty asm holds no
+// instruction, so there is no wait state hipcc could miss.)
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  uint32_t r = pack_bf16x2(lo, hi);
+  asm volatile("" : "+v"(r));
   return r;
 }
+__device__ __forceinline__ void store_pair_pk(float* p0, float* p1, float a, float b) { *p0 = a; *p1 = b; }
 __device__ __forceinline__ void store_pair_pk(bf16_t* p0, bf16_t* p1, float a, float b) {
   const uint32_t pk = cvt_pk_bf16(a, b);
   p0->bits = (uint16_t)(pk & 0xffffu);
   p1->bits = (uint16_t)(pk >> 16);
+}
+
+template <bool FAST>
+__device__ __forceinline__ ActOut act_eval(float a, float alpha) {
+  ActOut o;
+  float th, el, dexp;
+  if constexpr (FAST) {
+    // one v_exp_f32 + one v_rcp_f32 (bf16 pipeline only): the lean formulas above, one element
+    const float t = a * kLog2e;
+    const float e = BNF_EXP2(t);
+    float r = BNF_RCP(__builtin_fmaf(e, e, 1.f));
+    // Keep the reciprocal opaque: with both raw transcendental builtins visible, hipcc 7.2
+    // mis-optimises the column reductions that consume this value inside the fused kernel
+    // (wrong d bias / d k_o; every variant that hides either builtin is correct -- measured).
+    asm volatile("" : "+v"(r));
+    const float dl = min_with_one(e);
+    const float s1 = __builtin_fmaf(kLn2, max_with_zero(t), dl);          // elu + 1
+    o.ediff = __builtin_fmaf(2.f, r, s1) - 2.f;
+    o.h = __builtin_fmaf(-2.f * (1.f - alpha), r, __builtin_fmaf(alpha, s1, 1.f - 2.f * alpha));
+    o.dact = __builtin_fmaf(4.f * (1.f - alpha), __builtin_fmaf(-r, r, r), alpha * dl);
+    return o;
+  } else {
+    th = tanhf(a);
+    el = a > 0.f ? a : expm1f(a);
+    dexp = a > 0.f ? 1.f : expf(a);
+  }
+  o.h = th + alpha * (el - th);
+  o.dact = alpha * dexp + (1.f - alpha) * (1.f - th * th);
+  o.ediff = el - th;
+  return o;
+}
+
+template <bool FAST>
+__device__ __forceinline__ float act_fwd(float a, float alpha) {
+  float th, el;
+  if constexpr (FAST) {
+    const float t = a * kLog2e;
+    const float e = BNF_EXP2(t);
+    float r = BNF_RCP(__builtin_fmaf(e, e, 1.f));
+    asm volatile("" : "+v"(r));
+    const float s1 = __builtin_fmaf(kLn2, max_with_zero(t), min_with_one(e));
+    return __builtin_fmaf(-2.f * (1.f - alpha), r, __builtin_fmaf(alpha, s1, 1.f - 2.f * alpha));
+  } else {
+    th = tanhf(a);
+    el = a > 0.f ? a : expm1f(a);
+  }
+  return th + alpha * (el - th);
+}
+
+// Two-element versions for the epilogues: identical formulas, written on float2 so that the
+// adds / multiplies / fmas issue as packed v_pk_*_f32 (two elements per VALU slot; the
+// epilogues are VALU-bound).  exp2 / rcp / sign transfer / selects stay per element.
+struct ActOut2 {
+  f32x2 h, dact, ediff;
+};
+__device__ __forceinline__ f32x2 act_fwd2(f32x2 a, float alpha) {
+  const ActCore2 c = act_core2(a * kLog2e);
+  const f32x2 s = kLn2 * c.mxt + c.dl;
+  return (-2.f * (1.f - alpha)) * c.r + (alpha * s + (1.f - 2.f * alpha));
+}
+__device__ __forceinline__ ActOut2 act_eval2(f32x2 a, float alpha) {
+  ActOut2 o;
+  const ActCore2 c = act_core2(a * kLog2e);
+  const f32x2 s = kLn2 * c.mxt + c.dl;
+  o.ediff = (2.f * c.r + s) - 2.f;
+  o.h = (-2.f * (1.f - alpha)) * c.r + (alpha * s + (1.f - 2.f * alpha));
+  o.dact = (4.f * (1.f - alpha)) * (c.r - c.r * c.r) + alpha * c.dl;
+  return o;
 }
 
 // ---------------------------------------------------------------------------

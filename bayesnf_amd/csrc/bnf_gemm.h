@@ -185,7 +185,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total) {
 constexpr int kRowDotPitch = 36;   // floats: 16 lanes x ds_read_b128 at this pitch hit 64 distinct banks
 __host__ __device__ constexpr int epi_extra_lds(int epi, int wgm, int wgn, int esz) {
   if (epi != EPI_LAST) return 0;
-  const int xs = (64 * wgm * wgn + 64 * wgm + 2 * wgm * 64 * wgn + 16 + 2 * wgm * wgn) * 4;
+  const int xs = (64 * wgm * wgn + 64 * wgm + 2 * wgm * 64 * wgn + 16 + 3 * wgm * wgn) * 4;
   const int tile = 64 * wgm * (64 * wgn + 16 / esz) * esz;
   const int scratch = wgm * wgn * 64 * kRowDotPitch * 4;
   return xs + (scratch > tile ? scratch - tile : 0);
@@ -585,6 +585,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     const bool full_tile = m0 + kBM <= g.M;
     // running sums per element parity (folded after the loop)
     f32x2 sa2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, cs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    // bf16 (FAST): the lean activation core (bnf_device.h) with gamma * scale folded into the constants of
+    // act' -- dZ = z = raw act'_folded, sa2 = sum raw (elu - tanh), sg2 = sum z t (d gamma ~ (ln 2 / gamma)
+    // sum z t), cs2 = sum z
+    [[maybe_unused]] const ActConst ak = act_const(alpha);
+    [[maybe_unused]] const float gza = gamma * ep.scale * ak.alpha, gzc = gamma * ep.scale * ak.c2;
     // two instances of the element loop: only the last row tile needs the row masks
     auto dgrad_tile = [&](auto full_c) {
 #pragma unroll
@@ -600,31 +605,49 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
             unpack(apre[j][i][rg], av);
 #pragma unroll
             for (int q = 0; q < 4; q += 2) {
-              // rows past M carry copies of the last row: masked through the scale
-              f32x2 ms = {ep.scale, ep.scale};
-              if constexpr (!decltype(full_c)::value)
-                ms = f32x2{mb + q < g.M ? ep.scale : 0.f, mb + q + 1 < g.M ? ep.scale : 0.f};
-              const f32x2 dh = f32x2{acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]} * ms;
               const f32x2 a2 = {av[q], av[q + 1]};
-              ActOut2 o;
-              if (BNF_ABL(ep, 4)) { o.h = a2; o.dact = f32x2{1.f, 1.f}; o.ediff = a2; }
-              else if constexpr (FAST) o = act_eval2(a2, alpha);
-              else {
-                const ActOut o0 = act_eval<FAST>(a2.x, alpha), o1 = act_eval<FAST>(a2.y, alpha);
-                o.h = f32x2{o0.h, o1.h}; o.dact = f32x2{o0.dact, o1.dact}; o.ediff = f32x2{o0.ediff, o1.ediff};
+              if constexpr (FAST) {
+                f32x2 raw = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
+                // rows past M carry copies of the last row: masked out of the accumulator
+                if constexpr (!decltype(full_c)::value)
+                  raw = raw * f32x2{mb + q < g.M ? 1.f : 0.f, mb + q + 1 < g.M ? 1.f : 0.f};
+                const f32x2 tv = a2 * kLog2e;
+                f32x2 z = raw;
+                if (!BNF_ABL(ep, 4)) {
+                  const ActCore2 c = act_core2(tv);
+                  const f32x2 s = kLn2 * c.mxt + c.dl;
+                  const f32x2 dg = gzc * (c.r - c.r * c.r) + gza * c.dl;
+                  z = raw * dg;
+                  sa2 += raw * ((2.f * c.r + s) - 2.f);   // (in place: a running sum of raw would cost two more registers -> spills)
+                }
+                sg2 += z * tv;
+                cs2[j] += z;
+                zv[q] = z.x; zv[q + 1] = z.y;
+              } else {
+                // rows past M carry copies of the last row: masked through the scale
+                f32x2 ms = {ep.scale, ep.scale};
+                if constexpr (!decltype(full_c)::value)
+                  ms = f32x2{mb + q < g.M ? ep.scale : 0.f, mb + q + 1 < g.M ? ep.scale : 0.f};
+                const f32x2 dh = f32x2{acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]} * ms;
+                ActOut2 o;
+                if (BNF_ABL(ep, 4)) { o.h = a2; o.dact = f32x2{1.f, 1.f}; o.ediff = a2; }
+                else {
+                  const ActOut o0 = act_eval<FAST>(a2.x, alpha), o1 = act_eval<FAST>(a2.y, alpha);
+                  o.h = f32x2{o0.h, o1.h}; o.dact = f32x2{o0.dact, o1.dact}; o.ediff = f32x2{o0.ediff, o1.ediff};
+                }
+                sa2 += dh * o.ediff;
+                const f32x2 da = dh * o.dact;
+                sg2 += da * a2;
+                const f32x2 z = gamma * da;
+                cs2[j] += z;
+                zv[q] = z.x; zv[q + 1] = z.y;
               }
-              sa2 += dh * o.ediff;
-              const f32x2 da = dh * o.dact;
-              sg2 += da * a2;
-              const f32x2 z = gamma * da;
-              cs2[j] += z;
-              zv[q] = z.x; zv[q + 1] = z.y;
             }
             const int lr = wr * 64 + 4 * kg + i * 32 + 8 * rg, lc = wc * 64 + j * 32 + frow;
             if (!BNF_ABL(ep, 2)) {
 #pragma unroll
               for (int q = 0; q < 4; q += 2)
-                store_pair(tile + (lr + q) * kPitch + lc, tile + (lr + q + 1) * kPitch + lc, zv[q], zv[q + 1]);
+                store_pair_pk(tile + (lr + q) * kPitch + lc, tile + (lr + q + 1) * kPitch + lc, zv[q], zv[q + 1]);
             }
             // pin the running sums (see EPI_LAST): keeps the add chains from sinking to their use
             asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(cs2[0]), "+v"(cs2[1]));
@@ -634,7 +657,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     };
     if (full_tile) dgrad_tile(std::true_type{});
     else dgrad_tile(std::false_type{});
-    const float s_alpha = sa2.x + sa2.y, s_gamma = sg2.x + sg2.y;
+    float s_alpha = sa2.x + sa2.y, s_gamma = sg2.x + sg2.y;
+    if constexpr (FAST) {
+      s_alpha *= ep.scale;
+      s_gamma *= kLn2 / gamma;
+    }
     const float colsum[2] = {cs2[0].x + cs2[0].y, cs2[1].x + cs2[1].y};
     __syncthreads();
     if (!BNF_ABL(ep, 2)) tile_to_global(oz, ep.ld);
@@ -690,13 +717,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     float* s_dv = s_part + kBM * WGN;         // [kBM]
     float* s_col = s_dv + kBM;                // [2][WGM][kBN]
     float* s_sc = s_col + 2 * WGM * kBN;      // scalars
+    [[maybe_unused]] const ActConst ak = act_const(alpha);
+    float ksum = 0.f;    // FAST: c0 * (sum of k_o over this wave's columns), the constant term of the row dot
     {
-      const float gs = gamma * ep.scale;   // A = acc gs + gb
+      // FAST (bf16): the accumulators keep t = A log2(e) from here on (lean activation core, bnf_device.h);
+      // act(A) = c0 + c1 r + alpha s, so the row dot with k_o accumulates (k_o alpha) s + (k_o c1) r
+      const float gs = gamma * ep.scale * (FAST ? kLog2e : 1.f);   // A = acc gs + gb
       float gb[2], kov[2];
+      [[maybe_unused]] float ka[2], kc1[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        gb[j] = gamma * th[ep.off_bias + nw + j * 32];
+        gb[j] = gamma * th[ep.off_bias + nw + j * 32] * (FAST ? kLog2e : 1.f);
         kov[j] = th[ep.off_ko + nw + j * 32];
+        ka[j] = kov[j] * ak.alpha; kc1[j] = kov[j] * ak.c1;
+      }
+      if constexpr (FAST) {
+        ksum = wave_sum(kg == 0 ? kov[0] + kov[1] : 0.f);
+        if (lane == 0) s_sc[16 + 2 * kWaves + wave] = ksum;
+        ksum *= ak.c0;
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -709,12 +747,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
 #pragma unroll
               for (int q = 0; q < 4; q += 2) {
                 const f32x2 raw = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
-                const f32x2 av = raw * gs + gb[j];
-                acc[i][j][rg * 4 + q] = av.x;
-                acc[i][j][rg * 4 + q + 1] = av.y;
-                const f32x2 hk = act_fwd2(av, alpha) * kov[j];
-                pd[q] += hk.x;
-                pd[q + 1] += hk.y;
+                const f32x2 tv = raw * gs + gb[j];
+                acc[i][j][rg * 4 + q] = tv.x;
+                acc[i][j][rg * 4 + q + 1] = tv.y;
+                const ActCore2 c = act_core2(tv);
+                const f32x2 s = kLn2 * c.mxt + c.dl;
+                f32x2 pq = {pd[q], pd[q + 1]};
+                pq = ka[j] * s + pq;
+                pq = kc1[j] * c.r + pq;
+                pd[q] = pq.x;
+                pd[q + 1] = pq.y;
               }
             } else {
 #pragma unroll
@@ -738,7 +780,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
       f32x4 t4 = rp[0];
 #pragma unroll
       for (int c = 1; c < 8; ++c) t4 += rp[c];
-      s_part[(wr * 64 + lane) * WGN + wc] = (t4.x + t4.y) + (t4.z + t4.w);
+      s_part[(wr * 64 + lane) * WGN + wc] = ((t4.x + t4.y) + (t4.z + t4.w)) + ksum;
     }
     __syncthreads();
     BNF_MARK(ep, 3);
@@ -776,12 +818,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     __syncthreads();
     BNF_MARK(ep, 4);
     float* gr = ep.grad + (int64_t)e * ep.grad_stride;
+    float dv_all = 0.f;   // thread 0: sum of d loss / d v over the tile's rows
     if (tid == 0) {
       float u[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int w2 = 0; w2 < kBM / 64; ++w2)
 #pragma unroll
         for (int i = 0; i < 5; ++i) u[i] += s_sc[w2 * 5 + i];
+      dv_all = u[2];
       const float step_loss = -ep.lik_c * u[0];
       atomicAdd(&ep.loss[(int64_t)(e / ep.S) * ep.loss_stride + (ep.st ? ep.st->col : 0)], ep.loss_scale * step_loss);
       if (ep.loss_raw) atomicAdd(&ep.loss_raw[e], step_loss);
@@ -798,6 +842,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
     for (int j = 0; j < 2; ++j) sa[j] = sg[j] = cp[j] = ck[j] = f32x2{0.f, 0.f};
     const float kvn[2] = {th[ep.off_ko + nw] * inv_sw, th[ep.off_ko + nw + 32] * inv_sw};
     const float gk[2] = {gamma * kvn[0], gamma * kvn[1]};
+    // FAST: dZ = z = dv (gamma k_o / sqrt W) act'(A) formed directly (column factor folded into act''s
+    // constants); sa = sum dv (elu - tanh + 2) (the "+ 2" leaves through thread 0 below), sg = sum z t,
+    // cp = sum z (= d bias), ck = sum act(A) dv -- the row-panel kernel's scheme (bnf_panel.h)
+    [[maybe_unused]] const float gka[2] = {gk[0] * ak.alpha, gk[1] * ak.alpha};
+    [[maybe_unused]] const float gkc[2] = {gk[0] * ak.c2, gk[1] * ak.c2};
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -814,20 +863,29 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
             // place between the fences; pure arithmetic would otherwise be emitted before them)
             asm volatile("" : "+v"(av));
             const f32x2 dv2 = {dv4[q], dv4[q + 1]};
-            ActOut2 o;
             if constexpr (FAST) {
-              o = act_eval2(av, alpha);
+              const ActCore2 c = act_core2(av);     // av holds t = A log2(e)
+              const f32x2 s = kLn2 * c.mxt + c.dl;
+              const f32x2 h = ak.c1 * c.r + (ak.alpha * s + ak.c0);
+              const f32x2 dg = gkc[j] * (c.r - c.r * c.r) + gka[j] * c.dl;
+              const f32x2 z = dv2 * dg;
+              sa[j] += dv2 * (2.f * c.r + s);
+              sg[j] += z * av;
+              cp[j] += z;
+              ck[j] += h * dv2;
+              store_pair_pk(tile + (lr + q) * kPitch + lc, tile + (lr + q + 1) * kPitch + lc, z.x, z.y);
             } else {
               const ActOut o0 = act_eval<FAST>(av.x, alpha), o1 = act_eval<FAST>(av.y, alpha);
+              ActOut2 o;
               o.h = f32x2{o0.h, o1.h}; o.dact = f32x2{o0.dact, o1.dact}; o.ediff = f32x2{o0.ediff, o1.ediff};
+              const f32x2 p = dv2 * o.dact;
+              sa[j] += dv2 * o.ediff;
+              sg[j] += p * av;
+              cp[j] += p;
+              ck[j] += o.h * dv2;
+              const f32x2 z = gk[j] * p;
+              store_pair(tile + (lr + q) * kPitch + lc, tile + (lr + q + 1) * kPitch + lc, z.x, z.y);
             }
-            const f32x2 p = dv2 * o.dact;
-            sa[j] += dv2 * o.ediff;
-            sg[j] += p * av;
-            cp[j] += p;
-            ck[j] += o.h * dv2;
-            const f32x2 z = gk[j] * p;
-            store_pair(tile + (lr + q) * kPitch + lc, tile + (lr + q + 1) * kPitch + lc, z.x, z.y);
           }
         }
         // pin the running sums here: otherwise the add chains (and everything feeding them)
@@ -837,8 +895,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
         __builtin_amdgcn_sched_barrier(0);
       }
     const float s_alpha = kvn[0] * (sa[0].x + sa[0].y) + kvn[1] * (sa[1].x + sa[1].y);
-    const float s_gamma = kvn[0] * (sg[0].x + sg[0].y) + kvn[1] * (sg[1].x + sg[1].y);
-    const float cs_b[2] = {gk[0] * (cp[0].x + cp[0].y), gk[1] * (cp[1].x + cp[1].y)};
+    const float s_gamma = FAST ? (kLn2 / gamma) * ((sg[0].x + sg[0].y) + (sg[1].x + sg[1].y))
+                               : kvn[0] * (sg[0].x + sg[0].y) + kvn[1] * (sg[1].x + sg[1].y);
+    const float cs_b[2] = {FAST ? cp[0].x + cp[0].y : gk[0] * (cp[0].x + cp[0].y),
+                           FAST ? cp[1].x + cp[1].y : gk[1] * (cp[1].x + cp[1].y)};
     const float cs_k[2] = {ck[0].x + ck[0].y, ck[1].x + ck[1].y};
     __syncthreads();
     BNF_MARK(ep, 5);
@@ -875,6 +935,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
       for (int w2 = 0; w2 < kWaves; ++w2) {
         ta += s_sc[16 + w2 * 2];
         tg += s_sc[17 + w2 * 2];
+      }
+      if constexpr (FAST) {   // the "+ 2" of the sa sums: 2 (sum_c k_o / sqrt W) (sum_r dv); wave row 0 holds one column slab each
+        float ko_all = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < WGN; ++w2) ko_all += s_sc[16 + 2 * kWaves + w2];
+        ta -= 2.f * inv_sw * ko_all * dv_all;
       }
       atomicAdd(&gr[ep.off_act_weight], alpha * (1.f - alpha) * ta);
       atomicAdd(&gr[ep.off_layer_scale], sigmoidf(th[ep.off_layer_scale]) * tg / gamma);

@@ -43,17 +43,20 @@ struct NetDev {
 
 // Which data row does batch position r of (virtual) member e read?
 struct RowSrc {
-  int32_t mode;          // 0 identity, 1 per-member epoch shuffle, 2 shared random batch
+  int32_t mode;          // 0 identity, 1 per-member epoch shuffle, 2 shared random batch, 3 caller's row table
   int32_t S;             // virtual members per member (VI samples), >= 1
   uint64_t seed;
   uint64_t epoch;        // mode 1: epoch ; mode 2: step
-  int64_t pos0;          // mode 1: step * B
+  int64_t pos0;          // mode 1 / 3: step * B
   int64_t n_rows;        // N
   int64_t member_offset; // global id of local member 0
+  const int32_t* table;  // mode 3: this epoch's (members, table_ld) shuffled row ids (bnf_row_tables)
+  int64_t table_ld;
 };
 
 __device__ __forceinline__ int64_t row_of(const RowSrc& rs, int e, int64_t r) {
   if (rs.mode == 0) return r;
+  if (rs.mode == 3) return (int64_t)rs.table[(int64_t)(e / rs.S) * rs.table_ld + rs.pos0 + r];
   if (rs.mode == 1) {
     const FeistelKey fk = feistel_key(rs.seed, (uint32_t)(rs.member_offset + e / rs.S), rs.epoch,
                                       STREAM_SHUFFLE, (uint64_t)rs.n_rows);

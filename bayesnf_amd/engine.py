@@ -149,6 +149,23 @@ class Engine:
                                        _ptr(losses)), 'bnf_train')
     return losses
 
+  def set_row_tables(self, tables, epoch0=0):
+    """Epoch shuffles supplied by the caller (include/bnf.h bnf_row_tables): int32 (n_epochs, members,
+    (N // batch) * batch) row ids for the epochs [epoch0, epoch0 + n_epochs); uploaded and kept alive
+    here (together with the previous chunk, which may still be executing).  None restores the engine's
+    own shuffle."""
+    if tables is None:
+      self._row_tables = []
+      _native.check(self.lib.bnf_row_tables(self.handle, None, 0, 0), 'bnf_row_tables')
+      return
+    t = tables if isinstance(tables, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(tables, dtype=np.int32))
+    t = t.to(self.device, non_blocking=True).contiguous()
+    keep = (self.n_rows // self.batch) * self.batch
+    if t.dtype != torch.int32 or t.dim() != 3 or t.shape[1] != self.members or t.shape[2] != keep:
+      raise ValueError(f'row tables must be int32 (n_epochs, {self.members}, {keep}); got {tuple(t.shape)} {t.dtype}')
+    self._row_tables = (getattr(self, '_row_tables', []) + [t])[-2:]
+    _native.check(self.lib.bnf_row_tables(self.handle, _ptr(t), int(epoch0), int(t.shape[0])), 'bnf_row_tables')
+
   def vi_posterior_draws(self, n_draws: int) -> torch.Tensor:
     out = torch.empty((n_draws, self.members, self.net.P), dtype=torch.float32,
                       device=self.device)

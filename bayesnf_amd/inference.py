@@ -54,8 +54,10 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
 
   init_rng: 'jax' (default; env BNF_INIT_RNG) starts every member from the initial parameters the
   reference itself would draw for `seed` (threefry + TFP seed chain restated on the host,
-  `jaxseed`), 'philox' from the device generator (`bnf_init_params`).  Minibatch shuffles always
-  come from the device's keyed Feistel permutation.
+  `jaxseed`) and, for minibatch fits, shuffles every epoch with the reference's own per-member
+  `jax.random.permutation` stream (`jaxseed.map_row_tables` -> `bnf_row_tables`): same seed => the fit
+  follows the reference's trajectory.  'philox' draws the initial parameters from the device generator
+  (`bnf_init_params`) and shuffles with the device's keyed Feistel permutation (no index arrays).
 
   Returns (params, losses): params is a StructTuple whose leaves have shape
   (num_devices, num_particles // num_devices, *leaf_shape); losses has shape
@@ -82,6 +84,11 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
     keys = (jaxseed.member_keys(seed, world, per_device, i if num_splits > 1 else None)
             if init_rng == 'jax' else None)
 
+    # minibatch epochs under init_rng='jax': every member's per-epoch `jax.random.permutation` of the
+    # reference (inference.py:593-597), keys on the host once per fit
+    pkeys = (jaxseed.map_permute_keys(seed, world, per_device, num_epochs, i if num_splits > 1 else None)
+             if init_rng == 'jax' and batch_size < n_rows and num_epochs > 0 else None)
+
     def train_shard(sh):
       # device sh.index of the job owns the members [index * per_device, (index + 1) * per_device): the
       # whole optimisation is enqueued on that device's stream; nothing is waited for here
@@ -93,7 +100,18 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
         eng.set_params(jaxseed.map_initial_params(net, keys[sh.index], log_noise_init))
       else:
         eng.init_params(log_noise_init)
-      return eng, eng.train(0, num_epochs)
+      if pkeys is None:
+        return eng, eng.train(0, num_epochs)
+      # the shuffles are drawn on the host (threefry bits + stable sort per member and epoch) in chunks of
+      # <= ~64 MB of row ids; chunk c + 1 is drawn while the device runs the epochs of chunk c
+      keep = (n_rows // batch_size) * batch_size
+      per_chunk = int(max(1, min(num_epochs, (64 << 20) // max(1, 4 * per_device * keep))))
+      parts = []
+      for e0 in range(0, num_epochs, per_chunk):
+        n = min(per_chunk, num_epochs - e0)
+        eng.set_row_tables(jaxseed.map_row_tables(pkeys[sh.index][:, e0:e0 + n], n_rows, batch_size), epoch0=e0)
+        parts.append(eng.train(e0, n))
+      return eng, torch.cat(parts, dim=1)
 
     runs = distributed.run_shards(train_shard)
     thetas.append(distributed.gather_shards([e.params.view(per_device, net.P) for e, _ in runs]).cpu().numpy())

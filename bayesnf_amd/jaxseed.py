@@ -200,6 +200,61 @@ def vi_draw_keys(net, seed, world: int, rank: int, num_draws: int):
   return _jd_leaf_keys(_split_many(fold_in(sample_seed, _IID_SALT), num_draws), len(net.leaves))
 
 
+# ----------------------------------------------------------------------------- minibatch shuffles (MAP / MLE)
+def _bits_many(keys: np.ndarray, n: int) -> np.ndarray:
+  """jax.random.bits(key, (n,)) for an array of keys (M, 2) -> (M, n) uint32."""
+  keys = np.asarray(keys, dtype=_U32).reshape(-1, 2)
+  m = n + (n & 1)
+  c = np.arange(m, dtype=_U32)
+  c[n:] = 0
+  y0, y1 = _threefry((keys[:, 0, None], keys[:, 1, None]), c[None, :m // 2], c[None, m // 2:])
+  return np.concatenate([y0, y1], axis=1)[:, :n]
+
+
+def permutations(keys: np.ndarray, n: int) -> np.ndarray:
+  """`jax.random.permutation(key, jnp.arange(n))` for every key of (M, 2) -> int32 (M, n).
+  jax/_src/random.py `_shuffle`: ceil(3 ln n / ln(2^32 - 1)) rounds of `key, sub = split(key)`, a STABLE
+  sort of the current order by `bits(sub, (n,))`."""
+  keys = np.asarray(keys, dtype=_U32).reshape(-1, 2)
+  rounds = int(np.ceil(3 * np.log(max(1, n)) / np.log(np.iinfo(np.uint32).max)))
+  x = np.broadcast_to(np.arange(n, dtype=np.int32), (keys.shape[0], n)).copy()
+  for _ in range(rounds):
+    pair = _split_many(keys, 2)
+    keys, sub = pair[:, 0], pair[:, 1]
+    order = np.argsort(_bits_many(sub, n), axis=1, kind='stable')
+    x = np.take_along_axis(x, order, axis=1)
+  return x
+
+
+def map_permute_keys(seed, world: int, per_device: int, num_epochs: int, split_index=None) -> np.ndarray:
+  """(world, per_device, num_epochs, 2): the `permute_seed` of every member and epoch of ensemble_map
+  (/root/reference/src/bayesnf/inference.py:571-575, 593, 622; fit_map's `fold_in(seed, i)` :432-441):
+  `opt_seed = split(seed)[1]`, member key = `split(opt_seed, (devices, members))[d, e]`, and per epoch
+  `seed, permute_seed = split(seed)`.  A function of the GLOBAL member index only."""
+  key = as_key(seed)
+  if split_index is not None:
+    key = fold_in(key, int(split_index))
+  carry = split(split(key, 2)[1], world * per_device)
+  out = np.empty((world * per_device, num_epochs, 2), dtype=_U32)
+  for ep in range(num_epochs):
+    pair = _split_many(carry, 2)
+    carry, out[:, ep] = pair[:, 0], pair[:, 1]
+  return out.reshape(world, per_device, num_epochs, 2)
+
+
+def map_row_tables(permute_keys: np.ndarray, n_rows: int, batch: int) -> np.ndarray:
+  """Epoch shuffles for `bnf_row_tables`: permute_keys (members, n_epochs, 2) -> int32 (n_epochs, members,
+  (n_rows // batch) * batch): the leading full batches of each member's permuted data set
+  (`_reshape_to_batches` drops the ragged tail, inference.py:583-589)."""
+  pk = np.asarray(permute_keys, dtype=_U32)
+  members, n_epochs = pk.shape[0], pk.shape[1]
+  keep = (n_rows // batch) * batch
+  out = np.empty((n_epochs, members, keep), dtype=np.int32)
+  for ep in range(n_epochs):
+    out[ep] = permutations(pk[:, ep], n_rows)[:, :keep]
+  return out
+
+
 def leaf_offsets(net) -> np.ndarray:
   """int32 (n_leaves + 1): offsets of the packed leaves in the reference's order."""
   off = [lf.offset for lf in net.leaves] + [net.P]

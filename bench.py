@@ -248,24 +248,77 @@ def gather_rank_times(world, device, elapsed):
   return [float(v) for v in out.cpu()]
 
 
-def gather_posterior(world, device, local_means):
+class _SelftestCommLib:
+  """CPU self-test stand-in for the three communicator entry points of libbnf_hip.so (include/bnf.h:
+  bnf_comm_unique_id / bnf_comm_create / bnf_allgather): records what `_native.allgather` hands over --
+  the 128-byte id every rank must agree on, world / rank, buffer addresses and byte counts -- and moves the
+  bytes with the gloo group, so tests/test_bench_launcher.py covers the `--gather cabi` plumbing without a GPU."""
+
+  def __init__(self):
+    self.calls = []
+    self.ident = None
+
+  def bnf_comm_unique_id(self, buf):
+    buf.raw = bytes((7 * i + 3) % 251 for i in range(128))
+    return 0
+
+  def bnf_comm_create(self, raw, world, rank, device, out):
+    self.ident = bytes(raw.raw)
+    self.calls.append(('create', world, rank, device))
+    return 0
+
+  def bnf_allgather(self, comm, send, recv, nbytes, stream):
+    import ctypes
+    import torch
+    n = int(nbytes.value)
+    world = torch.distributed.get_world_size()
+    src = torch.frombuffer((ctypes.c_char * n).from_address(send.value), dtype=torch.uint8)
+    dst = torch.frombuffer((ctypes.c_char * (n * world)).from_address(recv.value), dtype=torch.uint8)
+    torch.distributed.all_gather_into_tensor(dst, src)
+    self.calls.append(('allgather', n))
+    return 0
+
+
+def gather_posterior(world, rank, device, local_means, impl, lib=None):
   """The job's only data collective (reference inference.py:452,486-492: pmap's output gather):
   every rank's device-resident predictive means (E_local, R) -> (world * E_local, R) on every rank
-  with ONE all_gather_into_tensor (RCCL over xGMI under backend nccl).  -> (tensor, ms)."""
+  with ONE all-gather over RCCL / xGMI -- impl 'cabi': `bnf_allgather` of the engine library (the C ABI a
+  non-torch host would call; librccl resolved inside libbnf_hip.so), 'torch': all_gather_into_tensor of
+  the nccl (= RCCL) process group.  -> (tensor, ms)."""
   import torch
   local_means = local_means.contiguous()
   if world == 1:
     return local_means, 0.0
   out = torch.empty((world * local_means.shape[0],) + tuple(local_means.shape[1:]), dtype=local_means.dtype,
                     device=device)
+  if impl == 'cabi':   # communicator set-up (id broadcast, ncclCommInitRank) outside the timed collective
+    from bayesnf_amd import _native
+    warm_s = torch.zeros(8, dtype=torch.float32, device=device)
+    warm_r = torch.zeros(8 * world, dtype=torch.float32, device=device)
+    _native.allgather(warm_s, warm_r, world, rank, lib=lib)
   if device.type == 'cuda':
     torch.cuda.synchronize(device)
   torch.distributed.barrier()
   t0 = time.perf_counter()
-  torch.distributed.all_gather_into_tensor(out, local_means)
+  if impl == 'cabi':
+    _native.allgather(local_means, out, world, rank, lib=lib)
+  else:
+    torch.distributed.all_gather_into_tensor(out, local_means)
   if device.type == 'cuda':
     torch.cuda.synchronize(device)
   return out, (time.perf_counter() - t0) * 1e3
+
+
+def gather_checksums(world, device, local_means):
+  """Every rank's own checksum of what it contributed (float64 sum), gathered separately from the
+  payload: rank 0 compares them with the sums of the blocks the posterior gather delivered."""
+  import torch
+  mine = local_means.double().sum().reshape(1).to(device)
+  if world == 1:
+    return [float(mine.item())]
+  out = torch.empty(world, dtype=torch.float64, device=device)
+  torch.distributed.all_gather_into_tensor(out, mine)
+  return [float(v) for v in out.cpu()]
 
 
 def main(argv=None):
@@ -275,6 +328,12 @@ def main(argv=None):
   ap.add_argument('--steps', type=int, default=30)
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--members-per-gpu', type=int, default=64)
+  ap.add_argument('--strong', action='store_true',
+                  help='strong scaling: --members-per-gpu is the size of the WHOLE ensemble, split evenly over the '
+                       'ranks (default: weak scaling, that many members on every GPU)')
+  ap.add_argument('--gather', default=None, choices=['cabi', 'torch'],
+                  help="posterior gather through bnf_allgather of the engine library (default on GPUs; env "
+                       "BNF_GATHER) or torch.distributed's all_gather_into_tensor")
   ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--profile-all', action='store_true',
@@ -297,6 +356,11 @@ def main(argv=None):
 
   X, y, input_scales = synthetic_grid()
   E = args.members_per_gpu
+  if args.strong:
+    if E % world:
+      raise SystemExit(f'[bench] --strong: {E} members do not split evenly over {world} ranks')
+    E //= world
+  gather_impl = args.gather or os.environ.get('BNF_GATHER') or ('torch' if args.selftest_cpu else 'cabi')
 
   def sync():
     if device.type == 'cuda':
@@ -365,13 +429,33 @@ def main(argv=None):
       Xd = torch.from_numpy(np.ascontiguousarray(X[:1024], dtype=np.float32)).to(device)
       local_means, _ = fwd.forward(eng.params.view(E, net.P), Xd)
       torch.cuda.synchronize(device)
-    allm, ms = gather_posterior(world, device, local_means)
-    gather = {'impl': 'torch.distributed.all_gather_into_tensor (backend %s)' % torch.distributed.get_backend(),
+    comm_lib = _SelftestCommLib() if (args.selftest_cpu and gather_impl == 'cabi') else None
+    sums = gather_checksums(world, device, local_means)
+    cabi_error = None
+    try:
+      allm, ms = gather_posterior(world, rank, device, local_means, gather_impl, lib=comm_lib)
+    except Exception as exc:  # pylint: disable=broad-except
+      if gather_impl != 'cabi':
+        raise
+      # the C-ABI communicator could not be set up on this node: say so in the line and gather with the
+      # process group instead (the timed region is already over; the collective is not part of `value`)
+      cabi_error, gather_impl = f'{type(exc).__name__}: {exc}'[:300], 'torch'
+      allm, ms = gather_posterior(world, rank, device, local_means, gather_impl)
+    got = [float(v) for v in allm.view(world, -1).double().sum(dim=1).cpu()]
+    gather = {'impl': ('bnf_allgather (C ABI of libbnf_hip.so -> ncclAllGather, RCCL)' if gather_impl == 'cabi' else
+                       'torch.distributed.all_gather_into_tensor (backend %s)' % torch.distributed.get_backend()),
               'shape': list(allm.shape), 'bytes_per_rank': local_means.numel() * local_means.element_size(),
-              'ms': ms, 'finite': bool(torch.isfinite(allm).all().item())}
+              'ms': ms, 'finite': bool(torch.isfinite(allm).all().item()),
+              'rank_checksums': sums,
+              'rank_checksums_ok': all(abs(a - b) <= 1e-9 * max(1.0, abs(a)) for a, b in zip(sums, got))}
+    if cabi_error:
+      gather['cabi_error'] = cabi_error
     if args.selftest_cpu:   # every rank's block must hold that rank's id
       blocks = allm.view(world, E, -1)[:, 0, 0].tolist()
       gather['rank_blocks_ok'] = blocks == [float(r) for r in range(world)]
+      if comm_lib is not None:
+        gather['cabi_calls'] = comm_lib.calls
+        gather['cabi_id_head'] = list(comm_lib.ident[:4])
     if not args.selftest_cpu:
       fwd.close()
 
@@ -382,7 +466,7 @@ def main(argv=None):
         'metric': 'train-steps/sec x ensemble_size (member-steps/s, whole job)',
         'value': value, 'unit': 'member-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'C2 chickenpox-like MAP: N=10232 rows, D=3, F=57, width=512, '
                                'depth=2, NORMAL, full batch, lr=0.005',

@@ -162,6 +162,18 @@ int bnf_train(bnf_handle* h, int64_t epoch0, int64_t num_epochs, float* losses /
  * surrogate (inference.py:741-745).  out: DEVICE (n_draws, members, P) f32. */
 int bnf_vi_posterior_draws(bnf_handle* h, int32_t n_draws, float* out /*DEVICE*/);
 
+/* The reference's OWN minibatch shuffles for MAP / MLE (optional; without it every member shuffles each
+ * epoch with the engine's keyed Feistel bijection -- same law, other numbers).  ensemble_map
+ * (inference.py:571-575, 593-597, 622) permutes the data set per member and per epoch with
+ * jax.random.permutation(permute_seed, N), permute_seed from the member's key chain; bayesnf_amd/jaxseed.py
+ * restates that chain on the host.
+ *   tables DEVICE int32 (n_epochs, members, (N / batch) * batch): row ids of the epochs
+ *          [epoch0, epoch0 + n_epochs) of bnf_train's epoch counter, step s of an epoch reading
+ *          columns [s * batch, (s + 1) * batch); values in [0, N).  Caller-owned, must stay alive while
+ *          those epochs are enqueued AND executing; epochs outside the range use the engine's shuffle.
+ * NULL restores the engine's shuffle.  Full-batch handles ignore it (no shuffle there). */
+int bnf_row_tables(bnf_handle* h, const int32_t* tables, int64_t epoch0, int64_t n_epochs);
+
 /* The reference's OWN random stream for the VI noise (optional; without it the noise comes from the
  * engine's counter-based generator -- same law, other numbers).  tfp.vi.fit_surrogate_posterior_stateless
  * (inference.py:727-738) draws, at every step, `vi_samples` joint samples of the surrogate, each leaf

@@ -193,6 +193,27 @@ def reference_map_init_matrices(model, seed, n_members: int, split_index=None):
   return mats
 
 
+def reference_map_permutations(seed, n_members: int, n_epochs: int, n_rows: int, split_index=None):
+  """The data-set permutation every member draws in every epoch of a minibatch MAP / MLE fit
+  (ensemble_map, inference.py:571-575: `init_seed, opt_seed = split(seed)`, member seed =
+  `split(opt_seed, (devices, members))[d, e]`; `_one_epoch` :593-597: `seed, permute_seed = split(seed)`,
+  `permute_dataset` :35-39 = `jax.random.permutation(permute_seed, arange(N))`) -> int (n_members,
+  n_epochs, n_rows).  The chain is read off the reference's source; no golden exercises it (the
+  reference's goldens are full-batch), so it rests on the pinned `split` / `bits` restatements."""
+  key = np.asarray(seed, dtype=U32)
+  if split_index is not None:
+    key = fold_in(key, int(split_index))
+  opt_seed = split(key, 2)[1]
+  seeds = split(opt_seed, n_members)
+  out = np.empty((n_members, n_epochs, n_rows), dtype=np.int64)
+  for e in range(n_members):
+    s = seeds[e]
+    for ep in range(n_epochs):
+      s, permute_seed = split(s, 2)
+      out[e, ep] = permutation(permute_seed, n_rows)
+  return out
+
+
 # --------------------------------------------------------------------------- the reference's VI chain
 # ensemble_vi (inference.py:626-764), determined against tests/test_data/bnf-vi.chickenpox.8.mini.pred.csv
 # the same way as the MAP chain (scripts/n1_vi_chain_search.py: of ~1,300 candidate chains exactly one

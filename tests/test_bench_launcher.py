@@ -34,6 +34,26 @@ def test_two_gloo_ranks_end_to_end_through_bench():
   assert g['shape'] == [6, 16] and g['rank_blocks_ok'] and g['finite'] and 'all_gather_into_tensor' in g['impl']
 
 
+def test_cabi_gather_plumbing_and_strong_scaling_flag():
+  """`--gather cabi` (the GPU default): `_native.allgather` makes the communicator id on rank 0, carries it
+  to the other rank over the process group, creates one communicator per rank and calls bnf_allgather with
+  the per-rank byte count -- here against bench.py's stand-in for the three C entry points (no GPU); the
+  per-rank checksums gathered beside the payload match the delivered blocks.  `--strong`: the ensemble
+  size is fixed and split over the ranks."""
+  r = _run(['--selftest-cpu', '--gpus', '2', '--steps', '2', '--warmup', '1', '--members-per-gpu', '6', '--strong',
+            '--gather', 'cabi'])
+  assert r.returncode == 0, r.stderr[-2000:]
+  d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+  assert d['scaling'] == 'strong' and d['config']['ensemble_size'] == 6 and d['config']['members_per_gpu'] == 3
+  g = d['posterior_gather']
+  assert 'bnf_allgather' in g['impl'] and g['shape'] == [6, 16] and g['rank_blocks_ok'] and g['rank_checksums_ok']
+  assert g['rank_checksums'] == [0.0, 48.0]                      # rank r contributes 3 x 16 values r
+  assert g['cabi_calls'][0] == ['create', 2, 0, 0]               # rank 0's view: world 2, rank 0
+  assert ['allgather', 3 * 16 * 4] in g['cabi_calls'] and g['cabi_id_head'] == [3, 10, 17, 24]
+  r = _run(['--selftest-cpu', '--gpus', '2', '--steps', '1', '--warmup', '1', '--members-per-gpu', '5', '--strong'])
+  assert r.returncode != 0 and 'do not split evenly' in (r.stderr + r.stdout)
+
+
 def test_single_rank_line_has_the_contract_fields():
   r = _run(['--selftest-cpu', '--steps', '3', '--warmup', '1'])
   assert r.returncode == 0, r.stderr[-2000:]

@@ -316,3 +316,43 @@ def test_vi_fit_reproduces_the_reference_golden(golden_dir):
     eps = R.reference_vi_posterior_noise(model, seed, 7, E)
     np.testing.assert_allclose(draws, p[0][None] + O.vi_sigma(p[1])[None] * eps, rtol=2e-5, atol=2e-5)
     eng.close()
+
+
+@pytest.mark.parametrize('cls,pw', [(BayesianNeuralFieldMAP, 1.0), (BayesianNeuralFieldMLE, 0.0)])
+def test_minibatch_fit_follows_the_reference_shuffle_stream(golden_dir, cls, pw):
+  """`fit(seed, batch_size=32)` through the product path (jaxseed key chain -> bnf_row_tables -> fp32
+  engine) equals the oracle trained on the reference's own per-member per-epoch
+  `jax.random.permutation` stream (oracle/jax_rng.py restates /root/reference/src/bayesnf/
+  inference.py:35-39,571-575,593-597) from the reference's own initial particles: minibatch fits are
+  seed-for-seed like full-batch ones (which the reference's goldens pin).  100 rows, batch 32: three
+  steps per epoch, the ragged tail of 4 rows dropped."""
+  from oracle import jax_rng as R
+  from tests.test_oracle_kat import _setup
+  from bayesnf_amd import spatiotemporal as st
+  df = _train_frame(golden_dir)
+  E, epochs, B = 4, 3, 32
+  est = cls(**MODEL).fit(df, seed=0, ensemble_size=E, num_epochs=epochs, learning_rate=0.005, batch_size=B)
+  model, X, y = _setup(golden_dir, st.BayesianNeuralFieldMAP)
+  key = R.prng_key(0)
+  theta0 = O.map_init(model, y, R.reference_map_init_matrices(model, key, E), dtype=np.float32).astype(np.float64)
+  perms = R.reference_map_permutations(key, E, epochs, len(y))             # (E, epochs, N)
+  theta_o, losses_o = O.train_map(model, theta0, X, y, lr=0.005,
+                                  num_epochs=epochs, batch_size=B, prior_weight=pw,
+                                  row_index_fn=lambda ep: perms[:, ep, :(len(y) // B) * B])
+  np.testing.assert_allclose(est.losses_[0], losses_o, rtol=1e-4)
+  from bayesnf_amd.spec import NetSpec
+  args = est._model_args(est.data_handler.get_test(df).shape)
+  theta_d = NetSpec(**args).pack(list(est.params_))[0]
+  assert util_rel_err(theta_d, theta_o) < 1e-3
+  # and it is NOT the engine's own shuffle: the Feistel stream gives other numbers from the same start
+  os.environ['BNF_INIT_RNG'] = 'philox'
+  try:
+    other = cls(**MODEL).fit(df, seed=0, ensemble_size=E, num_epochs=epochs, learning_rate=0.005, batch_size=B)
+  finally:
+    del os.environ['BNF_INIT_RNG']
+  assert np.abs(other.losses_[0] - losses_o).max() > 1e-3 * np.abs(losses_o).max()
+
+
+def util_rel_err(a, b):
+  a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+  return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))

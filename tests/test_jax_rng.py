@@ -152,3 +152,23 @@ def test_product_vi_noise_keys_equal_the_oracle_chain(golden_dir):
         np.testing.assert_array_equal(R.normal(keys[k, j, i], (lf.size,)), noise[k][0, j, lf.offset:lf.offset + lf.size])
     np.testing.assert_array_equal(R.normal(dk[3, i], (lf.size,)), draws[3, 0, lf.offset:lf.offset + lf.size])
   np.testing.assert_array_equal(jaxseed.leaf_offsets(_Net), [lf.offset for lf in model.leaves] + [model.P])
+
+
+def test_product_minibatch_shuffles_equal_the_oracle_chain():
+  """bayesnf_amd/jaxseed.py (vectorised over members, what `fit(batch_size=...)` uploads through
+  bnf_row_tables) against the oracle's member-by-member restatement of the reference's per-epoch
+  `jax.random.permutation` chain: one and two sort rounds (n^3 vs 2^32), odd n, several devices."""
+  from bayesnf_amd import jaxseed as J
+  key = np.array([7, 11], dtype=np.uint32)
+  for n, batch in ((100, 32), (101, 10), (1700, 512)):
+    ref = R.reference_map_permutations(key, 6, 3, n)                     # (members, epochs, n)
+    pk = J.map_permute_keys(key, 2, 3, 3)                                # (devices, members / device, epochs, 2)
+    keep = (n // batch) * batch
+    for d in range(2):
+      tab = J.map_row_tables(pk[d], n, batch)                            # (epochs, members / device, keep)
+      assert tab.shape == (3, 3, keep) and tab.dtype == np.int32
+      np.testing.assert_array_equal(np.transpose(tab, (1, 0, 2)), ref[3 * d:3 * d + 3, :, :keep])
+    assert sorted(ref[0, 0].tolist()) == list(range(n)) and not np.array_equal(ref[0, 0], ref[0, 1])
+  # num_splits > 1: fold_in(seed, i) first (fit_map, inference.py:432-441)
+  np.testing.assert_array_equal(J.map_row_tables(J.map_permute_keys(key, 1, 2, 2, split_index=1)[0], 50, 50)[1, 0],
+                                R.reference_map_permutations(key, 2, 2, 50, split_index=1)[0, 1])
