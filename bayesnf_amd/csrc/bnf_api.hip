@@ -725,9 +725,9 @@ static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
   static_assert(kLds <= 160 * 1024, "LDS per workgroup");
   static uint64_t attr_done = 0;
   allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L>, kLds, &attr_done);
-  const unsigned blocks = (unsigned)(pa.members * pa.panels);
   PanelArgs pa2 = pa;
   pa2.ablate = h->ablate;
+  const unsigned blocks = (unsigned)(pa.members * pa.panels);
   {
     EpiArgs tmp{};
     phase_prof_begin(h, KID_PANEL, blocks, &tmp);

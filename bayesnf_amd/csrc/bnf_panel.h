@@ -142,6 +142,9 @@ __global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ t
   }
 }
 
+#ifndef BNF_PANEL_PRIO
+#define BNF_PANEL_PRIO 0
+#endif
 #ifndef BNF_PANEL_NT
 #define BNF_PANEL_NT 1   // H1 / dZ1 / dZ0 leave with non-temporal stores (they are read once, by the weight-gradient kernels)
 #endif
@@ -177,19 +180,30 @@ __device__ __forceinline__ void lds_barrier() {
 // `side(it)` runs once per outer iteration (KS / PD of them) between MFMA groups: the caller
 // spreads the copy of the (static) panel to HBM over the contraction, so that its store issue
 // (~13 B/clk/CU, ~10k cycles per 128 KiB panel when done in one burst) hides under the MFMAs.
+// The first PD weight fragments of both streams: issued by the caller BEFORE the barrier that completes the
+// panel (the weights do not depend on it), so that their L2 latency runs under the tail of the previous
+// phase and the barrier wait instead of in front of the first MFMA.
+struct PanelRing {
+  bf16x8 fb[kPanelPD][2];
+};
+__device__ __forceinline__ void panel_prefetch(PanelRing& ring, const char* wp, int nt0, int KS, int lane) {
+  const char* w0 = wp + (size_t)nt0 * KS * 1024;   // uniform
+  const char* w1 = w0 + (size_t)KS * 1024;
+  const uint32_t loff = (uint32_t)lane * 16u;
+#pragma unroll
+  for (int p = 0; p < kPanelPD; ++p) {
+    ring.fb[p][0] = *reinterpret_cast<const bf16x8*>(w0 + p * 1024 + loff);
+    ring.fb[p][1] = *reinterpret_cast<const bf16x8*>(w1 + p * 1024 + loff);
+  }
+}
 template <int KPITCH_B, int RT, typename Side>
 __device__ __forceinline__ void panel_contract(f32x16 (&acc)[RT][2], const char* prow, const char* wp, int nt0, int KS,
-                                               int lane, Side side) {
+                                               int lane, PanelRing& ring, Side side) {
   constexpr int PD = kPanelPD;
   const char* w0 = wp + (size_t)nt0 * KS * 1024;   // uniform
   const char* w1 = w0 + (size_t)KS * 1024;
   const uint32_t loff = (uint32_t)lane * 16u;
-  bf16x8 fb[PD][2];
-#pragma unroll
-  for (int p = 0; p < PD; ++p) {
-    fb[p][0] = *reinterpret_cast<const bf16x8*>(w0 + p * 1024 + loff);
-    fb[p][1] = *reinterpret_cast<const bf16x8*>(w1 + p * 1024 + loff);
-  }
+  bf16x8 (&fb)[PD][2] = ring.fb;
   auto load_a = [&](bf16x8 (&fa)[RT], int ks) {
     const int ko = ks * 32;
 #pragma unroll
@@ -266,19 +280,32 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   constexpr int kH0Pitch = 144;             // Fp = 64: 128 bytes + 16 of padding
   const char* h0s = reinterpret_cast<const char*>(s_sc + 128);   // [BM][144 B] feature panel (H0L)
 
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid_k = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_k >> 6);
   const int rb = wave / WN, cs = wave % WN;
+  const int rbase = rb * WR, cbase = cs * 64;
+  const int KS0 = a.Fp / 16;
+#if BNF_PANEL_PRIO
+  // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per
+  // SIMD, item 4): the younger wave of every SIMD loses the issue arbitration in every phase
+  // (measured: 1313-1323 us against 1309-1315 us without, same box -- not kept, profiles/r03_panel_ab.md)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+  // (A persistent variant -- `ppw` consecutive panels per workgroup, the next panel's features requested a
+  // trip ahead -- was built and measured: 1390-1413 us for every ppw in {1, 2, 5, 10, 20} against 1355-1363 us
+  // for this one-panel-per-workgroup form on the same box: the loop costs registers (hipcc hoists the
+  // lane- and member-invariant values of all phases out of it: 145 SGPR spills, reloads inside the dZ1
+  // epilogue) and the per-panel start-up it was meant to hide is not the feature load.  profiles/r03_panel_ab.md)
+  const int tid = tid_k;
   const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
   const int e = (int)(item / (uint32_t)a.panels), pn = (int)(item % (uint32_t)a.panels);
   const int m0 = pn * BM;                   // first batch row of the panel
-  const int rbase = rb * WR, cbase = cs * 64;
-  const int KS0 = a.Fp / 16;
 
   const float* th = a.theta + (int64_t)e * a.theta_stride;
   const float* sc = a.scal + (int64_t)e * kScalStride;
   const float gamma0 = sc[0], gamma1 = sc[1], alpha = sc[BNF_MAX_LAYERS];
   const ActConst ak = act_const(alpha);
+  const float sp_in_u = (H0L && a.fbmeta) ? sc[kScalGroup + a.fb_in_group] : 1.f;   // softplus(scale of the raw-input group)
   const float inv_sw = 1.0f / sqrtf((float)a.Wt), inv_sf = 1.0f / sqrtf((float)a.F);
   float* gr = a.grad + (int64_t)e * a.grad_stride;
   // per-member scalars of the row phase and of the serial tails, fetched and transformed now (uniform):
@@ -293,8 +320,18 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   const float y_row = (tid < BM && m0 + tid < a.B) ? a.ybat[(int64_t)e * a.row_batch + m0 + tid] : 0.f;
 
   float* s_grp = s_sc + 64;                 // [BNF_MAX_GROUPS + BNF_MAX_INPUTS] sums of the fused featurisation backward
+  float* s_gfac = s_sc + 88;                // [BNF_MAX_GROUPS] sigmoid(scale_g) / softplus(scale_g) ...
+  int32_t* s_goff = reinterpret_cast<int32_t*>(s_sc + 100);   // [BNF_MAX_GROUPS] ... and the theta offset of scale_g
+  // what the serial tail of the fused featurisation backward needs from global memory is fetched NOW (two
+  // dependent loads per group) and parked in LDS after the first phase: at the end of the panel the other
+  // seven waves have nothing left to do while wave 0 finishes, so nothing there may wait for memory
+  float g_fac = 0.f; int32_t g_off = 0;
   if constexpr (H0L) {
     if (tid < BNF_MAX_GROUPS + BNF_MAX_INPUTS) s_grp[tid] = 0.f;   // (ordered by the barriers of the phases below)
+    if (a.fbmeta && tid < a.n_groups) {
+      g_off = a.fbmeta[256 + tid];
+      g_fac = sigmoidf(th[g_off]) / sc[kScalGroup + tid];
+    }
   }
   // fragment-major features: the fragment of (32-row block, k step) is 1 KiB, blocks are Fp/16 KiB apart
   const char* h0p = reinterpret_cast<const char*>(a.H0 + (int64_t)e * a.h0_batch + (int64_t)m0 * a.Fp) +
@@ -328,6 +365,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   // per wave instruction) issue underneath the VALU work of the next block instead of in a
   // 10k-cycle burst per panel (a CU issues stores at ~13 B/clk).
   auto block_to_global = [&](const LaneCtx& L, bf16_t* dst, int i) {
+    if (BNF_ABL(a, 8)) return;
     bf16_t* d = dst + (int64_t)e * a.act_batch + (int64_t)(m0 + rbase + i * 32) * W + cbase;
     const bf16_t* sp = tile + (rbase + i * 32) * kPitchE + cbase;
     u32x4 v[4];
@@ -350,7 +388,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   if constexpr (H0L) {   // feature panel -> LDS (row-major source, 16-byte chunks, 8 per row)
     const bf16_t* src = a.H0rm + (int64_t)e * a.h0_batch + (int64_t)m0 * 64;
 #pragma unroll
-    for (int c = 0; c < (BM * 8) / 512; ++c) {
+    for (int c = 0; c < (BNF_ABL(a, 32) ? 0 : (BM * 8) / 512); ++c) {
       const int q = tid + c * 512;
       *reinterpret_cast<u32x4*>(const_cast<char*>(h0s) + (q >> 3) * kH0Pitch + (q & 7) * 16) =
           *reinterpret_cast<const u32x4*>(src + (int64_t)(q >> 3) * 64 + (q & 7) * 8);
@@ -391,6 +429,11 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
 #pragma unroll
     for (int r = 0; r < 16; ++r) a0[r] = 0.f;
     if constexpr (H0L) {
+      if (BNF_ABL(a, 16)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a0[r] = 0.25f;
+        return;
+      }
       const char* ap = h0s + (rbase + i * 32 + L.frow) * kH0Pitch + L.kg * 16;
       bf16x8 fa[4];
 #pragma unroll
@@ -421,48 +464,68 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     const float gs = gamma0 * inv_sf * kLog2e;     // t = A0 log2(e): the activation core works on it (act_core2)
     float gb[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) gb[j] = gamma0 * kLog2e * th[a.off_bias0 + cbase + j * 32 + frow];
-    l0_weights(L);
+    for (int j = 0; j < 2; ++j) gb[j] = BNF_ABL(a, 64) ? 0.1f : gamma0 * kLog2e * th[a.off_bias0 + cbase + j * 32 + frow];
+    if (!BNF_ABL(a, 64)) l0_weights(L);
     if constexpr (H0L) lds_barrier();     // the staged feature panel is complete
-#pragma unroll 1
-    for (int i = 0; i < RT; ++i) {
-      f32x16 a0b[2];
-      if constexpr (H0L) {   // both tiles' MFMAs first: the second chain runs under the first tile's epilogue
-        l0_tile(L, a0b[0], i, 0);
-        l0_tile(L, a0b[1], i, 1);
-      }
+    // epilogue of one 32 x 32 tile: t = A0 log2(e) -> H1 = act(A0) -> LDS panel
+    auto l0_epilogue = [&](const f32x16& a0, int i, int j) {
+      const int lc = cbase + j * 32 + frow;
+      const float gbj = j ? gb[1] : gb[0];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x16& a0 = a0b[j];
-        if constexpr (!H0L) {
+      for (int rg = 0; rg < 4; ++rg) {
+        const int lr = rbase + i * 32 + 8 * rg + 4 * kg;
+#pragma unroll
+        for (int q = 0; q < 4; q += 2) {
+          const f32x2 tv = f32x2{a0[rg * 4 + q], a0[rg * 4 + q + 1]} * gs + gbj;
+          f32x2 h = tv;
+          if (!BNF_ABL(a, 2)) {
+            const ActCore2 c = act_core2(tv);
+            const f32x2 s = kLn2 * c.mxt + c.dl;
+            h = ak.c1 * c.r + (ak.alpha * s + ak.c0);
+          }
+          if (!BNF_ABL(a, 4)) store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, h.x, h.y);
+        }
+      }
+    };
+    if constexpr (H0L) {
+      // software pipeline over the 2 RT tiles: the MFMA chain of tile t + 1 is issued before the epilogue of
+      // tile t, and the copy of row block i - 1 to HBM leaves in the middle of row block i -- its LDS writes
+      // landed long ago, so the copy's lgkmcnt wait costs nothing (right behind its own block's last store it
+      // stalled both waves of a SIMD at the same point)
+      f32x16 a0b[2];
+      l0_tile(L, a0b[0], 0, 0);
+#pragma unroll 1
+      for (int i = 0; i < RT; ++i) {
+        l0_tile(L, a0b[1], i, 1);
+        l0_epilogue(a0b[0], i, 0);
+        if (i > 0) block_to_global(L, a.H1, i - 1);
+        if (i + 1 < RT) l0_tile(L, a0b[0], i + 1, 0);
+        l0_epilogue(a0b[1], i, 1);
+      }
+      block_to_global(L, a.H1, RT - 1);
+    } else {
+#pragma unroll 1
+      for (int i = 0; i < RT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 a0;
           if (!BNF_ABL(a, 1)) l0_tile(L, a0, i, j);
           else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) a0[r] = 0.25f;
           }
+          l0_epilogue(a0, i, j);
         }
-        const int lc = cbase + j * 32 + frow;
-        const float gbj = j ? gb[1] : gb[0];
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int lr = rbase + i * 32 + 8 * rg + 4 * kg;
-#pragma unroll
-          for (int q = 0; q < 4; q += 2) {
-            const f32x2 tv = f32x2{a0[rg * 4 + q], a0[rg * 4 + q + 1]} * gs + gbj;
-            f32x2 h = tv;
-            if (!BNF_ABL(a, 2)) {
-              const ActCore2 c = act_core2(tv);
-              const f32x2 s = kLn2 * c.mxt + c.dl;
-              h = ak.c1 * c.r + (ak.alpha * s + ak.c0);
-            }
-            if (!BNF_ABL(a, 4)) store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, h.x, h.y);
-          }
-        }
+        block_to_global(L, a.H1, i);
       }
-      block_to_global(L, a.H1, i);
     }
   }
   BNF_MARK(a, 1);
+  if constexpr (H0L) {
+    if (a.fbmeta && tid < a.n_groups) { s_gfac[tid] = g_fac; s_goff[tid] = g_off; }
+  }
+  PanelRing ring;
+  panel_prefetch(ring, wf1, 2 * cs, KS1, opaque_lane(tid) & 63);   // in flight across the barrier
   lds_barrier();
   BNF_MARK(a, 2);
 
@@ -470,7 +533,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   zero_acc();
   {
     const LaneCtx L = lane_ctx();
-    panel_contract<kPitchB, RT>(acc, L.prow, wf1, 2 * cs, KS1, L.lane, [](int) {});
+    panel_contract<kPitchB, RT>(acc, L.prow, wf1, 2 * cs, KS1, L.lane, ring, [](int) {});
   }
   BNF_MARK(a, 3);
   lds_barrier();     // every wave is done reading H1: the panel doubles as row-dot scratch below
@@ -636,8 +699,10 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
         asm volatile("" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sg[0]), "+v"(sg[1]), "+v"(cp[0]), "+v"(cp[1]),
                      "+v"(ck[0]), "+v"(ck[1]));
         __builtin_amdgcn_sched_barrier(0);
-        if (rg == 3) block_to_global(L, a.dZ1, i);
+        if (rg == 1 && i > 0) block_to_global(L, a.dZ1, i - 1);   // (deferred: see the layer-0 forward)
       }
+    block_to_global(L, a.dZ1, RT - 1);
+    panel_prefetch(ring, wb1, 2 * cs, KS1, lane);   // the accumulators are dead: weights of dH1 = dZ1 K1^T on their way
     float wsa = kvn[0] * (sa[0].x + sa[0].y) + kvn[1] * (sa[1].x + sa[1].y);
     float wsg = (kLn2 / gamma1) * ((sg[0].x + sg[0].y) + (sg[1].x + sg[1].y));
 #pragma unroll
@@ -689,7 +754,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   zero_acc();
   {
     const LaneCtx L = lane_ctx();
-    panel_contract<kPitchB, RT>(acc, L.prow, wb1, 2 * cs, KS1, L.lane, [](int) {});
+    panel_contract<kPitchB, RT>(acc, L.prow, wb1, 2 * cs, KS1, L.lane, ring, [](int) {});
   }
   BNF_MARK(a, 8);
   const LaneCtx L2 = lane_ctx();
@@ -752,9 +817,10 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
           asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(sacc), "+v"(cs2[0]), "+v"(cs2[1]));
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (j == 0 && i > 0) block_to_global(L, a.dZ0, i - 1);   // (deferred: see the layer-0 forward)
       }
-      block_to_global(L, a.dZ0, i);
     }
+    block_to_global(L, a.dZ0, RT - 1);
     BNF_MARK(a, 9);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -769,6 +835,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       s_sc[33 + wave * 2] = sg;
     }
   }
+  int4 md_red = {0, 0, 0, 0};   // fused featurisation backward: column table entry of the final reduction (wave 0)
   // =============================== dH0^T = (dZ0 K0^T / sqrt F)^T ==============================
   // Output tiles of 32 x 32 over the waves.  All W/16 weight fragments of a tile are requested
   // at once -- those of the wave's first tile BEFORE the barrier that completes the dZ0 panel --
@@ -785,9 +852,36 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
 #pragma unroll
       for (int u = 0; u < KS1; ++u) fb[u] = *reinterpret_cast<const bf16x8*>(bp + (size_t)u * 1024);
     };
-    if (wave < n_t) load_b(wave);
+    load_b(wave);   // (n_t >= 8: BM >= 128 rows and Fp >= 64 -- every wave has a first tile)
+    // fused featurisation backward: the column table entries of this wave's first tile and of the final
+    // reduction (wave 0: one column per lane), in flight across the barrier like the weights
+    int4 md_first = {0, 0, 0, 0};
+    if constexpr (H0L) {
+      if (a.fbmeta) {
+        md_first = *reinterpret_cast<const int4*>(a.fbmeta + 4 * ((wave % ct) * 32 + frow));
+        if (wave == 0) md_red = *reinterpret_cast<const int4*>(a.fbmeta + 4 * lane);
+      }
+    }
     BNF_MARK(a, 10);
     lds_barrier();
+    // the column sums and scalars of the dZ0 epilogue are complete: their atomics leave now, under the
+    // contraction below, instead of in a serial tail after it
+    for (int c = tid; c < W; c += 512) {
+      float b = 0.f;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) b += s_col[r * W + c];
+      atomicAdd(&gr[a.off_bias0 + c], b);
+    }
+    if (tid == 0) {
+      float ta = ta1, tg = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 8; ++w2) {
+        ta += s_sc[32 + w2 * 2];
+        tg += s_sc[33 + w2 * 2];
+      }
+      atomicAdd(&gr[a.off_law], alpha * (1.f - alpha) * ta);
+      atomicAdd(&gr[a.off_ls0], dgam0 * tg);
+    }
     for (int t = wave; t < n_t; t += 8) {
       const int mi = t / ct, ni = t - mi * ct;
       if (t != wave) load_b(t);
@@ -810,7 +904,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
           //   d lsa_d (Fourier cos / sin column k)   ~ -+ 2 pi 2^k sum_r dH0[r][f] H0[r][partner] u_d[r],
           //                                            u_d = H0[r][input column d] / softplus(scale_in)
           const int f = ni * 32 + frow;
-          const int4 md = *reinterpret_cast<const int4*>(a.fbmeta + 4 * f);
+          const int4 md = (t == wave) ? md_first : *reinterpret_cast<const int4*>(a.fbmeta + 4 * f);
           const char* hc = h0s + (mi * 32 + 4 * kg) * kH0Pitch;
           const int o_f = f * 2, o_p = (md.y & 0xff) * 2, o_u = ((md.y >> 8) & 0xff) * 2;
           float s1 = 0.f, s2 = 0.f;
@@ -849,11 +943,11 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       lds_barrier();
       if (wave == 0) {
         const int f = opaque_lane(tid) & 63;
-        const int4 md = *reinterpret_cast<const int4*>(a.fbmeta + 4 * f);
+        const int4 md = md_red;
         const float t1 = (s_col[W + f] + s_col[W + 64 + f]) + (s_col[W + 128 + f] + s_col[W + 192 + f]);
         const float t2 = (s_col[W + 256 + f] + s_col[W + 320 + f]) + (s_col[W + 384 + f] + s_col[W + 448 + f]);
         const int kind = md.x & 0xff, g = (md.x >> 8) & 0xff, d1 = (md.x >> 16) & 0xff, d2 = (md.x >> 24) & 0xff;
-        const float sp_in = sc[kScalGroup + a.fb_in_group];
+        const float sp_in = sp_in_u;
         if (g < BNF_MAX_GROUPS) atomicAdd(&s_grp[g], t1);                       // LDS atomics
         float v = 0.f;
         if (kind == kFbInput || kind == kFbInter) v = t1;
@@ -863,8 +957,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS atomics have landed
         __builtin_amdgcn_wave_barrier();
         if (f < a.n_groups) {
-          const int off = a.fbmeta[256 + f];
-          atomicAdd(&gr[off], sigmoidf(th[off]) / sc[kScalGroup + f] * s_grp[f]);
+          atomicAdd(&gr[s_goff[f]], s_gfac[f] * s_grp[f]);
         } else if (f >= BNF_MAX_GROUPS && f < BNF_MAX_GROUPS + a.n_inputs) {
           atomicAdd(&gr[a.off_lsa + f - BNF_MAX_GROUPS], -s_grp[f]);
         }
@@ -872,22 +965,6 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     }
   }
   BNF_MARK(a, 12);
-  for (int c = tid; c < W; c += 512) {
-    float b = 0.f;
-#pragma unroll
-    for (int r = 0; r < RB; ++r) b += s_col[r * W + c];
-    atomicAdd(&gr[a.off_bias0 + c], b);
-  }
-  if (tid == 0) {
-    float ta = ta1, tg = 0.f;
-#pragma unroll
-    for (int w2 = 0; w2 < 8; ++w2) {
-      ta += s_sc[32 + w2 * 2];
-      tg += s_sc[33 + w2 * 2];
-    }
-    atomicAdd(&gr[a.off_law], alpha * (1.f - alpha) * ta);
-    atomicAdd(&gr[a.off_ls0], dgam0 * tg);
-  }
   BNF_MARK(a, 13);
 }
 
