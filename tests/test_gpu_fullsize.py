@@ -107,12 +107,17 @@ def test_c2_bf16_predictive_rmse_within_2pct_of_fp32():
   # order + 200 Adam steps); bf16: final loss <= 0.1 %, RMSE of the ensemble-mean prediction <= 0.7 %,
   # mean over members <= 2.3 %, while a single member (the same one or two of the eight) lands 5-17 %
   # high in one run out of twelve.  Gates: loss 1 %, ensemble RMSE 2 % (the SURVEY 8(d) gate), median
-  # member 3 %, mean over members 5 %, at most one member beyond 8 % and none beyond 30 %.
+  # member 3 %, mean over members 5 %, at most one member beyond 8 % and none beyond 20 %.
+  # Round 3 (scripts/bf16_outlier_probe.py, profiles/r03_bf16_outliers.md; 192 bf16 and 160 fp32 fits): the
+  # spread is the problem's, not the kernels' -- fp32 fits from identical initial parameters already differ by
+  # 1-4 % in the same few members after 200 steps, the objective of an "outlier" member tracks the reference's
+  # to 5e-4 at every checkpoint, and the first leaves to wander are the input-scale leaves; bf16 widens the
+  # spread 2-3x: 20 of 192 runs with a member beyond 5 %, 2 beyond 8 %, largest 13.7 %.
   np.testing.assert_allclose(rmse['bf16'][1], rmse['fp32'][1], rtol=2e-2)
   np.testing.assert_allclose(np.median(rmse['bf16'][0]), np.median(rmse['fp32'][0]), rtol=3e-2)
   np.testing.assert_allclose(rmse['bf16'][0].mean(), rmse['fp32'][0].mean(), rtol=5e-2)
   dev = np.abs(rmse['bf16'][0] / rmse['fp32'][0] - 1.0)
-  assert np.sum(dev > 0.08) <= 1 and dev.max() < 0.30, dev
+  assert np.sum(dev > 0.08) <= 1 and dev.max() < 0.20, dev
 
 
 @pytest.mark.parametrize('width,depth', [(512, 4), (768, 2), (1024, 2)])

@@ -431,3 +431,27 @@ def test_graph_replayed_training_equals_eager(monkeypatch):
     eng.close()
   np.testing.assert_allclose(out['1'][0], out['0'][0], rtol=1e-5)
   assert util.rel_err(out['1'][1], out['0'][1]) < 1e-5
+
+
+@pytest.mark.parametrize('dtype,pipeline,width,depth', [('fp32', 'layers', 192, 3), ('fp32', 'auto', 256, 3),
+                                                       ('bf16', 'auto', 256, 3), ('bf16', 'panel', 512, 2)])
+def test_results_do_not_depend_on_stale_lds(dtype, pipeline, width, depth):
+  """LDS is not cleared between kernels: a kernel that read LDS it has not written would see the previous
+  kernel's leftovers, i.e. results that depend on what ran before (one candidate for the unexplained
+  one-off failure of test_forward_and_grad_fp32 in round 2).  The same loss + gradient evaluation with every
+  CU's LDS filled with quiet NaNs, with zeros and with a bit pattern right before it: identical up to the
+  order of the f32 atomics, and finite."""
+  n_rows, E = 257, 3
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth)
+  theta = util.random_theta(model, E, scale=0.3)
+  eng = _engine(net, X, y, members=E, compute_dtype=dtype, pipeline=pipeline)
+  eng.set_params(theta)
+  loss0, g0 = eng.debug_loss_and_grad()
+  scale = np.abs(g0).max(axis=1, keepdims=True)
+  for pattern in (0x7fc00000, 0x00000000, 0x5a5a5a5a):
+    eng.debug_poison_lds(pattern)
+    loss, g = eng.debug_loss_and_grad()
+    assert np.all(np.isfinite(loss)) and np.all(np.isfinite(g)), hex(pattern)
+    np.testing.assert_allclose(loss, loss0, rtol=1e-5)
+    assert (np.abs(g - g0) / scale).max() < 1e-4, hex(pattern)
+  eng.close()
