@@ -935,7 +935,7 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   a.bc1 = (float)(1.0 - std::pow(0.9, (double)t));
   a.bc2 = (float)(1.0 - std::pow(0.999, (double)t));
   a.kl_weight = kl; a.loss = loss; a.loss_stride = loss_stride; a.apply = apply ? 1 : 0;
-  a.gmu_out = gmu_out; a.grho_out = grho_out; a.ext_eps = h->ext_eps; a.jn = jn;
+  a.gmu_out = gmu_out; a.grho_out = grho_out; a.ext_eps = h->ext_eps; a.jn = jn; a.z = h->theta_c;
   {
     LaunchScope ls(h, KID_VIADAM);
     dim3 grid(cdiv(h->P, 256), (unsigned)E);

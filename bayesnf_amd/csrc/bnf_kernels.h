@@ -783,6 +783,8 @@ struct ViAdamArgs {
   float* gmu_out; float* grho_out;  // debug: (members, P) each
   const float* ext_eps;             // bnf_debug_vi_noise: (members, S, P) standard normals instead of the generator's
   JaxNoise jn;                      // the reference's stream when jn.keys != null
+  const float* z;                   // (members*S, P) the samples k_vi_sample wrote for this step (theta_c): the noise is
+                                    // recovered from them as (z - mu) / sigma instead of being generated a second time
 };
 
 __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
@@ -796,27 +798,25 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
     const float sig = vi_sigma(rho);
     const float loc = (p == a.off_shape) ? -1.5f : 0.f;
     float gmu = 0.f, grho = 0.f, e2 = 0.f, lpr = 0.f;
+    // The step's noise is NOT generated a second time (Philox + Box-Muller, or threefry + erfinv for the
+    // reference's stream: that was most of this kernel's 0.40 ms at C3/8, VALU-bound): k_vi_sample left
+    // z_s = mu + sigma eps_s in theta_c and nothing has written it since, so eps_s = (z_s - mu) / sigma --
+    // exact up to the rounding of z_s (|z| 6e-8 / sigma absolute on a unit normal).
+    const float inv_sig = 1.0f / sig;
     for (int s0 = 0; s0 < a.S; s0 += 4) {
-      Normal4 n4 = vi_eps4(a.seed, (uint32_t)(a.member_offset + e), (uint32_t)(s0 >> 2), (uint32_t)p,
-                           a.step, STREAM_VI_EPS);
-      if (a.ext_eps) {
+      float gl[4], zs[4];   // the four likelihood gradients and samples in flight together
 #pragma unroll
-        for (int k = 0; k < 4; ++k) n4.v[k] = a.ext_eps[((int64_t)e * a.S + min(s0 + k, a.S - 1)) * a.P + p];
-      } else if (a.jn.keys) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (s0 + k < a.S) n4.v[k] = jax_normal(a.jn, e, s0 + k, p);
+      for (int k = 0; k < 4; ++k) {
+        const int64_t gi = ((int64_t)e * a.S + min(s0 + k, a.S - 1)) * a.P + p;
+        gl[k] = a.grad[gi];
+        zs[k] = a.z[gi];
       }
-      float gl[4];   // the four likelihood gradients in flight together
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        gl[k] = a.grad[((int64_t)e * a.S + min(s0 + k, a.S - 1)) * a.P + p];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int s = s0 + k;
         if (s >= a.S) break;
-        const float eps = n4.v[k];
-        const float z = mu + sig * eps - loc;
+        const float eps = (zs[k] - mu) * inv_sig;
+        const float z = zs[k] - loc;
         const int64_t gi = ((int64_t)e * a.S + s) * a.P + p;
         // Logistic(loc, 1) prior: d(-log p)/dz = tanh(z/2), log p = -z - 2 softplus(-z);
         // both from u = exp(-|z|)

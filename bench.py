@@ -57,6 +57,39 @@ KERNEL_SYMBOL = {   # gemm_nt<T, epilogue, tag, wave rows, wave cols>
 }
 
 
+def sq_counters(kernel, dtype, members):
+  """Per-launch SQ counters of `kernel` from the committed rocprofv3 --pmc passes of this same command
+  (profiles/sq_counters.json, made by scripts/gpu_counters.sh + scripts/counter_summary.py), or None."""
+  path = os.path.join(ROOT, 'profiles', 'sq_counters.json')
+  if members != 64 or kernel not in KERNEL_SYMBOL or not os.path.exists(path):
+    return None
+  sym = KERNEL_SYMBOL[kernel].format(T='bnf::bf16_t' if dtype == 'bf16' else 'float')
+  with open(path) as f:
+    table = json.load(f)
+  for name, rec in table.items():
+    if name.startswith(sym.split('(')[0]):
+      return rec
+  return None
+
+
+def issue_floors(ctr, launch_us, n_simd=1024):
+  """How far the two issue-bound pipes of the dominant kernel are from saturation, from its SQ counters:
+  every SIMD issues at most one VALU-class instruction per 4 cycles (MI355X_MICROARCH.md: 8 issue slots per
+  32-cycle MFMA), a 32x32x16 bf16 MFMA holds the matrix pipe for 32 cycles.  Clock = GRBM_GUI_ACTIVE over the
+  kernel's duration in the counter pass when both are there, else 2.0 GHz (what this kernel sustains)."""
+  if not ctr or 'SQ_INSTS_VALU' not in ctr:
+    return None
+  ghz = 2.0
+  out = {'valu_insts_per_launch': ctr['SQ_INSTS_VALU'], 'mfma_insts_per_launch': ctr.get('SQ_INSTS_MFMA'),
+         'assumed_clock_ghz': ghz,
+         'valu_issue_floor_us': ctr['SQ_INSTS_VALU'] / n_simd * 4.0 / (ghz * 1e3)}
+  if ctr.get('SQ_INSTS_MFMA'):
+    out['mfma_pipe_floor_us'] = ctr['SQ_INSTS_MFMA'] / n_simd * 32.0 / (ghz * 1e3)
+    out['valu_per_mfma'] = ctr['SQ_INSTS_VALU'] / ctr['SQ_INSTS_MFMA']
+  out['valu_issue_frac_of_launch'] = out['valu_issue_floor_us'] / launch_us
+  return out
+
+
 def pmc_traffic(kernel, dtype, members):
   """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this
   same command (profiles/pmc_traffic.json, made by scripts/gpu_pmc.sh; FETCH_SIZE and
@@ -105,9 +138,52 @@ def _cpu_pool_init(barrier):
   _CPU_BARRIER = barrier
 
 
+def _numa_cpu_lists():
+  """[[cpu ids of node 0], [node 1], ...] from sysfs; one list with every allowed cpu when unreadable."""
+  allowed = sorted(os.sched_getaffinity(0))
+  nodes = []
+  try:
+    for d in sorted(os.listdir('/sys/devices/system/node')):
+      if not d.startswith('node') or not d[4:].isdigit():
+        continue
+      cpus = []
+      for part in open(f'/sys/devices/system/node/{d}/cpulist').read().strip().split(','):
+        lo, _, hi = part.partition('-')
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+      cpus = [c for c in cpus if c in allowed]
+      if cpus:
+        nodes.append(cpus)
+  except (OSError, ValueError):
+    nodes = []
+  return nodes or [allowed]
+
+
+def _pin_worker(k, nt, n_workers):
+  """Worker k of the side-by-side layout (n_workers > 1) gets `nt` cpus of ONE NUMA node, strided over the
+  node's physical cores so that every worker still reaches every CCD's L3 and fabric link (round 2's unpinned
+  8 x 16 layout was slower than one 16-thread process: threads migrated and pages sat on the other socket;
+  pinning each worker to CONSECUTIVE cores was worse still -- 4 x 32: 8.2 against 23.9 member-steps/s for one
+  unpinned 32-thread process -- because two CCDs' links then carry a worker's whole stream).  The
+  single-process sweep stays unpinned.  No-op where affinity cannot be set."""
+  if n_workers <= 1:
+    return
+  try:
+    nodes = _numa_cpu_lists()
+    # sysfs lists a node's physical cores first and their SMT siblings second: keep the first half when the
+    # node has at least twice the cpus the workers on it need
+    per_node = -(-n_workers // len(nodes))
+    phys = [c[:len(c) // 2] if len(c) // 2 >= per_node * nt else c for c in nodes]
+    n, j = k % len(nodes), k // len(nodes)
+    mine = phys[n][j::per_node][:nt]
+    if len(mine) == nt:
+      os.sched_setaffinity(0, set(mine))
+  except (OSError, AttributeError, ZeroDivisionError):
+    pass
+
+
 def _cpu_worker(args):
   """One worker of the CPU baseline: `members` members x `steps` timed full-batch steps on `nt` threads."""
-  X, y, input_scales, members, steps, nt, seed = args
+  X, y, input_scales, members, steps, nt, seed, n_workers = args
   import ctypes
   import torch
   from oracle import bnf_oracle as O
@@ -118,6 +194,7 @@ def _cpu_worker(args):
     libc.mallopt(-1, 1 << 30)   # M_TRIM_THRESHOLD
   except OSError:
     pass
+  _pin_worker(seed, nt, n_workers)
   torch.set_num_threads(nt)
   model = O.Model(input_scales=input_scales, **MODEL_KW)
   rng = np.random.default_rng(seed)
@@ -150,7 +227,7 @@ def cpu_baseline(X, y, input_scales, members=8, steps=3):
   tried = {}
   with ctx.Pool(1) as pool:
     for nt in sorted({n_max, max(1, n_max // 2), max(1, n_max // 4), min(n_max, 16), min(n_max, 8)}, reverse=True):
-      t0, t1 = pool.map_async(_cpu_worker, [(X, y, input_scales, members, steps, nt, 0)]).get(timeout=900)[0]
+      t0, t1 = pool.map_async(_cpu_worker, [(X, y, input_scales, members, steps, nt, 0, 1)]).get(timeout=900)[0]
       tried[nt] = round(members * steps / (t1 - t0), 3)
   nt = max(tried, key=tried.get)
   procs = max(1, n_max // nt)
@@ -158,7 +235,7 @@ def cpu_baseline(X, y, input_scales, members=8, steps=3):
   if procs > 1:
     try:   # (a worker that dies must not hang the bench: bounded waits, and the single-process figure stands)
       with ctx.Pool(procs, initializer=_cpu_pool_init, initargs=(ctx.Barrier(procs),)) as pool:
-        spans = pool.map_async(_cpu_worker, [(X, y, input_scales, members, steps, nt, k) for k in range(procs)],
+        spans = pool.map_async(_cpu_worker, [(X, y, input_scales, members, steps, nt, k, procs) for k in range(procs)],
                                chunksize=1).get(timeout=900)
       span = max(t for _, t in spans) - min(t for t, _ in spans)
       v = procs * members * steps / span
@@ -489,7 +566,8 @@ def main(argv=None):
                           'unit': 'TFLOP/s', 'frac': achieved / peak,
                           'traffic': pmc_traffic(dominant, args.dtype, E),
                           'avg_launch_us': d['avg_ms'] * 1e3, 'launches': d['calls'],
-                          'flops_per_launch': d['flops']}
+                          'flops_per_launch': d['flops'],
+                          'issue_floors': issue_floors(sq_counters(dominant, args.dtype, E), d['avg_ms'] * 1e3)}
       if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(X, y, input_scales)
     print(json.dumps(line), flush=True)

@@ -28,5 +28,20 @@ def main(out_dir):
     print(f'| {c} | ' + ' | '.join(cells) + ' |')
 
 
+def dump_json(out_dir, path):
+  """per-kernel per-launch averages as JSON (profiles/sq_counters.json, read by bench.py's roofline block)"""
+  import json
+  vals = defaultdict(lambda: defaultdict(list))
+  for f in glob.glob(os.path.join(out_dir, 'pass*', '**', '*counter_collection*.csv'), recursive=True):
+    with open(f) as fh:
+      for row in csv.DictReader(fh):
+        vals[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
+  out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in vals.items() if k.startswith(('void bnf', 'bnf::'))}
+  with open(path, 'w') as fh:
+    json.dump(out, fh, indent=1)
+
+
 if __name__ == '__main__':
   main(sys.argv[1])
+  if len(sys.argv) > 2:
+    dump_json(sys.argv[1], sys.argv[2])
