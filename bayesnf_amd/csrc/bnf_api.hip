@@ -132,6 +132,7 @@ struct bnf_handle {
   float* vacc = nullptr; float* dv = nullptr;   // output-layer dot accumulator, d loss / d v
   bool panel = false;         // row-panel forward + backward kernel (bnf_panel.h): bf16, depth 2, W = 256 / 512
   void* Wf[BNF_MAX_LAYERS]; void* Wb[BNF_MAX_LAYERS];   // fragment-major packed weights
+  void* park[BNF_MAX_LAYERS];                            // row-panel pipeline, depth > 2: parked pre-activations of the middle layers
     unsigned long long* prof_buf = nullptr;   // phase clocks (ABLATE builds)
   double prof_gap[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   double prof_blocks = 0;
@@ -208,6 +209,7 @@ static size_t carve(bnf_handle* h, char* base) {
     const int64_t npad = (l == 0) ? Fp : W;
     h->Wf[l] = h->panel ? take((size_t)Ev * npad * W * es) : nullptr;
     h->Wb[l] = h->panel ? take((size_t)Ev * npad * W * es) : nullptr;
+    h->park[l] = (h->panel && !fo && l >= 1 && l < h->L - 1) ? take((size_t)Ev * Bp * W * es) : nullptr;
   }
   h->dH0 = fo ? nullptr : (float*)take((size_t)Ev * Fp * Bp * 4);            // dH0^T (Fp, Bp)
   h->out = (float*)take((size_t)Ev * Bp * 4);
@@ -698,10 +700,10 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
 template <typename T>
 static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
   LaunchScope ls(h, KID_PACK);
-  PackJobs jb{};   // (the row-panel pipeline is a two-hidden-layer pipeline: bnf_create)
+  PackJobs jb{};
   jb.n_layers = h->L; jb.W = h->W;
   int tiles = 0;
-  for (int l = 0; l < h->L && l < 2; ++l) {
+  for (int l = 0; l < h->L; ++l) {
     jb.off_kernel[l] = h->nd.off_kernel[l];
     jb.n_in[l] = (l == 0) ? h->F : h->W;
     jb.n_pad[l] = (l == 0) ? h->Fp : h->W;   // multiples of 64
@@ -709,8 +711,7 @@ static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
     tiles += (jb.n_pad[l] / 64) * (h->W / 64);
     jb.wf[l] = h->Wf[l]; jb.wb[l] = h->Wb[l]; jb.batch[l] = h->pack_batch[l];
   }
-  jb.tile0[2] = tiles;
-  if (h->L == 1) jb.tile0[1] = tiles;
+  jb.tile0[h->L] = tiles;
   hipLaunchKernelGGL((k_pack_layers<T>), dim3((unsigned)tiles, (unsigned)nmem), dim3(256), 0, h->stream,
                      theta, (int64_t)h->Pf, jb, h->nd, h->scal);
 }
@@ -758,15 +759,19 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   PanelArgs pa{};
   pa.F = h->F; pa.Fp = h->Fp; pa.B = (int32_t)h->B; pa.members = nmem; pa.Wt = h->Wt;
   pa.theta = theta; pa.theta_stride = h->Pf; pa.scal = h->scal;
-  pa.off_bias0 = h->nd.off_bias[0]; pa.off_bias1 = h->nd.off_bias[1]; pa.off_bias_out = h->nd.off_bias[2];
-  pa.off_ko = h->nd.off_kernel[2]; pa.off_ls0 = h->nd.off_ls[0]; pa.off_ls1 = h->nd.off_ls[1];
+  const int L = h->L;
+  pa.n_layers = L;
+  for (int l = 0; l < L; ++l) {
+    pa.off_bias[l] = h->nd.off_bias[l]; pa.off_ls[l] = h->nd.off_ls[l];
+    pa.Wf[l] = (const bf16_t*)h->Wf[l]; pa.Wb[l] = (const bf16_t*)h->Wb[l];
+    pa.Hout[l] = (bf16_t*)h->H[l]; pa.dZ[l] = (bf16_t*)h->dZ[l]; pa.park[l] = (bf16_t*)h->park[l];
+  }
+  pa.off_bias_out = h->nd.off_bias[L]; pa.off_ko = h->nd.off_kernel[L];
   pa.off_os = h->nd.off_os; pa.off_law = h->nd.off_law; pa.off_lns = h->nd.off_lns;
   pa.off_shape = h->nd.off_shape; pa.off_infl = h->nd.off_infl; pa.obs = h->nd.obs;
   pa.H0 = (const bf16_t*)h->H0t; pa.H0rm = (const bf16_t*)h->H0; pa.h0_batch = Bp * h->Fp;   // fragment-major / row-major
-  pa.Wf0 = (const bf16_t*)h->Wf[0]; pa.Wf1 = (const bf16_t*)h->Wf[1];
-  pa.Wb0 = (const bf16_t*)h->Wb[0]; pa.Wb1 = (const bf16_t*)h->Wb[1];
   pa.w0_batch = h->pack_batch[0]; pa.w1_batch = h->pack_batch[1];
-  pa.H1 = (bf16_t*)h->H[0]; pa.dZ1 = (bf16_t*)h->dZ[1]; pa.dZ0 = (bf16_t*)h->dZ[0]; pa.act_batch = Bp * h->W;
+  pa.act_batch = Bp * h->W;
   pa.dH0t = h->dH0; pa.dh0_batch = (int64_t)h->Fp * Bp; pa.ldt = (int32_t)Bp;
   pa.ybat = h->ybat; pa.row_batch = Bp; pa.out = h->out; pa.out_batch = Bp;
   pa.grad = h->gradf; pa.grad_stride = h->Pf;
@@ -1096,10 +1101,12 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
       return fail(BNF_ERR_INVALID, "pipeline %d (0 auto, 1 layers, 3 panel)", want);
     }
     // pipeline 3: row-panel forward + backward kernel (bf16, two hidden layers, width 256 / 512)
-    const bool can_panel = !cfg->forward_only && h->bf16 && h->L == 2 && (h->W == 256 || h->W == 512) && h->Fp <= 128;
+    // pipeline 3: row-panel forward + backward kernel (bf16, >= 2 hidden layers, width 256 / 512): rows stay in LDS /
+    // registers through ALL layers; the middle layers of deeper networks park their pre-activations in HBM
+    const bool can_panel = !cfg->forward_only && h->bf16 && h->L >= 2 && (h->W == 256 || h->W == 512) && h->Fp <= 128;
     if (want == 3 && !can_panel) {
       delete h;
-      return fail(BNF_ERR_INVALID, "panel pipeline needs a bf16 training handle with depth 2, width 256/512 and <= 128 features");
+      return fail(BNF_ERR_INVALID, "panel pipeline needs a bf16 training handle with depth >= 2, width 256/512 and <= 128 features");
     }
     h->panel = can_panel && (want == 3 || want == 0);   // the default where it applies (C2: 2.71 -> 2.27 ms/step)
     if (h->panel) h->Bp = align_up(h->B, 256);
@@ -1790,8 +1797,8 @@ double bnf_kernel_flops(const bnf_handle* h, const char* name) {
     return 2.0 * Ev * B * W * W;
   if (!strcmp(name, "gemm_fwd_last"))   // last hidden layer + output-layer dot
     return 2.0 * Ev * B * (h->L > 1 ? W : F) * W + 2.0 * Ev * B * W;
-  if (!strcmp(name, "panel_fwd_bwd"))  // forward + backward-data contractions of both layers + output layer
-    return 4.0 * Ev * B * (F * W + W * W) + 2.0 * Ev * B * W;
+  if (!strcmp(name, "panel_fwd_bwd"))  // forward + backward-data contractions of every layer + output layer
+    return 4.0 * Ev * B * (F * W + (h->L - 1) * W * W) + 2.0 * Ev * B * W;
   return 0.0;
 }
 

@@ -42,19 +42,21 @@ struct PanelArgs {
   const float* theta;
   int64_t theta_stride;
   const float* scal;              // k_member_scalars table (kScalStride per member)
-  int32_t off_bias0, off_bias1, off_bias_out, off_ko, off_ls0, off_ls1, off_os, off_law;
+  int32_t n_layers;               // hidden layers L >= 2: layer 0 (features -> W), middle layers 1 .. L-2, last layer L-1
+  int32_t off_bias[BNF_MAX_LAYERS], off_ls[BNF_MAX_LAYERS];   // Dense_l/bias, inv_sp_layer_scale_l of the hidden layers
+  int32_t off_bias_out, off_ko, off_os, off_law;
   int32_t off_lns, off_shape, off_infl, obs;
   const bf16_t* H0;               // (members, Bp x Fp) features in A-fragment-major order (k_featurize H0f), rows >= B zero
   const bf16_t* H0rm;             // the same, row-major (Bp, Fp): staged into LDS by the H0L variant
   int64_t h0_batch;
-  const bf16_t* Wf0;              // fragment-major Bt[n][k] = K0[k][n]   (W/32 x Fp/16 fragments)
-  const bf16_t* Wf1;              //                 Bt[n][k] = K1[k][n]   (W/32 x W/16)
-  const bf16_t* Wb1;              //                 Bt[n][k] = K1[n][k]   (W/32 x W/16)
-  const bf16_t* Wb0;              //                 Bt[n][k] = K0[n][k]   (Fp/32 x W/16)
-  int64_t w0_batch, w1_batch;     // elements between members
-  bf16_t* H1;                     // (members, Bp, W) outputs, row-major
-  bf16_t* dZ1;
-  bf16_t* dZ0;
+  const bf16_t* Wf[BNF_MAX_LAYERS];   // fragment-major Bt[n][k] = K_l[k][n]   (W/32 x n_l/16 fragments; n_0 = Fp, else W)
+  const bf16_t* Wb[BNF_MAX_LAYERS];   //                 Bt[n][k] = K_l[n][k]   (n_l/32 x W/16)
+  int64_t w0_batch, w1_batch;     // elements between members: layer 0, every other layer
+  bf16_t* Hout[BNF_MAX_LAYERS];   // Hout[l] = H_{l+1} = act(A_l), l = 0 .. L-2: (members, Bp, W) row-major (weight gradients)
+  bf16_t* dZ[BNF_MAX_LAYERS];     // dZ[l], l = 0 .. L-1, likewise
+  bf16_t* park[BNF_MAX_LAYERS];   // middle layers 1 .. L-2: t_l = A_l log2(e) as bf16 in the OWNING WAVE's accumulator order
+                                  // ((member, panel, wave) x 16 chunks x 64 lanes x 8 values): written by the forward
+                                  // epilogue, read back by the same lanes in the backward one -- 1 KiB per wave instruction
   int64_t act_batch;
   float* dH0t;                    // (members, Fp, ldt) f32
   int64_t dh0_batch;
@@ -93,9 +95,10 @@ constexpr int kFbNone = 0, kFbInput = 1, kFbFourier = 2, kFbInter = 3;
 // the backward one in 32-byte pieces: 4 x 18.6 us at C2 against 50 us for this launch).
 struct PackJobs {
   int32_t n_layers, W;
-  int32_t off_kernel[2], n_in[2], n_pad[2], tile0[3];   // tile0[l]: first blockIdx.x of layer l
-  void* wf[2]; void* wb[2];
-  int64_t batch[2];
+  int32_t off_kernel[BNF_MAX_LAYERS], n_in[BNF_MAX_LAYERS], n_pad[BNF_MAX_LAYERS];
+  int32_t tile0[BNF_MAX_LAYERS + 1];   // tile0[l]: first blockIdx.x of layer l
+  void* wf[BNF_MAX_LAYERS]; void* wb[BNF_MAX_LAYERS];
+  int64_t batch[BNF_MAX_LAYERS];
 };
 // Workgroup 0 of a member also fills the member's row of the transformed-scalar table
 // (k_member_scalars folded in: one launch and one dependent-launch gap less per step).
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ t
   __shared__ float tile[64][65];
   const int e = blockIdx.y;
   if (scal && blockIdx.x == 0 && threadIdx.x == 0) member_scalars_row(nd, theta + (int64_t)e * theta_stride, scal + (int64_t)e * kScalStride);
-  const int l = ((int)blockIdx.x >= jb.tile0[1] && jb.n_layers > 1) ? 1 : 0;
+  int l = 0;
+  while (l + 1 < jb.n_layers && (int)blockIdx.x >= jb.tile0[l + 1]) ++l;
   const int t = (int)blockIdx.x - jb.tile0[l];
   const int W = jb.W, tn = W / 64;
   const int k0 = (t / tn) * 64, n0 = (t % tn) * 64;      // tile origin: K rows (fan-in), K columns
@@ -303,7 +307,8 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
 
   const float* th = a.theta + (int64_t)e * a.theta_stride;
   const float* sc = a.scal + (int64_t)e * kScalStride;
-  const float gamma0 = sc[0], gamma1 = sc[1], alpha = sc[BNF_MAX_LAYERS];
+  const int LL = a.n_layers - 1;            // index of the last hidden layer (1 for the two-layer networks)
+  const float gamma0 = sc[0], gamma1 = sc[LL], alpha = sc[BNF_MAX_LAYERS];   // gamma1: the LAST hidden layer's scale
   const ActConst ak = act_const(alpha);
   const float sp_in_u = (H0L && a.fbmeta) ? sc[kScalGroup + a.fb_in_group] : 1.f;   // softplus(scale of the raw-input group)
   const float inv_sw = 1.0f / sqrtf((float)a.Wt), inv_sf = 1.0f / sqrtf((float)a.F);
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   // a lone thread reaching for them later pays a full memory latency with the workgroup waiting
   const float gam_o = sc[BNF_MAX_LAYERS + 1], bias_o = th[a.off_bias_out];
   const float dgam_o = sigmoidf(th[a.off_os]);
-  const float dgam1 = sigmoidf(th[a.off_ls1]) / gamma1, dgam0 = sigmoidf(th[a.off_ls0]) / gamma0;
+  const float dgam1 = sigmoidf(th[a.off_ls[LL]]) / gamma1, dgam0 = sigmoidf(th[a.off_ls[0]]) / gamma0;
   const float lns = th[a.off_lns];
   const float e_lns = expf(lns), sigma = 0.01f + e_lns, inv_sigma = 1.0f / sigma;
   const float ll_const = -logf(sigma) - 0.918938533204672742f;
@@ -337,10 +342,10 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   const char* h0p = reinterpret_cast<const char*>(a.H0 + (int64_t)e * a.h0_batch + (int64_t)m0 * a.Fp) +
                     (size_t)(rbase / 32) * KS0 * 1024;                     // uniform; + i blocks, + lane * 16
   const size_t h0blk = (size_t)KS0 * 1024;
-  const char* wf0 = reinterpret_cast<const char*>(a.Wf0 + (int64_t)e * a.w0_batch);
-  const char* wf1 = reinterpret_cast<const char*>(a.Wf1 + (int64_t)e * a.w1_batch);
-  const char* wb1 = reinterpret_cast<const char*>(a.Wb1 + (int64_t)e * a.w1_batch);
-  const char* wb0 = reinterpret_cast<const char*>(a.Wb0 + (int64_t)e * a.w0_batch);
+  const char* wf0 = reinterpret_cast<const char*>(a.Wf[0] + (int64_t)e * a.w0_batch);
+  const char* wb0 = reinterpret_cast<const char*>(a.Wb[0] + (int64_t)e * a.w0_batch);
+  auto wfl = [&](int l) { return reinterpret_cast<const char*>(a.Wf[l] + (int64_t)e * a.w1_batch); };   // l >= 1
+  auto wbl = [&](int l) { return reinterpret_cast<const char*>(a.Wb[l] + (int64_t)e * a.w1_batch); };
   const char* w00u = wf0 + (size_t)(2 * cs) * KS0 * 1024;                  // layer-0 fragment streams (uniform)
   // lane-dependent values, re-derived at the start of every phase (see opaque_lane)
   struct LaneCtx {
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     const float gs = gamma0 * inv_sf * kLog2e;     // t = A0 log2(e): the activation core works on it (act_core2)
     float gb[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) gb[j] = BNF_ABL(a, 64) ? 0.1f : gamma0 * kLog2e * th[a.off_bias0 + cbase + j * 32 + frow];
+    for (int j = 0; j < 2; ++j) gb[j] = BNF_ABL(a, 64) ? 0.1f : gamma0 * kLog2e * th[a.off_bias[0] + cbase + j * 32 + frow];
     if (!BNF_ABL(a, 64)) l0_weights(L);
     if constexpr (H0L) lds_barrier();     // the staged feature panel is complete
     // epilogue of one 32 x 32 tile: t = A0 log2(e) -> H1 = act(A0) -> LDS panel
@@ -498,11 +503,11 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       for (int i = 0; i < RT; ++i) {
         l0_tile(L, a0b[1], i, 1);
         l0_epilogue(a0b[0], i, 0);
-        if (i > 0) block_to_global(L, a.H1, i - 1);
+        if (i > 0) block_to_global(L, a.Hout[0], i - 1);
         if (i + 1 < RT) l0_tile(L, a0b[0], i + 1, 0);
         l0_epilogue(a0b[1], i, 1);
       }
-      block_to_global(L, a.H1, RT - 1);
+      block_to_global(L, a.Hout[0], RT - 1);
     } else {
 #pragma unroll 1
       for (int i = 0; i < RT; ++i) {
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
           }
           l0_epilogue(a0, i, j);
         }
-        block_to_global(L, a.H1, i);
+        block_to_global(L, a.Hout[0], i);
       }
     }
   }
@@ -525,15 +530,74 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     if (a.fbmeta && tid < a.n_groups) { s_gfac[tid] = g_fac; s_goff[tid] = g_off; }
   }
   PanelRing ring;
-  panel_prefetch(ring, wf1, 2 * cs, KS1, opaque_lane(tid) & 63);   // in flight across the barrier
+  panel_prefetch(ring, wfl(1), 2 * cs, KS1, opaque_lane(tid) & 63);   // in flight across the barrier
   lds_barrier();
   BNF_MARK(a, 2);
 
-  // =============================== layer 1 forward ============================================
+  // this wave's slot of a middle layer's parked pre-activations: 16 chunks x 64 lanes x 8 bf16 (16 KiB)
+  auto park_ptr = [&](int l) {
+    return a.park[l] + ((((int64_t)e * a.panels + pn) * 8 + wave) * 16) * (64 * 8);
+  };
+  // =============================== middle layers forward (depth > 2) ==========================
+  // H_{l+1} = act(gamma_l (H_l K_l / sqrt W + b_l)): contraction out of the LDS panel exactly like the last
+  // layer's; the epilogue overwrites the panel with H_{l+1} (after the barrier: every wave has read H_l), copies it to
+  // HBM for the weight gradient, and PARKS t_l = A_l log2(e) for the backward pass as bf16 in this wave's own
+  // accumulator order -- the lanes that will need a value are the ones that hold it now, so the layout is free and
+  // both directions are whole 1 KiB wave accesses (the layer pipeline stores A_l^T, same rounding).
+#pragma unroll 1
+  for (int l = 1; l < LL; ++l) {
+    zero_acc();
+    {
+      const LaneCtx L = lane_ctx();
+      panel_contract<kPitchB, RT>(acc, L.prow, wfl(l), 2 * cs, KS1, L.lane, ring, [](int) {});
+    }
+    lds_barrier();
+    {
+      const LaneCtx L = lane_ctx();
+      const int lane = L.lane, frow = L.frow, kg = L.kg;
+      const float gl = sc[l];
+      const float gs = gl * inv_sw * kLog2e;
+      float gb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) gb[j] = gl * kLog2e * th[a.off_bias[l] + cbase + j * 32 + frow];
+      bf16_t* pk = park_ptr(l);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int lc = cbase + j * 32 + frow;
+          uint32_t pw[8];
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int lr = rbase + i * 32 + 8 * rg + 4 * kg;
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+              const f32x2 tv = f32x2{acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]} * gs + gb[j];
+              pw[rg * 2 + (q >> 1)] = pack_bf16x2(tv.x, tv.y);
+              const ActCore2 c = act_core2(tv);
+              const f32x2 s = kLn2 * c.mxt + c.dl;
+              const f32x2 h = ak.c1 * c.r + (ak.alpha * s + ak.c0);
+              store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, h.x, h.y);
+            }
+          }
+          u32x4* dst = reinterpret_cast<u32x4*>(pk + ((i * 2 + j) * 2 * 64 + lane) * 8);
+          __builtin_nontemporal_store(u32x4{pw[0], pw[1], pw[2], pw[3]}, dst);
+          __builtin_nontemporal_store(u32x4{pw[4], pw[5], pw[6], pw[7]}, dst + 64);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i > 0) block_to_global(L, a.Hout[l], i - 1);
+      }
+      block_to_global(L, a.Hout[l], RT - 1);
+      panel_prefetch(ring, wfl(l + 1), 2 * cs, KS1, lane);
+    }
+    lds_barrier();
+  }
+
+  // =============================== last hidden layer forward ==================================
   zero_acc();
   {
     const LaneCtx L = lane_ctx();
-    panel_contract<kPitchB, RT>(acc, L.prow, wf1, 2 * cs, KS1, L.lane, ring, [](int) {});
+    panel_contract<kPitchB, RT>(acc, L.prow, wfl(LL), 2 * cs, KS1, L.lane, ring, [](int) {});
   }
   BNF_MARK(a, 3);
   lds_barrier();     // every wave is done reading H1: the panel doubles as row-dot scratch below
@@ -549,7 +613,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     float ksum = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      gb[j] = gamma1 * kLog2e * th[a.off_bias1 + cbase + j * 32 + frow];
+      gb[j] = gamma1 * kLog2e * th[a.off_bias[LL] + cbase + j * 32 + frow];
       const float kov = th[a.off_ko + cbase + j * 32 + frow];
       ka[j] = kov * ak.alpha; kc1[j] = kov * ak.c1;
       ksum += kov;
@@ -699,10 +763,10 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
         asm volatile("" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sg[0]), "+v"(sg[1]), "+v"(cp[0]), "+v"(cp[1]),
                      "+v"(ck[0]), "+v"(ck[1]));
         __builtin_amdgcn_sched_barrier(0);
-        if (rg == 1 && i > 0) block_to_global(L, a.dZ1, i - 1);   // (deferred: see the layer-0 forward)
+        if (rg == 1 && i > 0) block_to_global(L, a.dZ[LL], i - 1);   // (deferred: see the layer-0 forward)
       }
-    block_to_global(L, a.dZ1, RT - 1);
-    panel_prefetch(ring, wb1, 2 * cs, KS1, lane);   // the accumulators are dead: weights of dH1 = dZ1 K1^T on their way
+    block_to_global(L, a.dZ[LL], RT - 1);
+    panel_prefetch(ring, wbl(LL), 2 * cs, KS1, lane);   // the accumulators are dead: weights of dH = dZ K^T on their way
     float wsa = kvn[0] * (sa[0].x + sa[0].y) + kvn[1] * (sa[1].x + sa[1].y);
     float wsg = (kLn2 / gamma1) * ((sg[0].x + sg[0].y) + (sg[1].x + sg[1].y));
 #pragma unroll
@@ -731,7 +795,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       b += s_col[r * W + c];
       k += s_col[(RB + r) * W + c];
     }
-    atomicAdd(&gr[a.off_bias1 + c], b);
+    atomicAdd(&gr[a.off_bias[LL] + c], b);
     atomicAdd(&gr[a.off_ko + c], k * inv_sw);
   }
   float ta1 = 0.f;   // d alpha (layer 1 share), kept by thread 0 until layer 0's share is known
@@ -746,7 +810,98 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
 #pragma unroll
     for (int w2 = 0; w2 < WN; ++w2) ko_all += s_sc[48 + w2];
     ta1 -= 2.f * inv_sw * ko_all * dv_all;   // the "+ 2" of the sa sums
-    atomicAdd(&gr[a.off_ls1], dgam1 * tg);
+    atomicAdd(&gr[a.off_ls[LL]], dgam1 * tg);
+  }
+
+  // =============================== middle layers backward (depth > 2) =========================
+  // for l = L-2 .. 1:  dH_{l+1} = dZ_{l+1} K_{l+1}^T (panel contraction), then
+  // dZ_l = gamma_l (dH_{l+1} / sqrt W) act'(A_l) with t_l read back from where this wave parked it
+#pragma unroll 1
+  for (int l = LL - 1; l >= 1; --l) {
+    zero_acc();
+    {
+      const LaneCtx L = lane_ctx();
+      panel_contract<kPitchB, RT>(acc, L.prow, wbl(l + 1), 2 * cs, KS1, L.lane, ring, [](int) {});
+    }
+    const LaneCtx L = lane_ctx();
+    const int lane = L.lane, frow = L.frow, kg = L.kg;
+    const bf16_t* pk = park_ptr(l);
+    u32x4 pv[2][2];       // parked t of tile (i, j): requested one tile ahead
+    auto park_load = [&](int t2, u32x4 (&dst)[2]) {
+      const u32x4* src = reinterpret_cast<const u32x4*>(pk + (min(t2, 2 * RT - 1) * 2 * 64 + lane) * 8);
+      dst[0] = __builtin_nontemporal_load(src);
+      dst[1] = __builtin_nontemporal_load(src + 64);
+    };
+    park_load(0, pv[0]);
+    lds_barrier();     // every wave is done reading dZ_{l+1}: the panel is overwritten with dZ_l
+    {
+      const float gl = sc[l];
+      const float gza = gl * inv_sw * ak.alpha, gzc = gl * inv_sw * ak.c2;
+      f32x2 sa2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, sacc = {0.f, 0.f}, cs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int t2 = 2 * i + j;
+          park_load(t2 + 1, pv[(t2 + 1) & 1]);
+          const u32x4 (&cur)[2] = pv[t2 & 1];
+          const int lc = cbase + j * 32 + frow;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int lr = rbase + i * 32 + 8 * rg + 4 * kg;
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+              const uint32_t w = cur[rg >> 1][(rg & 1) * 2 + (q >> 1)];
+              const f32x2 tv = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+              const f32x2 raw = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
+              const ActCore2 c = act_core2(tv);
+              const f32x2 s = kLn2 * c.mxt + c.dl;
+              const f32x2 dg = gzc * (c.r - c.r * c.r) + gza * c.dl;
+              const f32x2 z = raw * dg;
+              sa2 += raw * (2.f * c.r + s);
+              sacc += raw;
+              sg2 += z * tv;
+              cs2[j] += z;
+              store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, z.x, z.y);
+            }
+            asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(sacc), "+v"(cs2[0]), "+v"(cs2[1]));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (j == 0 && i > 0) block_to_global(L, a.dZ[l], i - 1);
+        }
+      }
+      block_to_global(L, a.dZ[l], RT - 1);
+      panel_prefetch(ring, wbl(l), 2 * cs, KS1, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float c = cs2[j].x + cs2[j].y;
+        c += __shfl_xor(c, 32, 64);
+        if (lane < 32) s_col[rb * W + cbase + j * 32 + lane] = c;
+      }
+      const float sa = wave_sum(inv_sw * ((sa2.x + sa2.y) - 2.f * (sacc.x + sacc.y)));
+      const float sg = wave_sum((kLn2 / gl) * (sg2.x + sg2.y));
+      if (lane == 0) {
+        s_sc[32 + wave * 2] = sa;
+        s_sc[33 + wave * 2] = sg;
+      }
+    }
+    lds_barrier();
+    for (int c = tid; c < W; c += 512) {
+      float b = 0.f;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) b += s_col[r * W + c];
+      atomicAdd(&gr[a.off_bias[l] + c], b);
+    }
+    if (tid == 0) {
+      float tg = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 8; ++w2) {
+        ta1 += s_sc[32 + w2 * 2];
+        tg += s_sc[33 + w2 * 2];
+      }
+      atomicAdd(&gr[a.off_ls[l]], sigmoidf(th[a.off_ls[l]]) / sc[l] * tg);
+    }
+    // (the next contraction's barrier-free start is safe: s_col / s_sc are next written after another barrier)
   }
 
   // =============================== dH1 = dZ1 K1^T ============================================
@@ -754,7 +909,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   zero_acc();
   {
     const LaneCtx L = lane_ctx();
-    panel_contract<kPitchB, RT>(acc, L.prow, wb1, 2 * cs, KS1, L.lane, ring, [](int) {});
+    panel_contract<kPitchB, RT>(acc, L.prow, wbl(1), 2 * cs, KS1, L.lane, ring, [](int) {});
   }
   BNF_MARK(a, 8);
   const LaneCtx L2 = lane_ctx();
@@ -771,7 +926,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     const float gs0 = gamma0 * inv_sf * kLog2e;
     float gb0[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) gb0[j] = gamma0 * kLog2e * th[a.off_bias0 + cbase + j * 32 + frow];
+    for (int j = 0; j < 2; ++j) gb0[j] = gamma0 * kLog2e * th[a.off_bias[0] + cbase + j * 32 + frow];
     const float gza = gamma0 * inv_sw * ak.alpha, gzc = gamma0 * inv_sw * ak.c2;
     f32x2 sa2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, sacc = {0.f, 0.f}, cs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
     f32x16 a0b[2];
@@ -817,10 +972,10 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
           asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(sacc), "+v"(cs2[0]), "+v"(cs2[1]));
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (j == 0 && i > 0) block_to_global(L, a.dZ0, i - 1);   // (deferred: see the layer-0 forward)
+        if (j == 0 && i > 0) block_to_global(L, a.dZ[0], i - 1);   // (deferred: see the layer-0 forward)
       }
     }
-    block_to_global(L, a.dZ0, RT - 1);
+    block_to_global(L, a.dZ[0], RT - 1);
     BNF_MARK(a, 9);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -870,7 +1025,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       float b = 0.f;
 #pragma unroll
       for (int r = 0; r < RB; ++r) b += s_col[r * W + c];
-      atomicAdd(&gr[a.off_bias0 + c], b);
+      atomicAdd(&gr[a.off_bias[0] + c], b);
     }
     if (tid == 0) {
       float ta = ta1, tg = 0.f;
@@ -880,7 +1035,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
         tg += s_sc[33 + w2 * 2];
       }
       atomicAdd(&gr[a.off_law], alpha * (1.f - alpha) * ta);
-      atomicAdd(&gr[a.off_ls0], dgam0 * tg);
+      atomicAdd(&gr[a.off_ls[0]], dgam0 * tg);
     }
     for (int t = wave; t < n_t; t += 8) {
       const int mi = t / ct, ni = t - mi * ct;

@@ -156,3 +156,65 @@ def test_weight_gradient_stream_kernels_match_the_two_stage_kernel(n_rows, monke
   errs = _leaf_errs(model, grads['stream'], grads['two_stage'])
   bad = {k: v for k, v in errs.items() if v > 2e-4}
   assert not bad, bad
+
+
+@pytest.mark.parametrize('width,depth,n_rows,obs', [(512, 3, 300, 'NORMAL'), (512, 4, 1000, 'NORMAL'), (256, 4, 700, 'NORMAL'),
+                                                    (256, 3, 300, 'NB'), (512, 5, 260, 'ZINB')])
+def test_deep_panel_step_vs_oracle_and_layer_pipeline(width, depth, n_rows, obs):
+  """Depth > 2 through the row-panel kernel (round 3: the middle layers' contractions run out of the same LDS
+  panel, their pre-activations are parked in HBM in the owning wave's register order and read back by the same
+  lanes in the backward pass -- bnf_panel.h) against the float64 oracle and against the bf16 layer pipeline:
+  loss, every gradient leaf, the activations H_{l+1} and dZ_l of EVERY layer as the weight-gradient kernels
+  read them, the network output."""
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth, observation_model=obs)
+  E = 3
+  theta = util.random_theta(model, E, scale=0.3)
+  res, acts = {}, {}
+  for pipe in ('panel', 'layers'):
+    eng = _engine(net, X, y, members=E, compute_dtype='bf16', pipeline=pipe)
+    eng.set_params(theta)
+    res[pipe] = eng.debug_loss_and_grad()
+    acts[pipe] = dict(out=eng.debug_activation(200),
+                      H=[eng.debug_activation(1 + l) for l in range(depth - 1)],
+                      dZ=[eng.debug_activation(300 + l) for l in range(depth)])
+    eng.close()
+  loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
+  out_o, ch = O.forward(model, theta, X, keep=True)
+  for l in range(depth - 1):
+    assert util.rel_err(acts['panel']['H'][l], ch['Hs'][l + 1]) < 2e-2 * (l + 1), l
+    assert util.rel_err(acts['panel']['H'][l], acts['layers']['H'][l]) < 1e-2 * (l + 1), l
+  for l in range(depth):
+    assert util.rel_err(acts['panel']['dZ'][l], acts['layers']['dZ'][l]) < 4e-2, l
+  assert util.rel_err(acts['panel']['out'], out_o) < 4e-2
+  loss_p, g_p = res['panel']
+  loss_l, g_l = res['layers']
+  np.testing.assert_allclose(loss_p, loss_o, rtol=5e-3)
+  np.testing.assert_allclose(loss_p, loss_l, rtol=1e-3)
+  bad = {k: v for k, v in _leaf_errs(model, g_p, g_o).items() if v > 6e-2}
+  assert not bad, ('vs oracle', bad)
+  bad = {k: v for k, v in _leaf_errs(model, g_p, g_l).items() if v > 3e-2}
+  assert not bad, ('vs layers', bad)
+
+
+def test_deep_panel_vi_step_and_training():
+  """C3's shape class: mean-field VI, depth 4, minibatch -- panel vs layer pipeline on one step (loss, d mu, d rho),
+  then a few steps of training through both, and the pipeline the engine picks by default IS the panel one."""
+  n_rows, E, S, B = 900, 2, 3, 400
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=512, depth=4)
+  res = {}
+  for pipe in ('panel', 'layers', 'auto'):
+    eng = _engine(net, X, y, mode='vi', members=E, vi_samples=S, kl_weight=0.2, seed=3, learning_rate=0.01,
+                  batch=B, compute_dtype='bf16', pipeline=pipe)
+    eng.init_params(0.0)
+    step = eng.debug_loss_and_grad(0, 0)
+    losses = eng.train(0, 6)
+    torch.cuda.synchronize()
+    res[pipe] = (step, losses.cpu().numpy(), eng.get_params())
+    eng.close()
+  np.testing.assert_allclose(res['panel'][0][0], res['layers'][0][0], rtol=2e-3)
+  for k in (0, 1):
+    bad = {n: v for n, v in _leaf_errs(model, res['panel'][0][1][k], res['layers'][0][1][k]).items() if v > 4e-2}
+    assert not bad, (k, bad)
+  np.testing.assert_allclose(res['panel'][1], res['layers'][1], rtol=5e-3)
+  assert np.all(np.isfinite(res['panel'][2])) and np.abs(res['panel'][2] - res['layers'][2]).max() < 0.05
+  np.testing.assert_allclose(res['auto'][1], res['panel'][1], rtol=1e-4)      # auto = panel for this shape
