@@ -399,45 +399,42 @@ static void launch_gemm_tn_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs&
   LaunchScope ls(h, kid, st, true);
   hipLaunchKernelGGL((gemm_tn<T, TAG, WG>), dim3(blocks), dim3(64 * WG * WG), kLds, st, g, ep);
 }
+enum { WG_TN128 = 0, WG_TN256 = 1, WG_RING = 2, WG_SKINNY = 3 };   // weight-gradient kernels (wgrad_plan)
 // layer-0 weight gradient as a 64 x 512 row stream (gemm_tn_skinny): Fp = 64, W a multiple of 512
 static void launch_gemm_tn_skinny(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep, hipStream_t st) {
   g.tiles_m = 1;
   g.tiles_n = g.N / 512;
-  // one workgroup per CU (144 KiB of LDS): split K until the chip is full; split-K = 1 stores
-  const int64_t base = (int64_t)g.members * g.tiles_n;
-  const int nk = g.K / kSkRows;
-  g.splitk = (int)std::max<int64_t>(1, std::min<int64_t>((h->num_cus + base - 1) / base, std::max(1, nk / 8)));
+  if (g.splitk < 1) g.splitk = 1;
   static uint64_t attr_done = 0;
   allow_lds(h, &gemm_tn_skinny, kSkLds, &attr_done);
-  const unsigned blocks = (unsigned)(base * g.splitk);
+  const unsigned blocks = (unsigned)((int64_t)g.members * g.tiles_n * g.splitk);
   LaunchScope ls(h, kid, st, true);
   hipLaunchKernelGGL(gemm_tn_skinny, dim3(blocks), dim3(512), kSkLds, st, g, ep);
 }
+// `kind`: what wgrad_plan chose (WG_*); g.splitk is the plan's too
 template <typename T, int TAG>
-static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep, hipStream_t st) {
+static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep, hipStream_t st, int kind) {
   if constexpr (sizeof(T) == 2 && TAG == 0) {
-    if (h->skinny && g.a_ld == 64 && g.N % 512 == 0 && g.K % 64 == 0) {
+    if (kind == WG_SKINNY) {
       launch_gemm_tn_skinny(h, kid, g, ep, st);
       return;
     }
   }
-  // 256 x 256 tiles when they still fill the chip (members x tiles >= half the CUs)
-  if (h->big_tiles && g.M % 256 == 0 && g.N % 256 == 0 &&
-      ((int64_t)g.members * (g.M / 256) * (g.N / 256) >= 128 || h->big_tiles == 2)) {
-    if constexpr (sizeof(T) == 2) {
-      if (h->tn_ring && g.K % 64 == 0) {   // the same tile with the K loop as a four-stage ring
-        g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
-        if (g.splitk < 1) g.splitk = 1;
-        static uint64_t attr_done = 0;
-        allow_lds(h, &gemm_tn_ring<TAG>, kRgLds, &attr_done);
-        const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
-        EpiArgs ep2 = ep;
-        ep2.ablate = h->ablate;
-        LaunchScope ls(h, kid, st, true);
-        hipLaunchKernelGGL((gemm_tn_ring<TAG>), dim3(blocks), dim3(512), kRgLds, st, g, ep2);
-        return;
-      }
+  if constexpr (sizeof(T) == 2) {
+    if (kind == WG_RING) {   // the 256 x 256 tile with the K loop as a four-stage ring
+      g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
+      if (g.splitk < 1) g.splitk = 1;
+      static uint64_t attr_done = 0;
+      allow_lds(h, &gemm_tn_ring<TAG>, kRgLds, &attr_done);
+      const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
+      EpiArgs ep2 = ep;
+      ep2.ablate = h->ablate;
+      LaunchScope ls(h, kid, st, true);
+      hipLaunchKernelGGL((gemm_tn_ring<TAG>), dim3(blocks), dim3(512), kRgLds, st, g, ep2);
+      return;
     }
+  }
+  if (kind == WG_TN256) {
     launch_gemm_tn_wg<T, TAG, 4>(h, kid, g, ep, st);
     return;
   }
@@ -524,14 +521,42 @@ struct LossSink {
   const StepState* st = nullptr;               // graph replay: per-step state in device memory
 };
 
-// split-K of layer l's weight-gradient contraction (1: the kernel STORES dK_l, > 1: f32 atomics)
-static int wgrad_splitk(const bnf_handle* h, int nmem, int l) {
-  const int M = (l == 0) ? h->F : h->W, N = h->W;
+// Which kernel computes layer l's weight gradient and with what split-K (1: the kernel STORES dK_l, > 1: f32
+// atomics).  ONE function decides for the launcher (run_wgrad_layer) and for the optimiser, which leaves the range
+// of a stored gradient uncleared (step_map): the two cannot disagree.
+struct WgradPlan { int kind, splitk; };
+static WgradPlan wgrad_plan(const bnf_handle* h, int nmem, int l) {
+  const int M = (l == 0) ? h->F : h->W, N = h->W, a_ld = (l == 0) ? h->Fp : h->W;
+  const int64_t K = h->Bp;
   const int tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
-  const int nk = (int)(h->Bp / (h->bf16 ? 64 : 32));
+  const int nk = (int)(K / (h->bf16 ? 64 : 32));
   const int sk = (1024 + nmem * tiles - 1) / (nmem * tiles);
-  return std::max(1, std::min(sk, std::max(1, nk / 4)));
+  const int base_sk = std::max(1, std::min(sk, std::max(1, nk / 4)));
+  if (h->bf16 && l == 0 && h->skinny && a_ld == 64 && N % 512 == 0 && K % 64 == 0) {
+    // layer 0 as a 64 x 512 row stream, one workgroup per CU (144 KiB of LDS): split K until the chip is full
+    const int64_t base = (int64_t)nmem * (N / 512);
+    const int nks = (int)(K / kSkRows);
+    return {WG_SKINNY, (int)std::max<int64_t>(1, std::min<int64_t>((h->num_cus + base - 1) / base, std::max(1, nks / 8)))};
+  }
+  // 256 x 256 tiles when they still fill the chip (members x tiles >= half the CUs)
+  if (h->big_tiles && M % 256 == 0 && N % 256 == 0) {
+    const int64_t units = (int64_t)nmem * (M / 256) * (N / 256);
+    if (units >= 128 || h->big_tiles == 2) {
+      if (h->bf16 && h->tn_ring && K % 64 == 0) {
+        // the four-stage ring, one workgroup per CU, NO split-K: splitting to shorten the last, partly filled
+        // round of workgroups was measured at C3/8 (320 tiles on 256 CUs) -- 2 splits 230 -> 300 us per launch,
+        // 4 splits 438 us, 5,680 -> 5,290 -> 4,730 member-steps/s: the f32 atomics of 80 x 512 x 512 outputs
+        // per split cost far more than the idle quarter round (gpurun_out/r03n).  BNF_RING_SPLITK forces one.
+        int best = 1;
+        if (const char* fs = getenv("BNF_RING_SPLITK")) best = std::max(1, atoi(fs));
+        return {WG_RING, best};
+      }
+      return {WG_TN256, base_sk};
+    }
+  }
+  return {WG_TN128, base_sk};
 }
+static int wgrad_splitk(const bnf_handle* h, int nmem, int l) { return wgrad_plan(h, nmem, l).splitk; }
 
 // weight gradient of layer l from the row-major H_l / dZ_l left in HBM, on stream `st`
 template <typename T>
@@ -544,12 +569,13 @@ static void run_wgrad_layer(bnf_handle* h, int nmem, int l, hipStream_t st) {
   g.a_ld = (l == 0) ? h->Fp : h->W; g.a_batch = Bp * g.a_ld;
   g.B = h->dZ[l]; g.b_ld = h->W; g.b_batch = Bp * h->W;
   g.M = (l == 0) ? h->F : h->W; g.N = h->W; g.K = (int)Bp; g.members = nmem;
-  g.splitk = wgrad_splitk(h, nmem, l);
+  const WgradPlan plan = wgrad_plan(h, nmem, l);
+  g.splitk = plan.splitk;
   EpiArgs ep{};
   ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->Wt));
   ep.grad = h->gradf; ep.grad_stride = h->Pf; ep.off_out = h->nd.off_kernel[l]; ep.ld_f32 = h->W;
-  if (l == 0) launch_gemm_tn<T, 0>(h, KID_WGRAD0, g, ep, st);
-  else launch_gemm_tn<T, 1>(h, KID_WGRAD, g, ep, st);
+  if (l == 0) launch_gemm_tn<T, 0>(h, KID_WGRAD0, g, ep, st, plan.kind);
+  else launch_gemm_tn<T, 1>(h, KID_WGRAD, g, ep, st, plan.kind);
 }
 
 // dZ_l has just been enqueued on the main stream: start its weight gradient on the side
@@ -720,12 +746,12 @@ static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
 // row-panel pipeline (bf16, depth 2): pack fragments -> featurise -> k_panel_fwd_bwd ->
 // featurise backward -> gemm_tn weight gradients
 // ---------------------------------------------------------------------------
-template <int WN, int RT, bool H0L>
-static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
+template <int WN, int RT, bool H0L, bool DEEP>
+static void launch_panel_d(bnf_handle* h, const PanelArgs& pa) {
   constexpr int kLds = panel_lds_bytes(WN, RT, H0L);
   static_assert(kLds <= 160 * 1024, "LDS per workgroup");
   static uint64_t attr_done = 0;
-  allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L>, kLds, &attr_done);
+  allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L, DEEP>, kLds, &attr_done);
   PanelArgs pa2 = pa;
   pa2.ablate = h->ablate;
   const unsigned blocks = (unsigned)(pa.members * pa.panels);
@@ -736,9 +762,15 @@ static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
   }
   {
     LaunchScope ls(h, KID_PANEL);
-    hipLaunchKernelGGL((k_panel_fwd_bwd<WN, RT, H0L>), dim3(blocks), dim3(512), kLds, h->stream, pa2);
+    hipLaunchKernelGGL((k_panel_fwd_bwd<WN, RT, H0L, DEEP>), dim3(blocks), dim3(512), kLds, h->stream, pa2);
   }
   phase_prof_end(h, KID_PANEL, blocks, 512);
+}
+
+template <int WN, int RT, bool H0L>
+static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
+  if (pa.n_layers == 2) launch_panel_d<WN, RT, H0L, false>(h, pa);
+  else launch_panel_d<WN, RT, H0L, true>(h, pa);
 }
 
 static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs, float c,
@@ -870,7 +902,7 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
   a.apply = apply ? 1 : 0; a.loss_raw = sink.raw; a.st = sink.st;
   // the largest hidden-layer kernel whose gradient the next step stores (no split-K) is not cleared
   a.keep_lo = a.keep_hi = 0;
-  if (!h->pad && h->P % 4 == 0 && !h->adam_clear_all)
+  if (!h->pad && h->P % 4 == 0 && !h->adam_clear_all && h->ablate == 0)
     for (int l = 1; l < h->L; ++l)
       if (wgrad_splitk(h, E, l) == 1 && a.keep_hi == 0) {
         a.keep_lo = (h->nd.off_kernel[l] + 3) / 4 * 4;
@@ -1624,6 +1656,14 @@ int bnf_debug_gemm_nt(bnf_handle* h, const float* A, const float* Bt, int32_t M,
   return BNF_OK;
 }
 
+// the raw weight-gradient core on a caller's shape: the tile the production dispatch would pick for it
+static int debug_tn_kind(const bnf_handle* h, const GemmArgs& g) {
+  if (h->big_tiles && g.M % 256 == 0 && g.N % 256 == 0 &&
+      ((int64_t)g.members * (g.M / 256) * (g.N / 256) >= 128 || h->big_tiles == 2))
+    return (h->bf16 && h->tn_ring && g.K % 64 == 0) ? WG_RING : WG_TN256;
+  return WG_TN128;
+}
+
 int bnf_debug_gemm_tn(bnf_handle* h, const float* A, const float* B, int32_t R, int32_t M, int32_t N,
                       float* C) {
   if (!h || !A || !B || !C) return fail(BNF_ERR_INVALID, "null");
@@ -1641,11 +1681,11 @@ int bnf_debug_gemm_tn(bnf_handle* h, const float* A, const float* B, int32_t R, 
   if (h->bf16) {
     hipLaunchKernelGGL((k_from_f32<bf16_t>), dim3(cdiv((int64_t)R * M, 256)), dim3(256), 0, st, A, (int64_t)R, M, (bf16_t*)dA, M);
     hipLaunchKernelGGL((k_from_f32<bf16_t>), dim3(cdiv((int64_t)R * N, 256)), dim3(256), 0, st, B, (int64_t)R, N, (bf16_t*)dB, N);
-    launch_gemm_tn<bf16_t, 2>(h, KID_WGRAD, g, ep, st);
+    launch_gemm_tn<bf16_t, 2>(h, KID_WGRAD, g, ep, st, debug_tn_kind(h, g));
   } else {
     hipLaunchKernelGGL((k_from_f32<float>), dim3(cdiv((int64_t)R * M, 256)), dim3(256), 0, st, A, (int64_t)R, M, (float*)dA, M);
     hipLaunchKernelGGL((k_from_f32<float>), dim3(cdiv((int64_t)R * N, 256)), dim3(256), 0, st, B, (int64_t)R, N, (float*)dB, N);
-    launch_gemm_tn<float, 2>(h, KID_WGRAD, g, ep, st);
+    launch_gemm_tn<float, 2>(h, KID_WGRAD, g, ep, st, debug_tn_kind(h, g));
   }
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipFree(dA));

@@ -267,7 +267,9 @@ __device__ __forceinline__ void l0_mma(f32x16& a0, const L0Blk& bk) {
 // every 32 x 32 tile re-fetches 8 KiB of operands through the vector memory path -- 768 KiB per
 // panel over both passes, as much as the two W x W contractions stream -- and those phases were
 // bound by that stream (~10k of a panel's 160k cycles each).
-template <int WN, int RT, bool H0L>
+// DEEP = false: exactly two hidden layers (the benchmark shape): the middle-layer loops are compiled out and the
+// last layer's index is a constant (the run-time-depth form cost it 0.8 % at C2, same box).
+template <int WN, int RT, bool H0L, bool DEEP = false>
 __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const PanelArgs a) {
   constexpr int W = 64 * WN, RB = 8 / WN, WR = 32 * RT, BM = WR * RB;   // WR = rows per wave
   constexpr int kPitchE = W + 8;            // panel row pitch, elements (16 bytes of padding)
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
 
   const float* th = a.theta + (int64_t)e * a.theta_stride;
   const float* sc = a.scal + (int64_t)e * kScalStride;
-  const int LL = a.n_layers - 1;            // index of the last hidden layer (1 for the two-layer networks)
+  const int LL = DEEP ? a.n_layers - 1 : 1; // index of the last hidden layer (1 for the two-layer networks)
   const float gamma0 = sc[0], gamma1 = sc[LL], alpha = sc[BNF_MAX_LAYERS];   // gamma1: the LAST hidden layer's scale
   const ActConst ak = act_const(alpha);
   const float sp_in_u = (H0L && a.fbmeta) ? sc[kScalGroup + a.fb_in_group] : 1.f;   // softplus(scale of the raw-input group)
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   // accumulator order -- the lanes that will need a value are the ones that hold it now, so the layout is free and
   // both directions are whole 1 KiB wave accesses (the layer pipeline stores A_l^T, same rounding).
 #pragma unroll 1
-  for (int l = 1; l < LL; ++l) {
+  for (int l = 1; DEEP && l < LL; ++l) {
     zero_acc();
     {
       const LaneCtx L = lane_ctx();
@@ -817,7 +819,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   // for l = L-2 .. 1:  dH_{l+1} = dZ_{l+1} K_{l+1}^T (panel contraction), then
   // dZ_l = gamma_l (dH_{l+1} / sqrt W) act'(A_l) with t_l read back from where this wave parked it
 #pragma unroll 1
-  for (int l = LL - 1; l >= 1; --l) {
+  for (int l = LL - 1; DEEP && l >= 1; --l) {
     zero_acc();
     {
       const LaneCtx L = lane_ctx();

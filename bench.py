@@ -53,7 +53,7 @@ KERNEL_SYMBOL = {   # gemm_nt<T, epilogue, tag, wave rows, wave cols>
     'gemm_wgrad_l0': 'bnf::gemm_tn_skinny(bnf::GemmArgs, bnf::EpiArgs)',
     'gemm_wgrad': 'void bnf::gemm_tn_ring<1>(bnf::GemmArgs, bnf::EpiArgs)',
     'last_bwd': 'void bnf::k_last_bwd<{T}>',
-    'panel_fwd_bwd': 'void bnf::k_panel_fwd_bwd<8, 4, true>(bnf::PanelArgs)',
+    'panel_fwd_bwd': 'void bnf::k_panel_fwd_bwd<8, 4, true',   # (+ the DEEP flag: false at the benchmark depth)
 }
 
 
