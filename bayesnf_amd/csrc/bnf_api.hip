@@ -192,7 +192,7 @@ static size_t carve(bnf_handle* h, char* base) {
   // no transposed copies (the weight-gradient contraction reads row-major, gemm_tn); the row-panel
   // kernel reads the features as MFMA A fragments from a second, fragment-major copy (H0t slot)
   // (the H0L variant -- W = 512, Fp = 64 -- stages the row-major copy in LDS instead and skips it)
-  h->h0l = h->panel && h->W == 512 && h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L");
+  h->h0l = h->panel && (h->W == 512 || h->W == 1024) && h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L");
   h->H0t = (h->panel && !h->h0l) ? take((size_t)Ev * Bp * Fp * es) : nullptr;
   for (int l = 0; l < h->L; ++l) {
     h->A[l] = (h->panel || (h->fuse_last && l == h->L - 1) || (h->recompute_a0 && l == 0)) ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
@@ -746,12 +746,12 @@ static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
 // row-panel pipeline (bf16, depth 2): pack fragments -> featurise -> k_panel_fwd_bwd ->
 // featurise backward -> gemm_tn weight gradients
 // ---------------------------------------------------------------------------
-template <int WN, int RT, bool H0L, bool DEEP>
+template <int WN, int RT, bool H0L, bool DEEP, int CH>
 static void launch_panel_d(bnf_handle* h, const PanelArgs& pa) {
-  constexpr int kLds = panel_lds_bytes(WN, RT, H0L);
+  constexpr int kLds = panel_lds_bytes(WN, RT, H0L, CH);
   static_assert(kLds <= 160 * 1024, "LDS per workgroup");
   static uint64_t attr_done = 0;
-  allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L, DEEP>, kLds, &attr_done);
+  allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH>, kLds, &attr_done);
   PanelArgs pa2 = pa;
   pa2.ablate = h->ablate;
   const unsigned blocks = (unsigned)(pa.members * pa.panels);
@@ -762,15 +762,15 @@ static void launch_panel_d(bnf_handle* h, const PanelArgs& pa) {
   }
   {
     LaunchScope ls(h, KID_PANEL);
-    hipLaunchKernelGGL((k_panel_fwd_bwd<WN, RT, H0L, DEEP>), dim3(blocks), dim3(512), kLds, h->stream, pa2);
+    hipLaunchKernelGGL((k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH>), dim3(blocks), dim3(512), kLds, h->stream, pa2);
   }
   phase_prof_end(h, KID_PANEL, blocks, 512);
 }
 
-template <int WN, int RT, bool H0L>
+template <int WN, int RT, bool H0L, int CH = 1>
 static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
-  if (pa.n_layers == 2) launch_panel_d<WN, RT, H0L, false>(h, pa);
-  else launch_panel_d<WN, RT, H0L, true>(h, pa);
+  if (pa.n_layers == 2) launch_panel_d<WN, RT, H0L, false, CH>(h, pa);
+  else launch_panel_d<WN, RT, H0L, true, CH>(h, pa);
 }
 
 static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs, float c,
@@ -809,13 +809,25 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   pa.grad = h->gradf; pa.grad_stride = h->Pf;
   pa.loss = sink.loss; pa.loss_raw = sink.raw; pa.loss_stride = sink.stride; pa.S = h->S;
   pa.loss_scale = sink.scale; pa.lik_c = c; pa.st = sink.st;
-  // 128-row panels at W = 512 (the feature panel staged in LDS when Fp = 64), 256-row panels at W = 256
-  if (h->W == 512) {
+  // 128-row panels at W = 512 (the feature panel staged in LDS when Fp = 64), 256-row panels at W = 256,
+  // 64-row panels with two 64-column slabs per wave at W = 1024
+  auto with_fused_featbwd = [&]() {
+    pa.fbmeta = h->fbmeta; pa.off_lsa = h->nd.off_lsa; pa.n_groups = h->nd.n_groups; pa.n_inputs = h->nd.D;
+    pa.fb_in_group = h->fb_in_group;
+    feat_bwd_fused = h->fbmeta != nullptr;
+  };
+  if (h->W == 1024) {
+    pa.panels = (int32_t)(Bp / panel_rows(8, 2));
+    if (h->h0l) {
+      with_fused_featbwd();
+      launch_panel<8, 2, true, 2>(h, pa);
+    } else {
+      launch_panel<8, 2, false, 2>(h, pa);
+    }
+  } else if (h->W == 512) {
     pa.panels = (int32_t)(Bp / panel_rows(8, 4));
     if (h->h0l) {
-      pa.fbmeta = h->fbmeta; pa.off_lsa = h->nd.off_lsa; pa.n_groups = h->nd.n_groups; pa.n_inputs = h->nd.D;
-      pa.fb_in_group = h->fb_in_group;
-      feat_bwd_fused = h->fbmeta != nullptr;
+      with_fused_featbwd();
       launch_panel<8, 4, true>(h, pa);
     } else {
       launch_panel<8, 4, false>(h, pa);
@@ -1135,10 +1147,10 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
     // pipeline 3: row-panel forward + backward kernel (bf16, two hidden layers, width 256 / 512)
     // pipeline 3: row-panel forward + backward kernel (bf16, >= 2 hidden layers, width 256 / 512): rows stay in LDS /
     // registers through ALL layers; the middle layers of deeper networks park their pre-activations in HBM
-    const bool can_panel = !cfg->forward_only && h->bf16 && h->L >= 2 && (h->W == 256 || h->W == 512) && h->Fp <= 128;
+    const bool can_panel = !cfg->forward_only && h->bf16 && h->L >= 2 && (h->W == 256 || h->W == 512 || h->W == 1024) && h->Fp <= 128;
     if (want == 3 && !can_panel) {
       delete h;
-      return fail(BNF_ERR_INVALID, "panel pipeline needs a bf16 training handle with depth >= 2, width 256/512 and <= 128 features");
+      return fail(BNF_ERR_INVALID, "panel pipeline needs a bf16 training handle with depth >= 2, width 256/512/1024 and <= 128 features");
     }
     h->panel = can_panel && (want == 3 || want == 0);   // the default where it applies (C2: 2.71 -> 2.27 ms/step)
     if (h->panel) h->Bp = align_up(h->B, 256);
@@ -1149,7 +1161,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
     // its contraction depth is Fp <= 128: cheaper to redo than to write + gather A_0^T
     h->recompute_a0 = !cfg->forward_only && !h->panel && want == 0 && h->L >= 2 && h->Fp <= 128;
   }
-  h->h0l = h->panel && h->W == 512 && h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L");
+  h->h0l = h->panel && (h->W == 512 || h->W == 1024) && h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L");
   if (h->h0l &&
       !(getenv("BNF_PANEL_FEATBWD") && atoi(getenv("BNF_PANEL_FEATBWD")) == 0)) {
     // fused featurisation backward of the H0L panel kernel: what each feature column contributes

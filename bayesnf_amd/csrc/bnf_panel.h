@@ -157,9 +157,10 @@ constexpr int kPanelPD = 4;       // weight fragments in flight per stream
 // RT = 32-row tiles per wave (4: one workgroup per CU, 256 registers; 2: two workgroups per CU, 128)
 __host__ __device__ constexpr int panel_rows(int wn, int rt) { return 32 * rt * (8 / wn); }
 // h0l: the feature panel (Fp = 64: BM x 144 bytes) is staged in LDS as well -- fits for W = 512
-__host__ __device__ constexpr int panel_lds_bytes(int wn, int rt, bool h0l) {
-  const int W = 64 * wn, BM = panel_rows(wn, rt), RB = 8 / wn;
-  return BM * (W * 2 + 16) + (BM * wn + BM + 2 * RB * W + 128) * 4 + (h0l ? BM * 144 : 0);
+// ch: 64-column slabs per wave (1: W = 64 wn; 2: W = 128 wn -- the width-1024 variant)
+__host__ __device__ constexpr int panel_lds_bytes(int wn, int rt, bool h0l, int ch = 1) {
+  const int W = 64 * wn * ch, BM = panel_rows(wn, rt), RB = 8 / wn;
+  return BM * (W * 2 + 16) + (BM * wn * ch + BM + 2 * RB * W + 128) * 4 + (h0l ? BM * 144 : 0);
 }
 
 // Makes a lane value opaque to the optimiser at this point: everything derived from it (fragment
@@ -269,9 +270,13 @@ __device__ __forceinline__ void l0_mma(f32x16& a0, const L0Blk& bk) {
 // bound by that stream (~10k of a panel's 160k cycles each).
 // DEEP = false: exactly two hidden layers (the benchmark shape): the middle-layer loops are compiled out and the
 // last layer's index is a constant (the run-time-depth form cost it 0.8 % at C2, same box).
-template <int WN, int RT, bool H0L, bool DEEP = false>
-__global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const PanelArgs a) {
-  constexpr int W = 64 * WN, RB = 8 / WN, WR = 32 * RT, BM = WR * RB;   // WR = rows per wave
+// CH = 2: every wave owns TWO 64-column slabs, carried one after the other through every phase (the width-1024
+// variant: 8 waves x 2 x 64 columns, 64-row panels so that the panel still fits in LDS; twice the weight stream per
+// MFMA of the 128-row form).
+template <int WN, int RT, bool H0L, bool DEEP = false, int CH = 1>
+__global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
+  constexpr int W = 64 * WN * CH, RB = 8 / WN, WR = 32 * RT, BM = WR * RB;   // WR = rows per wave
+  constexpr int kSlabs = WN * CH;           // 64-column slabs of the layer
   constexpr int kPitchE = W + 8;            // panel row pitch, elements (16 bytes of padding)
   constexpr int kPitchB = kPitchE * 2;
   constexpr int KS1 = W / 16;
@@ -279,8 +284,8 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
   float* xs = reinterpret_cast<float*>(smem + BM * kPitchB);
-  float* s_part = xs;                       // [BM][WN] row-dot partials
-  float* s_dv = s_part + BM * WN;           // [BM]
+  float* s_part = xs;                       // [BM][kSlabs] row-dot partials
+  float* s_dv = s_part + BM * kSlabs;       // [BM]
   float* s_col = s_dv + BM;                 // [2][RB][W] column sums
   float* s_sc = s_col + 2 * RB * W;         // scalars
   constexpr int kH0Pitch = 144;             // Fp = 64: 128 bytes + 16 of padding
@@ -289,7 +294,8 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   const int tid_k = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid_k >> 6);
   const int rb = wave / WN, cs = wave % WN;
-  const int rbase = rb * WR, cbase = cs * 64;
+  const int rbase = rb * WR;
+  auto slab = [&](int hc) { return cs * CH + hc; };          // this wave's hc-th 64-column slab
   const int KS0 = a.Fp / 16;
 #if BNF_PANEL_PRIO
   // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per
@@ -348,19 +354,18 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   const char* wb0 = reinterpret_cast<const char*>(a.Wb[0] + (int64_t)e * a.w0_batch);
   auto wfl = [&](int l) { return reinterpret_cast<const char*>(a.Wf[l] + (int64_t)e * a.w1_batch); };   // l >= 1
   auto wbl = [&](int l) { return reinterpret_cast<const char*>(a.Wb[l] + (int64_t)e * a.w1_batch); };
-  const char* w00u = wf0 + (size_t)(2 * cs) * KS0 * 1024;                  // layer-0 fragment streams (uniform)
   // lane-dependent values, re-derived at the start of every phase (see opaque_lane)
   struct LaneCtx {
     int lane, frow, kg;
     const char *h0row, *w00, *w01, *prow;
   };
-  auto lane_ctx = [&]() {
+  auto lane_ctx = [&](int hc = 0) {
     LaneCtx c;
     c.lane = opaque_lane(tid) & 63;
     c.frow = c.lane & 31;
     c.kg = c.lane >> 5;
     c.h0row = h0p + c.lane * 16;
-    c.w00 = w00u + c.lane * 16;
+    c.w00 = wf0 + (size_t)(2 * slab(hc)) * KS0 * 1024 + c.lane * 16;      // layer-0 fragment streams of slab hc
     c.w01 = c.w00 + (size_t)KS0 * 1024;
     c.prow = smem + (rbase + c.frow) * kPitchB + c.kg * 16;   // A fragments of this lane
     return c;
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   // writes must have landed (lgkmcnt), no workgroup barrier, and the stores (128-byte runs, 1 KiB
   // per wave instruction) issue underneath the VALU work of the next block instead of in a
   // 10k-cycle burst per panel (a CU issues stores at ~13 B/clk).
-  auto block_to_global = [&](const LaneCtx& L, bf16_t* dst, int i) {
+  auto block_to_global = [&](const LaneCtx& L, bf16_t* dst, int i, int cbase) {
     if (BNF_ABL(a, 8)) return;
     bf16_t* d = dst + (int64_t)e * a.act_batch + (int64_t)(m0 + rbase + i * 32) * W + cbase;
     const bf16_t* sp = tile + (rbase + i * 32) * kPitchE + cbase;
@@ -402,14 +407,16 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     }
   }
   BNF_MARK(a, 0);
-  f32x16 acc[RT][2];
+  f32x16 accs[CH][RT][2];   // [slab][row tile][column tile]; the phases below see one slab at a time as `acc`
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+    for (int hc = 0; hc < CH; ++hc)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accs[hc][i][j][r] = 0.f;
   };
   // Layer-0 pre-activations of the 32 x 32 tile (row block i, column half j) of this wave,
   // a0 = H0 K0 (un-scaled).  `blk` enters holding the first four k steps of tile t = 2 i + j and
@@ -465,15 +472,17 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   };
 
   // =============================== layer 0 forward -> H1 panel ===============================
-  {
-    const LaneCtx L = lane_ctx();
+  if constexpr (H0L) lds_barrier();     // the staged feature panel is complete
+#pragma unroll
+  for (int hc = 0; hc < CH; ++hc) {
+    const int cbase = slab(hc) * 64;
+    const LaneCtx L = lane_ctx(hc);
     const int frow = L.frow, kg = L.kg;
     const float gs = gamma0 * inv_sf * kLog2e;     // t = A0 log2(e): the activation core works on it (act_core2)
     float gb[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) gb[j] = BNF_ABL(a, 64) ? 0.1f : gamma0 * kLog2e * th[a.off_bias[0] + cbase + j * 32 + frow];
     if (!BNF_ABL(a, 64)) l0_weights(L);
-    if constexpr (H0L) lds_barrier();     // the staged feature panel is complete
     // epilogue of one 32 x 32 tile: t = A0 log2(e) -> H1 = act(A0) -> LDS panel
     auto l0_epilogue = [&](const f32x16& a0, int i, int j) {
       const int lc = cbase + j * 32 + frow;
@@ -505,11 +514,11 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       for (int i = 0; i < RT; ++i) {
         l0_tile(L, a0b[1], i, 1);
         l0_epilogue(a0b[0], i, 0);
-        if (i > 0) block_to_global(L, a.Hout[0], i - 1);
+        if (i > 0) block_to_global(L, a.Hout[0], i - 1, cbase);
         if (i + 1 < RT) l0_tile(L, a0b[0], i + 1, 0);
         l0_epilogue(a0b[1], i, 1);
       }
-      block_to_global(L, a.Hout[0], RT - 1);
+      block_to_global(L, a.Hout[0], RT - 1, cbase);
     } else {
 #pragma unroll 1
       for (int i = 0; i < RT; ++i) {
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
           }
           l0_epilogue(a0, i, j);
         }
-        block_to_global(L, a.Hout[0], i);
+        block_to_global(L, a.Hout[0], i, cbase);
       }
     }
   }
@@ -531,14 +540,24 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   if constexpr (H0L) {
     if (a.fbmeta && tid < a.n_groups) { s_gfac[tid] = g_fac; s_goff[tid] = g_off; }
   }
-  PanelRing ring;
-  panel_prefetch(ring, wfl(1), 2 * cs, KS1, opaque_lane(tid) & 63);   // in flight across the barrier
+  PanelRing ring[CH];
+  auto ring_prefetch = [&](const char* wp, int lane) {   // the first weight fragments of every slab of this wave
+#pragma unroll
+    for (int hc = 0; hc < CH; ++hc) panel_prefetch(ring[hc], wp, 2 * slab(hc), KS1, lane);
+  };
+  auto contract_all = [&](const char* wp) {              // accs[hc] += panel . W[:, slab hc] for every slab
+    const LaneCtx L = lane_ctx();
+#pragma unroll
+    for (int hc = 0; hc < CH; ++hc)
+      panel_contract<kPitchB, RT>(accs[hc], L.prow, wp, 2 * slab(hc), KS1, L.lane, ring[hc], [](int) {});
+  };
+  ring_prefetch(wfl(1), opaque_lane(tid) & 63);   // in flight across the barrier
   lds_barrier();
   BNF_MARK(a, 2);
 
-  // this wave's slot of a middle layer's parked pre-activations: 16 chunks x 64 lanes x 8 bf16 (16 KiB)
-  auto park_ptr = [&](int l) {
-    return a.park[l] + ((((int64_t)e * a.panels + pn) * 8 + wave) * 16) * (64 * 8);
+  // this wave's slot of a middle layer's parked pre-activations: per slab 4 RT chunks x 64 lanes x 8 bf16
+  auto park_ptr = [&](int l, int hc) {
+    return a.park[l] + (((((int64_t)e * a.panels + pn) * 8 + wave) * CH + hc) * (4 * RT)) * (64 * 8);   // 4 RT chunks of 1 KiB per slab
   };
   // =============================== middle layers forward (depth > 2) ==========================
   // H_{l+1} = act(gamma_l (H_l K_l / sqrt W + b_l)): contraction out of the LDS panel exactly like the last
@@ -549,12 +568,12 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
 #pragma unroll 1
   for (int l = 1; DEEP && l < LL; ++l) {
     zero_acc();
-    {
-      const LaneCtx L = lane_ctx();
-      panel_contract<kPitchB, RT>(acc, L.prow, wfl(l), 2 * cs, KS1, L.lane, ring, [](int) {});
-    }
+    contract_all(wfl(l));
     lds_barrier();
-    {
+#pragma unroll
+    for (int hc = 0; hc < CH; ++hc) {
+      const int cbase = slab(hc) * 64;
+      f32x16 (&acc)[RT][2] = accs[hc];
       const LaneCtx L = lane_ctx();
       const int lane = L.lane, frow = L.frow, kg = L.kg;
       const float gl = sc[l];
@@ -562,7 +581,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       float gb[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) gb[j] = gl * kLog2e * th[a.off_bias[l] + cbase + j * 32 + frow];
-      bf16_t* pk = park_ptr(l);
+      bf16_t* pk = park_ptr(l, hc);
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
 #pragma unroll
@@ -587,25 +606,26 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
           __builtin_nontemporal_store(u32x4{pw[4], pw[5], pw[6], pw[7]}, dst + 64);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (i > 0) block_to_global(L, a.Hout[l], i - 1);
+        if (i > 0) block_to_global(L, a.Hout[l], i - 1, cbase);
       }
-      block_to_global(L, a.Hout[l], RT - 1);
-      panel_prefetch(ring, wfl(l + 1), 2 * cs, KS1, lane);
+      block_to_global(L, a.Hout[l], RT - 1, cbase);
     }
+    ring_prefetch(wfl(l + 1), opaque_lane(tid) & 63);
     lds_barrier();
   }
 
   // =============================== last hidden layer forward ==================================
   zero_acc();
-  {
-    const LaneCtx L = lane_ctx();
-    panel_contract<kPitchB, RT>(acc, L.prow, wfl(LL), 2 * cs, KS1, L.lane, ring, [](int) {});
-  }
+  contract_all(wfl(LL));
   BNF_MARK(a, 3);
   lds_barrier();     // every wave is done reading H1: the panel doubles as row-dot scratch below
 
   // ---- A1 = gamma1 (acc / sqrt W + b1) kept in the accumulators; row dots act(A1) . k_o ----
-  {
+  float ksum_wave = 0.f;   // sum of k_o over all of this wave's columns
+#pragma unroll
+  for (int hc = 0; hc < CH; ++hc) {
+    const int cbase = slab(hc) * 64;
+    f32x16 (&acc)[RT][2] = accs[hc];
     const LaneCtx L = lane_ctx();
     const int lane = L.lane, frow = L.frow, kg = L.kg;
     // the accumulators keep t1 = A1 log2(e) from here on; row dot of act(A1) = c0 + c1 r + alpha s with k_o:
@@ -620,8 +640,9 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       ka[j] = kov * ak.alpha; kc1[j] = kov * ak.c1;
       ksum += kov;
     }
-    ksum = wave_sum(kg == 0 ? ksum : 0.f);           // sum of k_o over this wave's 64 columns
-    if (lane == 0) s_sc[48 + wave] = ksum;           // (read by thread 0 after the barriers below)
+    ksum = wave_sum(kg == 0 ? ksum : 0.f);           // sum of k_o over this slab's 64 columns
+    ksum_wave += ksum;
+    if (hc == CH - 1 && lane == 0) s_sc[48 + wave] = ksum_wave;   // (read by thread 0 after the barriers below)
     ksum *= ak.c0;
     float* s_dot = reinterpret_cast<float*>(smem) + wave * (64 * kRowDotPitch);   // [64 rows][32 lanes]
 #pragma unroll
@@ -660,7 +681,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       f32x4 t4 = rp[0];
 #pragma unroll
       for (int c = 1; c < 8; ++c) t4 += rp[c];
-      s_part[(rbase + half * 64 + lane) * WN + cs] = ((t4.x + t4.y) + (t4.z + t4.w)) + ksum;
+      s_part[(rbase + half * 64 + lane) * kSlabs + slab(hc)] = ((t4.x + t4.y) + (t4.z + t4.w)) + ksum;
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -673,7 +694,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       const int m = m0 + tid;
       float vsum = 0.f;
 #pragma unroll
-      for (int c = 0; c < WN; ++c) vsum += s_part[tid * WN + c];
+      for (int c = 0; c < kSlabs; ++c) vsum += s_part[tid * kSlabs + c];
       float dvv = 0.f;
       if (m < a.B) {
         const float v = vsum * inv_sw + bias_o;
@@ -722,7 +743,11 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     if (a.obs == BNF_OBS_ZINB) atomicAdd(&gr[a.off_infl], u[4]);
   }
   // ---- dZ1 = gamma1 (dv k_o / sqrt W) act'(A1) -> panel; column sums and scalar gradients ----
-  {
+  float wsa_all = 0.f, wsg_all = 0.f;
+#pragma unroll
+  for (int hc = 0; hc < CH; ++hc) {
+    const int cbase = slab(hc) * 64;
+    f32x16 (&acc)[RT][2] = accs[hc];
     const LaneCtx L = lane_ctx();
     const int lane = L.lane, frow = L.frow, kg = L.kg;
     f32x2 sa[2], sg[2], cp[2], ck[2];
@@ -765,10 +790,10 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
         asm volatile("" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sg[0]), "+v"(sg[1]), "+v"(cp[0]), "+v"(cp[1]),
                      "+v"(ck[0]), "+v"(ck[1]));
         __builtin_amdgcn_sched_barrier(0);
-        if (rg == 1 && i > 0) block_to_global(L, a.dZ[LL], i - 1);   // (deferred: see the layer-0 forward)
+        if (rg == 1 && i > 0) block_to_global(L, a.dZ[LL], i - 1, cbase);   // (deferred: see the layer-0 forward)
       }
-    block_to_global(L, a.dZ[LL], RT - 1);
-    panel_prefetch(ring, wbl(LL), 2 * cs, KS1, lane);   // the accumulators are dead: weights of dH = dZ K^T on their way
+    block_to_global(L, a.dZ[LL], RT - 1, cbase);
+    if (hc == CH - 1) ring_prefetch(wbl(LL), lane);   // the accumulators are dead: weights of dH = dZ K^T on their way
     float wsa = kvn[0] * (sa[0].x + sa[0].y) + kvn[1] * (sa[1].x + sa[1].y);
     float wsg = (kLn2 / gamma1) * ((sg[0].x + sg[0].y) + (sg[1].x + sg[1].y));
 #pragma unroll
@@ -781,11 +806,11 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
         s_col[(RB + rb) * W + cbase + j * 32 + lane] = k;
       }
     }
-    wsa = wave_sum(wsa);
-    wsg = wave_sum(wsg);
-    if (lane == 0) {
-      s_sc[32 + wave * 2] = wsa;
-      s_sc[33 + wave * 2] = wsg;
+    wsa_all += wave_sum(wsa);
+    wsg_all += wave_sum(wsg);
+    if (hc == CH - 1 && lane == 0) {
+      s_sc[32 + wave * 2] = wsa_all;
+      s_sc[33 + wave * 2] = wsg_all;
     }
   }
   BNF_MARK(a, 6);
@@ -821,22 +846,24 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
 #pragma unroll 1
   for (int l = LL - 1; DEEP && l >= 1; --l) {
     zero_acc();
-    {
-      const LaneCtx L = lane_ctx();
-      panel_contract<kPitchB, RT>(acc, L.prow, wbl(l + 1), 2 * cs, KS1, L.lane, ring, [](int) {});
-    }
+    contract_all(wbl(l + 1));
     const LaneCtx L = lane_ctx();
     const int lane = L.lane, frow = L.frow, kg = L.kg;
-    const bf16_t* pk = park_ptr(l);
     u32x4 pv[2][2];       // parked t of tile (i, j): requested one tile ahead
-    auto park_load = [&](int t2, u32x4 (&dst)[2]) {
+    auto park_load = [&](const bf16_t* pk, int t2, u32x4 (&dst)[2]) {
       const u32x4* src = reinterpret_cast<const u32x4*>(pk + (min(t2, 2 * RT - 1) * 2 * 64 + lane) * 8);
       dst[0] = __builtin_nontemporal_load(src);
       dst[1] = __builtin_nontemporal_load(src + 64);
     };
-    park_load(0, pv[0]);
+    park_load(park_ptr(l, 0), 0, pv[0]);
     lds_barrier();     // every wave is done reading dZ_{l+1}: the panel is overwritten with dZ_l
-    {
+    float sa_all = 0.f, sg_all = 0.f;
+#pragma unroll
+    for (int hc = 0; hc < CH; ++hc) {
+      const int cbase = slab(hc) * 64;
+      f32x16 (&acc)[RT][2] = accs[hc];
+      const bf16_t* pk = park_ptr(l, hc);
+      if (hc > 0) park_load(pk, 0, pv[0]);
       const float gl = sc[l];
       const float gza = gl * inv_sw * ak.alpha, gzc = gl * inv_sw * ak.c2;
       f32x2 sa2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, sacc = {0.f, 0.f}, cs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
@@ -845,7 +872,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int t2 = 2 * i + j;
-          park_load(t2 + 1, pv[(t2 + 1) & 1]);
+          park_load(pk, t2 + 1, pv[(t2 + 1) & 1]);
           const u32x4 (&cur)[2] = pv[t2 & 1];
           const int lc = cbase + j * 32 + frow;
 #pragma unroll
@@ -869,22 +896,22 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
             asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(sacc), "+v"(cs2[0]), "+v"(cs2[1]));
             __builtin_amdgcn_sched_barrier(0);
           }
-          if (j == 0 && i > 0) block_to_global(L, a.dZ[l], i - 1);
+          if (j == 0 && i > 0) block_to_global(L, a.dZ[l], i - 1, cbase);
         }
       }
-      block_to_global(L, a.dZ[l], RT - 1);
-      panel_prefetch(ring, wbl(l), 2 * cs, KS1, lane);
+      block_to_global(L, a.dZ[l], RT - 1, cbase);
+      if (hc == CH - 1) ring_prefetch(wbl(l), lane);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         float c = cs2[j].x + cs2[j].y;
         c += __shfl_xor(c, 32, 64);
         if (lane < 32) s_col[rb * W + cbase + j * 32 + lane] = c;
       }
-      const float sa = wave_sum(inv_sw * ((sa2.x + sa2.y) - 2.f * (sacc.x + sacc.y)));
-      const float sg = wave_sum((kLn2 / gl) * (sg2.x + sg2.y));
-      if (lane == 0) {
-        s_sc[32 + wave * 2] = sa;
-        s_sc[33 + wave * 2] = sg;
+      sa_all += wave_sum(inv_sw * ((sa2.x + sa2.y) - 2.f * (sacc.x + sacc.y)));
+      sg_all += wave_sum((kLn2 / gl) * (sg2.x + sg2.y));
+      if (hc == CH - 1 && lane == 0) {
+        s_sc[32 + wave * 2] = sa_all;
+        s_sc[33 + wave * 2] = sg_all;
       }
     }
     lds_barrier();
@@ -909,18 +936,20 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   // =============================== dH1 = dZ1 K1^T ============================================
   BNF_MARK(a, 7);
   zero_acc();
-  {
-    const LaneCtx L = lane_ctx();
-    panel_contract<kPitchB, RT>(acc, L.prow, wbl(1), 2 * cs, KS1, L.lane, ring, [](int) {});
-  }
+  contract_all(wbl(1));
   BNF_MARK(a, 8);
-  const LaneCtx L2 = lane_ctx();
+  const LaneCtx L2 = lane_ctx(0);
   l0_weights(L2);                         // first operands of the A0 recomputation, in flight across the barrier
   lds_barrier();     // every wave is done reading dZ1: the panel is overwritten with dZ0 (and s_col / s_sc reused)
 
   // ---- dZ0 = gamma0 (dH1 / sqrt W) act'(A0), A0 recomputed per 32-row block ----------------
-  {
-    const LaneCtx& L = L2;
+  float sa0_all = 0.f, sg0_all = 0.f;
+#pragma unroll
+  for (int hc = 0; hc < CH; ++hc) {
+    const int cbase = slab(hc) * 64;
+    f32x16 (&acc)[RT][2] = accs[hc];
+    const LaneCtx L = (hc == 0) ? L2 : lane_ctx(hc);
+    if (hc > 0) l0_weights(L);
     const int lane = L.lane, frow = L.frow, kg = L.kg;
     // as in the dZ1 epilogue: dZ0 = z = dH1 (gamma0 / sqrt W) act'(A0) formed directly from the raw
     // accumulator; sa2 = sum raw (elu - tanh + 2) with sacc = sum raw taking the "+ 2" back out,
@@ -974,10 +1003,10 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
           asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(sacc), "+v"(cs2[0]), "+v"(cs2[1]));
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (j == 0 && i > 0) block_to_global(L, a.dZ[0], i - 1);   // (deferred: see the layer-0 forward)
+        if (j == 0 && i > 0) block_to_global(L, a.dZ[0], i - 1, cbase);   // (deferred: see the layer-0 forward)
       }
     }
-    block_to_global(L, a.dZ[0], RT - 1);
+    block_to_global(L, a.dZ[0], RT - 1, cbase);
     BNF_MARK(a, 9);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -985,11 +1014,11 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
       c += __shfl_xor(c, 32, 64);
       if (lane < 32) s_col[rb * W + cbase + j * 32 + lane] = c;
     }
-    const float sa = wave_sum(inv_sw * ((sa2.x + sa2.y) - 2.f * (sacc.x + sacc.y)));
-    const float sg = wave_sum((kLn2 / gamma0) * (sg2.x + sg2.y));
-    if (lane == 0) {
-      s_sc[32 + wave * 2] = sa;
-      s_sc[33 + wave * 2] = sg;
+    sa0_all += wave_sum(inv_sw * ((sa2.x + sa2.y) - 2.f * (sacc.x + sacc.y)));
+    sg0_all += wave_sum((kLn2 / gamma0) * (sg2.x + sg2.y));
+    if (hc == CH - 1 && lane == 0) {
+      s_sc[32 + wave * 2] = sa0_all;
+      s_sc[33 + wave * 2] = sg0_all;
     }
   }
   int4 md_red = {0, 0, 0, 0};   // fused featurisation backward: column table entry of the final reduction (wave 0)
@@ -1003,13 +1032,14 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     const int ct = a.Fp / 32;                     // column tiles of dH0
     const int n_t = (BM / 32) * ct;
     float* dh0 = a.dH0t + (int64_t)e * a.dh0_batch;
-    bf16x8 fb[KS1];
-    auto load_b = [&](int t) {
-      const char* bp = wb0 + (size_t)(t % ct) * KS1 * 1024 + lane * 16;
+    constexpr int KC = KS1 < 32 ? KS1 : 32;       // weight fragments in registers at a time (128 registers)
+    bf16x8 fb[KC];
+    auto load_b = [&](int t, int k0) {
+      const char* bp = wb0 + ((size_t)(t % ct) * KS1 + k0) * 1024 + lane * 16;
 #pragma unroll
-      for (int u = 0; u < KS1; ++u) fb[u] = *reinterpret_cast<const bf16x8*>(bp + (size_t)u * 1024);
+      for (int u = 0; u < KC; ++u) fb[u] = *reinterpret_cast<const bf16x8*>(bp + (size_t)u * 1024);
     };
-    load_b(wave);   // (n_t >= 8: BM >= 128 rows and Fp >= 64 -- every wave has a first tile)
+    load_b(wave, 0);   // (unconditional: a wave without a first tile -- 64-row panels -- loads a tile it never uses)
     // fused featurisation backward: the column table entries of this wave's first tile and of the final
     // reduction (wave 0: one column per lane), in flight across the barrier like the weights
     int4 md_first = {0, 0, 0, 0};
@@ -1041,17 +1071,20 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
     }
     for (int t = wave; t < n_t; t += 8) {
       const int mi = t / ct, ni = t - mi * ct;
-      if (t != wave) load_b(t);
       const char* ap = smem + (mi * 32 + frow) * kPitchB + kg * 16;
       f32x16 c0, c1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
 #pragma unroll
-      for (int u = 0; u < KS1; u += 2) {
-        const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(ap + u * 32);
-        const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(ap + (u + 1) * 32);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb[u], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb[u + 1], c1, 0, 0, 0);
+      for (int k0 = 0; k0 < KS1; k0 += KC) {
+        if (t != wave || k0 != 0) load_b(t, k0);
+#pragma unroll
+        for (int u = 0; u < KC; u += 2) {
+          const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(ap + (k0 + u) * 32);
+          const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(ap + (k0 + u + 1) * 32);
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb[u], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb[u + 1], c1, 0, 0, 0);
+        }
       }
       if constexpr (H0L) {
         if (a.fbmeta) {
@@ -1081,7 +1114,7 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
           s2 += __shfl_xor(s2, 32, 64);
           if (lane < 32) {   // this wave is the only writer of (mi, f)
             s_col[W + mi * 64 + f] = s1 * inv_sf;
-            s_col[W + 256 + mi * 64 + f] = s2 * inv_sf;
+            s_col[W + (BM / 32) * 64 + mi * 64 + f] = s2 * inv_sf;
           }
           continue;          // dH0^T itself is not needed any more
         }
@@ -1096,13 +1129,17 @@ __global__ __launch_bounds__(512, RT == 4 ? 2 : 4) void k_panel_fwd_bwd(const Pa
   BNF_MARK(a, 11);
   if constexpr (H0L) {
     if (a.fbmeta) {
-      static_assert(!H0L || (BM == 128 && W >= 512), "fused featurisation backward: 4 row tiles x 64 columns in s_col[W..2W)");
+      static_assert(!H0L || (RB == 1 && W >= 512), "fused featurisation backward: BM / 32 row tiles x 64 columns, twice, in s_col[W..2W)");
       lds_barrier();
       if (wave == 0) {
         const int f = opaque_lane(tid) & 63;
         const int4 md = md_red;
-        const float t1 = (s_col[W + f] + s_col[W + 64 + f]) + (s_col[W + 128 + f] + s_col[W + 192 + f]);
-        const float t2 = (s_col[W + 256 + f] + s_col[W + 320 + f]) + (s_col[W + 384 + f] + s_col[W + 448 + f]);
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < BM / 32; ++mi) {
+          t1 += s_col[W + mi * 64 + f];
+          t2 += s_col[W + (BM / 32) * 64 + mi * 64 + f];
+        }
         const int kind = md.x & 0xff, g = (md.x >> 8) & 0xff, d1 = (md.x >> 16) & 0xff, d2 = (md.x >> 24) & 0xff;
         const float sp_in = sp_in_u;
         if (g < BNF_MAX_GROUPS) atomicAdd(&s_grp[g], t1);                       // LDS atomics

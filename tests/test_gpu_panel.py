@@ -159,7 +159,9 @@ def test_weight_gradient_stream_kernels_match_the_two_stage_kernel(n_rows, monke
 
 
 @pytest.mark.parametrize('width,depth,n_rows,obs', [(512, 3, 300, 'NORMAL'), (512, 4, 1000, 'NORMAL'), (256, 4, 700, 'NORMAL'),
-                                                    (256, 3, 300, 'NB'), (512, 5, 260, 'ZINB')])
+                                                    (256, 3, 300, 'NB'), (512, 5, 260, 'ZINB'),
+                                                    # width 1024: 64-row panels, two 64-column slabs per wave (C4's shape class)
+                                                    (1024, 2, 300, 'NORMAL'), (1024, 4, 700, 'NORMAL'), (1024, 3, 200, 'ZINB')])
 def test_deep_panel_step_vs_oracle_and_layer_pipeline(width, depth, n_rows, obs):
   """Depth > 2 through the row-panel kernel (round 3: the middle layers' contractions run out of the same LDS
   panel, their pre-activations are parked in HBM in the owning wave's register order and read back by the same
@@ -218,3 +220,22 @@ def test_deep_panel_vi_step_and_training():
   np.testing.assert_allclose(res['panel'][1], res['layers'][1], rtol=5e-3)
   assert np.all(np.isfinite(res['panel'][2])) and np.abs(res['panel'][2] - res['layers'][2]).max() < 0.05
   np.testing.assert_allclose(res['auto'][1], res['panel'][1], rtol=1e-4)      # auto = panel for this shape
+
+
+def test_width_1024_panel_without_the_lds_feature_panel(monkeypatch):
+  """The width-1024 variant also exists without the staged feature panel / fused featurisation backward
+  (BNF_PANEL_NO_H0L, what a feature count above 64 selects): same gradients as with it."""
+  n_rows, E = 300, 2
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=1024, depth=3)
+  theta = util.random_theta(model, E, scale=0.3)
+  g = {}
+  for flag in ('0', '1'):
+    if flag == '1':
+      monkeypatch.setenv('BNF_PANEL_NO_H0L', '1')
+    eng = _engine(net, X, y, members=E, compute_dtype='bf16', pipeline='panel')
+    eng.set_params(theta)
+    g[flag] = eng.debug_loss_and_grad()
+    eng.close()
+  np.testing.assert_allclose(g['0'][0], g['1'][0], rtol=1e-4)
+  bad = {k: v for k, v in _leaf_errs(model, g['0'][1], g['1'][1]).items() if v > 1.5e-2}
+  assert not bad, bad
