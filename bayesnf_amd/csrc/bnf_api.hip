@@ -426,7 +426,7 @@ static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep
       if (g.splitk < 1) g.splitk = 1;
       static uint64_t attr_done = 0;
       allow_lds(h, &gemm_tn_ring<TAG>, kRgLds, &attr_done);
-      const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
+      const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk * (g.n_multi > 1 ? g.n_multi : 1));
       EpiArgs ep2 = ep;
       ep2.ablate = h->ablate;
       LaunchScope ls(h, kid, st, true);
@@ -598,8 +598,40 @@ static void wgrad_join(bnf_handle* h) {
   }
 }
 
+// the W x W weight gradients of layers 1 .. L-1 as ONE launch of the ring kernel (same shape, same split-K = 1):
+// 3 x 320 tiles at C3/8 are 4 rounds of the chip instead of 3 x 2
+static bool wgrad_multi_ok(const bnf_handle* h, int nmem) {
+  if (!h->bf16 || h->L < 3 || h->overlap || getenv("BNF_WGRAD_NO_MULTI")) return false;
+  for (int l = 1; l < h->L; ++l) {
+    const WgradPlan p = wgrad_plan(h, nmem, l);
+    if (p.kind != WG_RING || p.splitk != 1) return false;
+  }
+  // only where it saves rounds of the chip (C3/8: 3 x 320 tiles = 4 rounds instead of 6, +6.6 % on the step; C4/8:
+  // 3 x 512 tiles = 6 rounds either way and the merged launch measured 1 % slower -- gpurun_out/r03q)
+  const int64_t units = (int64_t)nmem * (h->W / 256) * (h->W / 256), cus = h->num_cus, n = h->L - 1;
+  return (n * units + cus - 1) / cus < n * ((units + cus - 1) / cus);
+}
 template <typename T>
 static void run_wgrad(bnf_handle* h, int nmem) {
+  if constexpr (sizeof(T) == 2) {
+    if (wgrad_multi_ok(h, nmem)) {
+      wgrad_after_dz<T>(h, nmem, 0);
+      const int64_t Bp = h->Bp;
+      GemmArgs g{};
+      g.a_ld = h->W; g.a_batch = Bp * h->W; g.b_ld = h->W; g.b_batch = Bp * h->W;
+      g.M = h->W; g.N = h->W; g.K = (int)Bp; g.members = nmem; g.splitk = 1;
+      g.n_multi = h->L - 1;
+      for (int l = 1; l < h->L; ++l) {
+        g.A_multi[l - 1] = h->H[l - 1]; g.B_multi[l - 1] = h->dZ[l]; g.off_out_multi[l - 1] = h->nd.off_kernel[l];
+      }
+      g.A = g.A_multi[0]; g.B = g.B_multi[0];
+      EpiArgs ep{};
+      ep.scale = 1.0f / sqrtf((float)h->Wt);
+      ep.grad = h->gradf; ep.grad_stride = h->Pf; ep.off_out = h->nd.off_kernel[1]; ep.ld_f32 = h->W;
+      launch_gemm_tn<T, 1>(h, KID_WGRAD, g, ep, h->stream, WG_RING);
+      return;
+    }
+  }
   for (int l = 0; l < h->L; ++l) wgrad_after_dz<T>(h, nmem, l);
   wgrad_join(h);
 }
@@ -985,6 +1017,15 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   a.bc2 = (float)(1.0 - std::pow(0.999, (double)t));
   a.kl_weight = kl; a.loss = loss; a.loss_stride = loss_stride; a.apply = apply ? 1 : 0;
   a.gmu_out = gmu_out; a.grho_out = grho_out; a.ext_eps = h->ext_eps; a.jn = jn; a.z = h->theta_c;
+  // the Dense kernels whose gradient the next step's weight-gradient kernel stores (split-K = 1) need no clearing
+  a.n_keep = 0;
+  if (!h->pad && !h->adam_clear_all && h->ablate == 0)
+    for (int l = 0; l < h->L; ++l)
+      if (wgrad_splitk(h, h->Ev, l) == 1) {
+        a.keep_lo[a.n_keep] = h->nd.off_kernel[l];
+        a.keep_hi[a.n_keep] = h->nd.off_kernel[l] + ((l == 0) ? h->F : h->W) * h->W;
+        ++a.n_keep;
+      }
   {
     LaunchScope ls(h, KID_VIADAM);
     dim3 grid(cdiv(h->P, 256), (unsigned)E);
@@ -1845,6 +1886,8 @@ double bnf_kernel_flops(const bnf_handle* h, const char* name) {
   const double Ev = h->Ev, B = (double)h->B, W = h->Wt, F = h->F;
   if (!strcmp(name, "gemm_fwd_l0") || !strcmp(name, "gemm_dgrad0") || !strcmp(name, "gemm_wgrad_l0"))
     return 2.0 * Ev * B * F * W;
+  if (!strcmp(name, "gemm_wgrad") && h->panel && wgrad_multi_ok(h, h->Ev))   // one launch for the layers 1 .. L-1
+    return 2.0 * Ev * B * W * W * (h->L - 1);
   if (!strcmp(name, "gemm_fwd") || !strcmp(name, "gemm_dgrad") || !strcmp(name, "gemm_wgrad"))
     return 2.0 * Ev * B * W * W;
   if (!strcmp(name, "gemm_fwd_last"))   // last hidden layer + output-layer dot

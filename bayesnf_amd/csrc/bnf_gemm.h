@@ -40,6 +40,11 @@ struct GemmArgs {
   int32_t a_ld, b_ld;
   int32_t M, N, K;  // K: multiple of the tile depth, zero padded
   int32_t tiles_m, tiles_n, splitk, members;
+  // gemm_tn_ring only: n_multi > 1 = that many contractions of the SAME shape in one launch (the W x W weight
+  // gradients of every layer above layer 0: one launch fills the chip's last round once instead of once per layer)
+  int32_t n_multi;
+  const void* A_multi[BNF_MAX_LAYERS]; const void* B_multi[BNF_MAX_LAYERS];
+  int32_t off_out_multi[BNF_MAX_LAYERS];
 };
 
 struct EpiArgs {
@@ -1371,23 +1376,30 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const E
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  const uint32_t per_member = (uint32_t)(g.tiles_m * g.tiles_n * g.splitk);
+  const int n_multi = g.n_multi > 1 ? g.n_multi : 1;
+  const uint32_t per_layer = (uint32_t)(g.tiles_m * g.tiles_n * g.splitk);
+  const uint32_t per_member = per_layer * (uint32_t)n_multi;
   uint32_t w = xcd_remap(blockIdx.x, gridDim.x);
   const int e = (int)(w / per_member);
   w -= (uint32_t)e * per_member;
+  const int which = (int)(w / per_layer);      // which of the n_multi contractions
+  w -= (uint32_t)which * per_layer;
   const int tiles = g.tiles_m * g.tiles_n;
   const int split = (int)(w / (uint32_t)tiles);
   w -= (uint32_t)split * tiles;
   const int tm = (int)(w / (uint32_t)g.tiles_n), tn = (int)(w % (uint32_t)g.tiles_n);
   const int m0 = tm * 256, n0 = tn * 256;
+  const void* gA = g.n_multi > 1 ? g.A_multi[which] : g.A;
+  const void* gB = g.n_multi > 1 ? g.B_multi[which] : g.B;
+  const int32_t off_out = g.n_multi > 1 ? g.off_out_multi[which] : ep.off_out;
 
   const int nk_total = g.K / kRgRows;
   const int nk_per = (nk_total + g.splitk - 1) / g.splitk;
   const int kt0 = split * nk_per;
   const int kt1 = min(nk_total, kt0 + nk_per);
 
-  const char* Ab = reinterpret_cast<const char*>(g.A) + (int64_t)e * g.a_batch * 2 + m0 * 2;
-  const char* Bb = reinterpret_cast<const char*>(g.B) + (int64_t)e * g.b_batch * 2 + n0 * 2;
+  const char* Ab = reinterpret_cast<const char*>(gA) + (int64_t)e * g.a_batch * 2 + m0 * 2;
+  const char* Bb = reinterpret_cast<const char*>(gB) + (int64_t)e * g.b_batch * 2 + n0 * 2;
 
   uint32_t src_a[2], src_b[2];
 #pragma unroll
@@ -1532,7 +1544,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const E
   const int mw = m0 + wr * 128 + 4 * kg;
   const int nw = n0 + wc * 64 + frow;
   float* out = ep.out_f32 ? ep.out_f32 + (int64_t)e * ep.f32_batch
-                          : ep.grad + (int64_t)e * ep.grad_stride + ep.off_out;
+                          : ep.grad + (int64_t)e * ep.grad_stride + off_out;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = nw + j * 32;

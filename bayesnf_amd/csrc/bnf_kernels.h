@@ -785,6 +785,8 @@ struct ViAdamArgs {
   JaxNoise jn;                      // the reference's stream when jn.keys != null
   const float* z;                   // (members*S, P) the samples k_vi_sample wrote for this step (theta_c): the noise is
                                     // recovered from them as (z - mu) / sigma instead of being generated a second time
+  int32_t n_keep;                   // parameter ranges whose sample gradients the next step STORES (weight-gradient
+  int32_t keep_lo[BNF_MAX_LAYERS], keep_hi[BNF_MAX_LAYERS];   // kernels without split-K): not cleared here
 };
 
 __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
@@ -803,6 +805,8 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
     // z_s = mu + sigma eps_s in theta_c and nothing has written it since, so eps_s = (z_s - mu) / sigma --
     // exact up to the rounding of z_s (|z| 6e-8 / sigma absolute on a unit normal).
     const float inv_sig = 1.0f / sig;
+    bool clear = a.apply != 0;
+    for (int k = 0; k < a.n_keep; ++k) clear = clear && !(p >= a.keep_lo[k] && p < a.keep_hi[k]);
     for (int s0 = 0; s0 < a.S; s0 += 4) {
       float gl[4], zs[4];   // the four likelihood gradients and samples in flight together
 #pragma unroll
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
         // both from u = exp(-|z|)
         const float u = hw_exp_neg_abs(z);
         const float g = gl[k] + copysignf((1.f - u) * __builtin_amdgcn_rcpf(1.f + u), z);
-        if (a.apply) a.grad[gi] = 0.f;
+        if (clear) a.grad[gi] = 0.f;
         gmu += g;
         grho += g * eps;
         e2 += eps * eps;

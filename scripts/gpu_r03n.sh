@@ -1,6 +1,6 @@
 #!/bin/bash
 # r03 visit N: DEEP template + ring split-K plan: tests, C3 over BNF_RING_SPLITK, C2 A/B
-set -u
+set -u; ulimit -c 0
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/${1:-r03n}; mkdir -p "$OUT"; cd "$ROOT"
 echo "== pytest all"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > "$OUT/pytest.txt" 2>&1; echo "rc=$?"; tail -6 "$OUT/pytest.txt"
 cfg() { timeout 300 python scripts/bench_configs.py $2 2>/dev/null | python -c "import sys,json
