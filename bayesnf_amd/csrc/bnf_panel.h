@@ -146,6 +146,9 @@ __global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ t
   }
 }
 
+#ifndef BNF_EPI_FENCE_EVERY
+#define BNF_EPI_FENCE_EVERY 1   // scheduling fence after every 4-row group of an epilogue (2: after every second one)
+#endif
 #ifndef BNF_PANEL_PRIO
 #define BNF_PANEL_PRIO 0
 #endif
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
           float* dst = s_dot + (ii * 32 + 8 * rg + 4 * kg) * kRowDotPitch + frow;
 #pragma unroll
           for (int q = 0; q < 4; ++q) dst[q * kRowDotPitch] = pd[q];
-          __builtin_amdgcn_sched_barrier(0);
+          if (BNF_EPI_FENCE_EVERY == 1 || (rg & 1)) __builtin_amdgcn_sched_barrier(0);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
         }
         asm volatile("" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sg[0]), "+v"(sg[1]), "+v"(cp[0]), "+v"(cp[1]),
                      "+v"(ck[0]), "+v"(ck[1]));
-        __builtin_amdgcn_sched_barrier(0);
+        if (BNF_EPI_FENCE_EVERY == 1 || (rg & 1)) __builtin_amdgcn_sched_barrier(0);
         if (rg == 1 && i > 0) block_to_global(L, a.dZ[LL], i - 1, cbase);   // (deferred: see the layer-0 forward)
       }
     block_to_global(L, a.dZ[LL], RT - 1, cbase);
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
             if (!BNF_ABL(a, 4)) store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, z.x, z.y);
           }
           asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(sacc), "+v"(cs2[0]), "+v"(cs2[1]));
-          __builtin_amdgcn_sched_barrier(0);
+          if (BNF_EPI_FENCE_EVERY == 1 || (rg & 1)) __builtin_amdgcn_sched_barrier(0);
         }
         if (j == 0 && i > 0) block_to_global(L, a.dZ[0], i - 1, cbase);   // (deferred: see the layer-0 forward)
       }
