@@ -533,10 +533,20 @@ static WgradPlan wgrad_plan(const bnf_handle* h, int nmem, int l) {
   const int sk = (1024 + nmem * tiles - 1) / (nmem * tiles);
   const int base_sk = std::max(1, std::min(sk, std::max(1, nk / 4)));
   if (h->bf16 && l == 0 && h->skinny && a_ld == 64 && N % 512 == 0 && K % 64 == 0) {
-    // layer 0 as a 64 x 512 row stream, one workgroup per CU (144 KiB of LDS): split K until the chip is full
+    // layer 0 as a 64 x 512 row stream, one workgroup per CU (144 KiB of LDS): the K split with the shortest
+    // schedule -- rounds of the chip x rows per workgroup (C3/8, 80 members: 3 splits = 240 workgroups in one round
+    // instead of 4 = 320 in two, the second a quarter full); ties go to the fewest splits (fewest atomics)
     const int64_t base = (int64_t)nmem * (N / 512);
     const int nks = (int)(K / kSkRows);
-    return {WG_SKINNY, (int)std::max<int64_t>(1, std::min<int64_t>((h->num_cus + base - 1) / base, std::max(1, nks / 8)))};
+    const int max_s = (int)std::max<int64_t>(1, std::min<int64_t>((h->num_cus + base - 1) / base, std::max(1, nks / 8)));
+    int best = 1;
+    double best_cost = 1e30;
+    for (int sp = 1; sp <= max_s; ++sp) {
+      const int64_t rounds = (base * sp + h->num_cus - 1) / h->num_cus;
+      const double cost = (double)rounds * (double)((nks + sp - 1) / sp);
+      if (cost < best_cost * 0.98) { best_cost = cost; best = sp; }
+    }
+    return {WG_SKINNY, best};
   }
   // 256 x 256 tiles when they still fill the chip (members x tiles >= half the CUs)
   if (h->big_tiles && M % 256 == 0 && N % 256 == 0) {
@@ -755,9 +765,7 @@ static void run_backward(bnf_handle* h, const float* theta, int nmem, const RowS
 // ---------------------------------------------------------------------------
 // fragment-major weights for the row-panel kernel
 // ---------------------------------------------------------------------------
-template <typename T>
-static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
-  LaunchScope ls(h, KID_PACK);
+static PackJobs pack_jobs(const bnf_handle* h, int* n_tiles) {
   PackJobs jb{};
   jb.n_layers = h->L; jb.W = h->W;
   int tiles = 0;
@@ -770,6 +778,14 @@ static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
     jb.wf[l] = h->Wf[l]; jb.wb[l] = h->Wb[l]; jb.batch[l] = h->pack_batch[l];
   }
   jb.tile0[h->L] = tiles;
+  *n_tiles = tiles;
+  return jb;
+}
+template <typename T>
+static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
+  LaunchScope ls(h, KID_PACK);
+  int tiles = 0;
+  const PackJobs jb = pack_jobs(h, &tiles);
   hipLaunchKernelGGL((k_pack_layers<T>), dim3((unsigned)tiles, (unsigned)nmem), dim3(256), 0, h->stream,
                      theta, (int64_t)h->Pf, jb, h->nd, h->scal);
 }
@@ -946,7 +962,7 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
   a.apply = apply ? 1 : 0; a.loss_raw = sink.raw; a.st = sink.st;
   // the largest hidden-layer kernel whose gradient the next step stores (no split-K) is not cleared
   a.keep_lo = a.keep_hi = 0;
-  if (!h->pad && h->P % 4 == 0 && !h->adam_clear_all && h->ablate == 0)
+  if (!h->pad && !h->adam_clear_all && h->ablate == 0)
     for (int l = 1; l < h->L; ++l)
       if (wgrad_splitk(h, E, l) == 1 && a.keep_hi == 0) {
         a.keep_lo = (h->nd.off_kernel[l] + 3) / 4 * 4;
@@ -954,13 +970,7 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
       }
   {
     LaunchScope ls(h, KID_ADAM);
-    if (h->P % 4 == 0) {
-      hipLaunchKernelGGL((k_adam_map<4>), dim3(cdiv(h->P / 4, 256), (unsigned)E), dim3(256), 0,
-                         h->stream, a);
-    } else {
-      hipLaunchKernelGGL((k_adam_map<1>), dim3(cdiv(h->P, 256), (unsigned)E), dim3(256), 0,
-                         h->stream, a);
-    }
+    hipLaunchKernelGGL(k_adam_map, dim3(cdiv(cdiv(h->P, 4), 256), (unsigned)E), dim3(256), 0, h->stream, a);
   }
   if (apply) h->adam_t = t;
   return BNF_OK;
@@ -988,7 +998,7 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
                 (long long)h->adam_t, (long long)h->vi_key_rows, (long long)h->vi_key_t0);
   {
     LaunchScope ls(h, KID_VISAMPLE);
-    dim3 grid(cdiv(h->P, 256), (unsigned)E, (unsigned)((S + 3) / 4));
+    dim3 grid(cdiv(cdiv(h->P, 4), 256), (unsigned)E, (unsigned)((S + 3) / 4));
     hipLaunchKernelGGL(k_vi_sample, grid, dim3(256), 0, h->stream, mu, rho, h->P, S, h->cfg.seed,
                        h->cfg.member_offset, (uint64_t)step, (uint32_t)STREAM_VI_EPS, h->theta_c,
                        (int64_t)S * h->P, (int64_t)h->P, h->ext_eps, jn);
@@ -1028,7 +1038,7 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
       }
   {
     LaunchScope ls(h, KID_VIADAM);
-    dim3 grid(cdiv(h->P, 256), (unsigned)E);
+    dim3 grid(cdiv(cdiv(h->P, 4), 256), (unsigned)E);
     hipLaunchKernelGGL(k_vi_adam, grid, dim3(256), 0, h->stream, a);
   }
   if (apply) h->adam_t = t;
@@ -1438,7 +1448,7 @@ int bnf_vi_posterior_draws(bnf_handle* h, int32_t n_draws, float* out) {
   if (n_draws < 1 || n_draws > 65535 || !out) return fail(BNF_ERR_INVALID, "n_draws/out");
   HIPCHK(hipSetDevice(h->cfg.device));
   const int E = h->cfg.members;
-  dim3 grid(cdiv(h->P, 256), (unsigned)E, (unsigned)((n_draws + 3) / 4));
+  dim3 grid(cdiv(cdiv(h->P, 4), 256), (unsigned)E, (unsigned)((n_draws + 3) / 4));
   JaxNoise jn{};
   if (h->vi_draw_keys) {
     if (n_draws > h->vi_draw_rows) return fail(BNF_ERR_INVALID, "n_draws exceeds the draw-key table");

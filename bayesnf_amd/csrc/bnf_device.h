@@ -137,6 +137,34 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
   *reinterpret_cast<u32x4*>(p) = w;
 }
 
+// 4 consecutive floats at ANY 4-byte aligned address (gfx950 global memory takes dword-aligned
+// dwordx4 accesses; hipcc emits global_load/store_dwordx4 for this type).  The row stride of the
+// parameter-shaped arrays (P floats per member) is not a multiple of 4 in general, and a 16-byte access
+// per lane streams at ~2x the rate of a 4-byte one (MI355X_MICROARCH.md: 8-byte accesses reach
+// 0.54 - 0.70 of the 16-byte rate).  nv < 4: the row's tail, element by element.
+typedef f32x4 __attribute__((aligned(4))) f32x4u;
+__device__ __forceinline__ void load4u(const float* p, int nv, float (&o)[4]) {
+  if (nv >= 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4u*>(p);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (k < nv) ? p[k] : 0.f;
+  }
+}
+template <bool NT = false>
+__device__ __forceinline__ void store4u(float* p, int nv, const float (&v)[4]) {
+  if (nv >= 4) {
+    const f32x4 w = {v[0], v[1], v[2], v[3]};
+    if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<f32x4u*>(p));
+    else *reinterpret_cast<f32x4u*>(p) = w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nv) p[k] = v[k];
+  }
+}
+
 // raw (undecoded) vectors: issue the load early, decode at the point of use so
 // the compiler does not have to wait for the data right after the load
 struct RawF4 { f32x4 v; };

@@ -661,31 +661,28 @@ __global__ void k_step_advance(StepState* st) {
 #ifndef BNF_ADAM_NT
 #define BNF_ADAM_NT 1
 #endif
-template <int VEC>
+// A thread owns four consecutive parameters (16-byte accesses at any 4-byte aligned address: load4u);
+// the last thread of a member takes the P % 4 tail element by element.
 __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
   __shared__ float red[4];
   const int e = blockIdx.y;
-  const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const float bc1 = a.st ? a.st->bc1 : a.bc1, bc2 = a.st ? a.st->bc2 : a.bc2;
   float lp = 0.f;
   if (p0 < a.P) {
+    const int nv = min(4, a.P - p0);
     const int64_t i0 = (int64_t)e * a.stride + p0;
-    float th[VEC], g[VEC], m[VEC], v[VEC];
-    if constexpr (VEC == 4) {
-      load4(a.theta + i0, th); load4(a.grad + i0, g);
-      if (a.apply) { load4(a.m + i0, m); load4(a.v + i0, v); }
-    } else {
-      th[0] = a.theta[i0]; g[0] = a.grad[i0];
-      if (a.apply) { m[0] = a.m[i0]; v[0] = a.v[i0]; }
-    }
+    float th[4], g[4], m[4], v[4];
+    load4u(a.theta + i0, nv, th); load4u(a.grad + i0, nv, g);
+    if (a.apply) { load4u(a.m + i0, nv, m); load4u(a.v + i0, nv, v); }
     // One hardware exp2 / log2 / rcp / sqrt each (1 ulp) instead of the libm tanhf, expf + log1pf and
     // the IEEE divide / sqrt sequences: 246 VALU instructions per element made this kernel VALU-bound
     // (profiles/r02z_mfma_valu_counters.md: VALU busy ~100 %, 4.2 TB/s); with e = exp(-|z|):
     //   tanh(z / 2) = sign(z) (1 - e) / (1 + e),   log Logistic(z) = -z - 2 softplus(-z) = -|z| - 2 log1p(e)
     const float ibc1 = 1.0f / bc1, ibc2 = 1.0f / bc2;
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      if (a.prior_weight != 0.f) {
+    for (int k = 0; k < 4; ++k) {
+      if (a.prior_weight != 0.f && k < nv) {
         const float z = th[k] - ((p0 + k) == a.off_shape ? -1.5f : 0.f);
         const float az = fabsf(z);
         const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * az);
@@ -700,23 +697,13 @@ __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
         g[k] = 0.f;  // ready for the next step's atomics
       }
     }
-    if constexpr (VEC == 4) {
-      if (!(a.apply && p0 >= a.keep_lo && p0 < a.keep_hi)) store4(a.grad + i0, g[0], g[1], g[2], g[3]);
-      if (a.apply) {
-        store4(a.theta + i0, th[0], th[1], th[2], th[3]);
-#if BNF_ADAM_NT
-        // the moments are touched once per step: written through, they do not sit dirty in the memory-side
-        // cache while the next kernels stream
-        __builtin_nontemporal_store(f32x4{m[0], m[1], m[2], m[3]}, reinterpret_cast<f32x4*>(a.m + i0));
-        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(a.v + i0));
-#else
-        store4(a.m + i0, m[0], m[1], m[2], m[3]);
-        store4(a.v + i0, v[0], v[1], v[2], v[3]);
-#endif
-      }
-    } else {
-      a.grad[i0] = g[0];
-      if (a.apply) { a.theta[i0] = th[0]; a.m[i0] = m[0]; a.v[i0] = v[0]; }
+    if (!(a.apply && p0 >= a.keep_lo && p0 < a.keep_hi)) store4u(a.grad + i0, nv, g);
+    if (a.apply) {
+      store4u(a.theta + i0, nv, th);
+      // the moments are touched once per step: written through (non-temporal), they do not sit dirty in the
+      // memory-side cache while the next kernels stream
+      store4u<BNF_ADAM_NT != 0>(a.m + i0, nv, m);
+      store4u<BNF_ADAM_NT != 0>(a.v + i0, nv, v);
     }
   }
   const float s = wave_sum(lp);
@@ -751,25 +738,45 @@ __global__ __launch_bounds__(256) void k_vi_sample(const float* __restrict__ mu,
                                                    float* __restrict__ z, int64_t z_member_stride,
                                                    int64_t z_sample_stride, const float* __restrict__ ext_eps = nullptr,
                                                    JaxNoise jn = JaxNoise{}) {
-  // grid: (ceil(P/256), members, ceil(S/4)): one Philox call serves the four samples of a group
+  // grid: (ceil(ceil(P/4)/256), members, ceil(S/4)): a thread serves four consecutive parameters (16-byte
+  // accesses: load4u / store4u) x the four samples of a group -- one Philox call per parameter and group
   const int e = blockIdx.y, s0 = blockIdx.z * 4;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  const int64_t i = (int64_t)e * P + p;
-  const float m = mu[i], sg = vi_sigma(rho[i]);
-  Normal4 n4 = vi_eps4(seed, (uint32_t)(member_offset + e), (uint32_t)blockIdx.z, (uint32_t)p, step, stream);
+  const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (p0 >= P) return;
+  const int nv = min(4, P - p0);
+  const int64_t i = (int64_t)e * P + p0;
+  float m[4], sg[4];
+  load4u(mu + i, nv, m);
+  load4u(rho + i, nv, sg);
+  Normal4 n4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sg[k] = vi_sigma(sg[k]);
+    n4[k] = vi_eps4(seed, (uint32_t)(member_offset + e), (uint32_t)blockIdx.z, (uint32_t)(p0 + k), step, stream);
+  }
   if (ext_eps) {   // bnf_debug_vi_noise: the caller's standard normals, (members, S, P)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) n4.v[k] = ext_eps[((int64_t)e * S + min(s0 + k, S - 1)) * P + p];
+    for (int ks = 0; ks < 4; ++ks) {
+      float ev[4];
+      load4u(ext_eps + ((int64_t)e * S + min(s0 + ks, S - 1)) * P + p0, nv, ev);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) n4[k].v[ks] = ev[k];
+    }
   } else if (jn.keys) {   // the reference's stream (jaxseed.vi_noise_keys)
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (s0 + k < S) n4.v[k] = jax_normal(jn, e, s0 + k, p);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        if (k < nv && s0 + ks < S) n4[k].v[ks] = jax_normal(jn, e, s0 + ks, p0 + k);
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (s0 + k < S)
-      z[(int64_t)e * z_member_stride + (int64_t)(s0 + k) * z_sample_stride + p] = m + sg * n4.v[k];
+  for (int ks = 0; ks < 4; ++ks)
+    if (s0 + ks < S) {
+      float zv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) zv[k] = m[k] + sg[k] * n4[k].v[ks];
+      store4u(z + (int64_t)e * z_member_stride + (int64_t)(s0 + ks) * z_sample_stride + p0, nv, zv);
+    }
 }
 
 struct ViAdamArgs {
@@ -790,65 +797,102 @@ struct ViAdamArgs {
 };
 
 __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
+  // grid: (ceil(ceil(P/4)/256), members): a thread owns four consecutive parameters -- every access is 16 bytes
+  // per lane (load4u), which is what this kernel is bound by: at C3/8 it reads 2 x 267 MB of sample gradients and
+  // samples and reads + writes 6 x 53 MB of optimiser state (3.2 TB/s with 4-byte accesses)
   __shared__ float red[4];
   const int e = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   float lterm = 0.f;
-  if (p < a.P) {
-    const int64_t i = (int64_t)e * a.P + p;
-    const float mu = a.mu[i], rho = a.rho[i];
-    const float sig = vi_sigma(rho);
-    const float loc = (p == a.off_shape) ? -1.5f : 0.f;
-    float gmu = 0.f, grho = 0.f, e2 = 0.f, lpr = 0.f;
+  if (p0 < a.P) {
+    const int nv = min(4, a.P - p0);
+    const int64_t i = (int64_t)e * a.P + p0;
+    float mu[4], rho[4], sig[4], inv_sig[4], loc[4];
+    float gmu[4] = {0.f, 0.f, 0.f, 0.f}, grho[4] = {0.f, 0.f, 0.f, 0.f}, e2[4] = {0.f, 0.f, 0.f, 0.f}, lpr[4] = {0.f, 0.f, 0.f, 0.f};
+    load4u(a.mu + i, nv, mu);
+    load4u(a.rho + i, nv, rho);
     // The step's noise is NOT generated a second time (Philox + Box-Muller, or threefry + erfinv for the
     // reference's stream: that was most of this kernel's 0.40 ms at C3/8, VALU-bound): k_vi_sample left
     // z_s = mu + sigma eps_s in theta_c and nothing has written it since, so eps_s = (z_s - mu) / sigma --
     // exact up to the rounding of z_s (|z| 6e-8 / sigma absolute on a unit normal).
-    const float inv_sig = 1.0f / sig;
-    bool clear = a.apply != 0;
-    for (int k = 0; k < a.n_keep; ++k) clear = clear && !(p >= a.keep_lo[k] && p < a.keep_hi[k]);
-    for (int s0 = 0; s0 < a.S; s0 += 4) {
-      float gl[4], zs[4];   // the four likelihood gradients and samples in flight together
+    bool clear[4], all_clear = true, any_clear = false;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int64_t gi = ((int64_t)e * a.S + min(s0 + k, a.S - 1)) * a.P + p;
-        gl[k] = a.grad[gi];
-        zs[k] = a.z[gi];
+    for (int k = 0; k < 4; ++k) {
+      sig[k] = vi_sigma(rho[k]);
+      inv_sig[k] = 1.0f / sig[k];
+      loc[k] = (p0 + k == a.off_shape) ? -1.5f : 0.f;
+      clear[k] = a.apply != 0;
+      for (int r = 0; r < a.n_keep; ++r) clear[k] = clear[k] && !(p0 + k >= a.keep_lo[r] && p0 + k < a.keep_hi[r]);
+      all_clear = all_clear && clear[k];
+      any_clear = any_clear || clear[k];
+    }
+    const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < a.S; s0 += 4) {
+      float gl[4][4], zs[4][4];   // the likelihood gradients and samples of four samples in flight together
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int64_t gi = ((int64_t)e * a.S + min(s0 + ks, a.S - 1)) * a.P + p0;
+        load4u(a.grad + gi, nv, gl[ks]);
+        load4u(a.z + gi, nv, zs[ks]);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int s = s0 + k;
+      for (int ks = 0; ks < 4; ++ks) {
+        const int s = s0 + ks;
         if (s >= a.S) break;
-        const float eps = (zs[k] - mu) * inv_sig;
-        const float z = zs[k] - loc;
-        const int64_t gi = ((int64_t)e * a.S + s) * a.P + p;
-        // Logistic(loc, 1) prior: d(-log p)/dz = tanh(z/2), log p = -z - 2 softplus(-z);
-        // both from u = exp(-|z|)
-        const float u = hw_exp_neg_abs(z);
-        const float g = gl[k] + copysignf((1.f - u) * __builtin_amdgcn_rcpf(1.f + u), z);
-        if (clear) a.grad[gi] = 0.f;
-        gmu += g;
-        grho += g * eps;
-        e2 += eps * eps;
-        lpr += -fabsf(z) - 2.f * hw_log1p_of_exp(u);     // -z - 2 softplus(-z)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float eps = (zs[ks][k] - mu[k]) * inv_sig[k];
+          const float z = zs[ks][k] - loc[k];
+          // Logistic(loc, 1) prior: d(-log p)/dz = tanh(z/2), log p = -z - 2 softplus(-z);
+          // both from u = exp(-|z|)
+          const float u = hw_exp_neg_abs(z);
+          const float g = gl[ks][k] + copysignf((1.f - u) * __builtin_amdgcn_rcpf(1.f + u), z);
+          gmu[k] += g;
+          grho[k] += g * eps;
+          e2[k] += eps * eps;
+          lpr[k] += -fabsf(z) - 2.f * hw_log1p_of_exp(u);     // -z - 2 softplus(-z)
+        }
+        if (any_clear) {
+          float* gp = a.grad + ((int64_t)e * a.S + s) * a.P + p0;
+          if (all_clear) {
+            store4u(gp, nv, zero4);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (k < nv && clear[k]) gp[k] = 0.f;
+          }
+        }
       }
     }
     const float invS = 1.f / (float)a.S;
-    gmu *= invS;
-    grho = hw_sigmoid(rho) * (grho * invS - __builtin_amdgcn_rcpf(sig));
-    // mean_s [ log q(z_s) - log p(z_s) ] for this coordinate
-    lterm = (-0.5f * e2 * invS - 0.69314718055994530942f * __builtin_amdgcn_logf(sig) - 0.918938533204672742f) - lpr * invS;
+    float m1[4], v1[4], m2[4], v2[4];
     if (a.apply) {
-      const float ibc1 = 1.0f / a.bc1, ibc2 = 1.0f / a.bc2;
-      float m = 0.9f * a.m_mu[i] + 0.1f * gmu, v = 0.999f * a.v_mu[i] + 0.001f * gmu * gmu;
-      a.m_mu[i] = m; a.v_mu[i] = v;
-      a.mu[i] = mu - a.lr * (m * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + 1e-8f);
-      m = 0.9f * a.m_rho[i] + 0.1f * grho; v = 0.999f * a.v_rho[i] + 0.001f * grho * grho;
-      a.m_rho[i] = m; a.v_rho[i] = v;
-      a.rho[i] = rho - a.lr * (m * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ibc2) + 1e-8f);
+      load4u(a.m_mu + i, nv, m1); load4u(a.v_mu + i, nv, v1);
+      load4u(a.m_rho + i, nv, m2); load4u(a.v_rho + i, nv, v2);
+    }
+    const float ibc1 = 1.0f / a.bc1, ibc2 = 1.0f / a.bc2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gmu[k] *= invS;
+      grho[k] = hw_sigmoid(rho[k]) * (grho[k] * invS - __builtin_amdgcn_rcpf(sig[k]));
+      // mean_s [ log q(z_s) - log p(z_s) ] for this coordinate
+      if (k < nv)
+        lterm += (-0.5f * e2[k] * invS - 0.69314718055994530942f * __builtin_amdgcn_logf(sig[k]) - 0.918938533204672742f) - lpr[k] * invS;
+      if (a.apply) {
+        m1[k] = 0.9f * m1[k] + 0.1f * gmu[k]; v1[k] = 0.999f * v1[k] + 0.001f * gmu[k] * gmu[k];
+        mu[k] = mu[k] - a.lr * (m1[k] * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v1[k] * ibc2) + 1e-8f);
+        m2[k] = 0.9f * m2[k] + 0.1f * grho[k]; v2[k] = 0.999f * v2[k] + 0.001f * grho[k] * grho[k];
+        rho[k] = rho[k] - a.lr * (m2[k] * ibc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v2[k] * ibc2) + 1e-8f);
+      }
+    }
+    if (a.apply) {
+      store4u(a.mu + i, nv, mu);
+      store4u(a.rho + i, nv, rho);
+      store4u<true>(a.m_mu + i, nv, m1); store4u<true>(a.v_mu + i, nv, v1);     // touched once per step: written through
+      store4u<true>(a.m_rho + i, nv, m2); store4u<true>(a.v_rho + i, nv, v2);
     } else {
-      a.gmu_out[i] = gmu;
-      a.grho_out[i] = grho;
+      store4u(a.gmu_out + i, nv, gmu);
+      store4u(a.grho_out + i, nv, grho);
     }
   }
   const float s = wave_sum(lterm);

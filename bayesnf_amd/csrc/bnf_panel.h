@@ -102,27 +102,13 @@ struct PackJobs {
 };
 // Workgroup 0 of a member also fills the member's row of the transformed-scalar table
 // (k_member_scalars folded in: one launch and one dependent-launch gap less per step).
+// the 8 forward and 8 backward fragments of the 64 x 64 tile of layer l's kernel staged in `tile` (origin k0, n0)
 template <typename T>
-__global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ theta, int64_t theta_stride,
-                                                     PackJobs jb, NetDev nd, float* __restrict__ scal) {
-  __shared__ float tile[64][65];
-  const int e = blockIdx.y;
-  if (scal && blockIdx.x == 0 && threadIdx.x == 0) member_scalars_row(nd, theta + (int64_t)e * theta_stride, scal + (int64_t)e * kScalStride);
-  int l = 0;
-  while (l + 1 < jb.n_layers && (int)blockIdx.x >= jb.tile0[l + 1]) ++l;
-  const int t = (int)blockIdx.x - jb.tile0[l];
-  const int W = jb.W, tn = W / 64;
-  const int k0 = (t / tn) * 64, n0 = (t % tn) * 64;      // tile origin: K rows (fan-in), K columns
-  const float* K = theta + (int64_t)e * theta_stride + jb.off_kernel[l];
-  const int tid = threadIdx.x, lane = tid & 63;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int r = (tid >> 6) + 4 * i;
-    tile[r][lane] = (k0 + r < jb.n_in[l]) ? K[(int64_t)(k0 + r) * W + n0 + lane] : 0.f;
-  }
-  __syncthreads();
-  T* wf = (T*)jb.wf[l] + (int64_t)e * jb.batch[l];
-  T* wb = (T*)jb.wb[l] + (int64_t)e * jb.batch[l];
+__device__ __forceinline__ void pack_tile_fragments(const float (&tile)[64][65], const PackJobs& jb, int l, int64_t e,
+                                                    int k0, int n0, int tid) {
+  const int W = jb.W;
+  T* wf = (T*)jb.wf[l] + e * jb.batch[l];
+  T* wb = (T*)jb.wb[l] + e * jb.batch[l];
   const int KSf = jb.n_pad[l] / 16, KSb = W / 16;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -144,6 +130,37 @@ __global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ t
       store8(wb + (f * 64 + fl) * 8, v);
     }
   }
+}
+__device__ __forceinline__ void pack_tile_of(const PackJobs& jb, int bx, int* l_out, int* k0, int* n0) {
+  int l = 0;
+  while (l + 1 < jb.n_layers && bx >= jb.tile0[l + 1]) ++l;
+  const int t = bx - jb.tile0[l], tn = jb.W / 64;
+  *l_out = l; *k0 = (t / tn) * 64; *n0 = (t % tn) * 64;      // tile origin: K rows (fan-in), K columns
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ theta, int64_t theta_stride,
+                                                     PackJobs jb, NetDev nd, float* __restrict__ scal) {
+  __shared__ float tile[64][65];
+  const int e = blockIdx.y;
+  if (scal && blockIdx.x == 0 && threadIdx.x == 0) member_scalars_row(nd, theta + (int64_t)e * theta_stride, scal + (int64_t)e * kScalStride);
+  int l, k0, n0;
+  pack_tile_of(jb, (int)blockIdx.x, &l, &k0, &n0);
+  const int W = jb.W;
+  const float* K = theta + (int64_t)e * theta_stride + jb.off_kernel[l];
+  const int tid = threadIdx.x;
+  // 16 bytes per lane (K starts at an arbitrary 4-byte aligned offset of the member's parameters: load4u);
+  // sixteen lanes cover a 256-byte row of the tile, a wave four rows per access
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (tid >> 4) + 16 * i, c = (tid & 15) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k0 + r < jb.n_in[l]) load4u(K + (int64_t)(k0 + r) * W + n0 + c, 4, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[r][c + j] = v[j];
+  }
+  __syncthreads();
+  pack_tile_fragments<T>(tile, jb, l, e, k0, n0, tid);
 }
 
 #ifndef BNF_EPI_FENCE_EVERY
