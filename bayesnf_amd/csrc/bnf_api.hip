@@ -192,7 +192,7 @@ static size_t carve(bnf_handle* h, char* base) {
   // no transposed copies (the weight-gradient contraction reads row-major, gemm_tn); the row-panel
   // kernel reads the features as MFMA A fragments from a second, fragment-major copy (H0t slot)
   // (the H0L variant -- W = 512, Fp = 64 -- stages the row-major copy in LDS instead and skips it)
-  h->h0l = h->panel && (h->W == 512 || h->W == 1024) && h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L");
+  h->h0l = h->panel && (((h->W == 512 || h->W == 1024) && h->Fp == 64) || (h->W == 256 && h->Fp == 128)) && !getenv("BNF_PANEL_NO_H0L");
   h->H0t = (h->panel && !h->h0l) ? take((size_t)Ev * Bp * Fp * es) : nullptr;
   for (int l = 0; l < h->L; ++l) {
     h->A[l] = (h->panel || (h->fuse_last && l == h->L - 1) || (h->recompute_a0 && l == 0)) ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
@@ -469,14 +469,14 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
   const int64_t Bp = h->Bp;
   {
     LaunchScope ls(h, KID_FEAT);
-    dim3 grid(cdiv(rows, kFeatRows), (unsigned)nmem);
+    dim3 grid(cdiv(rows, kFeatRows) * (unsigned)nmem);
     const size_t lds = (size_t)kFeatRows * (h->Fp + 16 / h->es) * h->es;
     static uint64_t attr_done = 0;
     allow_lds(h, &k_featurize<T>, 160 * 1024, &attr_done);
     hipLaunchKernelGGL((k_featurize<T>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, X, stab,
                        y, h->scal, rows, (T*)h->H0, Bp * h->Fp,
                        (T*)nullptr, (int64_t)h->Fp * Bp, (int32_t)Bp,
-                       train ? h->ybat : (float*)nullptr, Bp);
+                       train ? h->ybat : (float*)nullptr, Bp, (int32_t)nmem);
   }
   const int n_layers = (train && h->fuse_last) ? h->L - 1 : h->L;   // EPI_LAST runs in run_backward
   for (int l = 0; l < n_layers; ++l) {
@@ -551,6 +551,13 @@ static WgradPlan wgrad_plan(const bnf_handle* h, int nmem, int l) {
   // 256 x 256 tiles when they still fill the chip (members x tiles >= half the CUs)
   if (h->big_tiles && M % 256 == 0 && N % 256 == 0) {
     const int64_t units = (int64_t)nmem * (M / 256) * (N / 256);
+    if (units < 128 && h->big_tiles != 2 && h->bf16 && h->tn_ring && K % 64 == 0 && K >= 16384) {
+      // few large units with a long batch (C5/8: 64 members x one 256 x 256 tile x 71k rows): the ring kernel with K split
+      // until the chip is full -- every operand byte is read ONCE (four 128 x 128 tiles read each half twice), and
+      // the atomics of the splits (256 x 256 floats each) are nothing next to 2 x K x 256 operand elements
+      const int sp = (int)std::min<int64_t>((h->num_cus + units - 1) / units, K / 4096);
+      if (sp >= 1) return {WG_RING, std::max(1, sp)};
+    }
     if (units >= 128 || h->big_tiles == 2) {
       if (h->bf16 && h->tn_ring && K % 64 == 0) {
         // the four-stage ring, one workgroup per CU, NO split-K: splitting to shorten the last, partly filled
@@ -794,12 +801,12 @@ static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
 // row-panel pipeline (bf16, depth 2): pack fragments -> featurise -> k_panel_fwd_bwd ->
 // featurise backward -> gemm_tn weight gradients
 // ---------------------------------------------------------------------------
-template <int WN, int RT, bool H0L, bool DEEP, int CH>
+template <int WN, int RT, bool H0L, bool DEEP, int CH, int FP>
 static void launch_panel_d(bnf_handle* h, const PanelArgs& pa) {
-  constexpr int kLds = panel_lds_bytes(WN, RT, H0L, CH);
+  constexpr int kLds = panel_lds_bytes(WN, RT, H0L, CH, FP);
   static_assert(kLds <= 160 * 1024, "LDS per workgroup");
   static uint64_t attr_done = 0;
-  allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH>, kLds, &attr_done);
+  allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH, FP>, kLds, &attr_done);
   PanelArgs pa2 = pa;
   pa2.ablate = h->ablate;
   const unsigned blocks = (unsigned)(pa.members * pa.panels);
@@ -810,15 +817,15 @@ static void launch_panel_d(bnf_handle* h, const PanelArgs& pa) {
   }
   {
     LaunchScope ls(h, KID_PANEL);
-    hipLaunchKernelGGL((k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH>), dim3(blocks), dim3(512), kLds, h->stream, pa2);
+    hipLaunchKernelGGL((k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH, FP>), dim3(blocks), dim3(512), kLds, h->stream, pa2);
   }
   phase_prof_end(h, KID_PANEL, blocks, 512);
 }
 
-template <int WN, int RT, bool H0L, int CH = 1>
+template <int WN, int RT, bool H0L, int CH = 1, int FP = 64>
 static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
-  if (pa.n_layers == 2) launch_panel_d<WN, RT, H0L, false, CH>(h, pa);
-  else launch_panel_d<WN, RT, H0L, true, CH>(h, pa);
+  if (pa.n_layers == 2) launch_panel_d<WN, RT, H0L, false, CH, FP>(h, pa);
+  else launch_panel_d<WN, RT, H0L, true, CH, FP>(h, pa);
 }
 
 static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs, float c,
@@ -827,13 +834,13 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   run_pack_fragments<bf16_t>(h, theta, nmem);     // also fills the member scalar table the next kernels read
   {
     LaunchScope ls(h, KID_FEAT);
-    dim3 grid(cdiv(h->B, kFeatRows), (unsigned)nmem);
+    dim3 grid(cdiv(h->B, kFeatRows) * (unsigned)nmem);
     const size_t lds = (size_t)kFeatRows * (h->Fp + 8) * 2;
     static uint64_t attr_done = 0;
     allow_lds(h, &k_featurize<bf16_t>, 160 * 1024, &attr_done);
     hipLaunchKernelGGL((k_featurize<bf16_t>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, h->X, h->stab,
                        h->y, h->scal, h->B, (bf16_t*)h->H0, Bp * h->Fp, (bf16_t*)h->H0t,
-                       (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp);
+                       (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp, (int32_t)nmem);
   }
   bool feat_bwd_fused = false;
   PanelArgs pa{};
@@ -880,6 +887,12 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
     } else {
       launch_panel<8, 4, false>(h, pa);
     }
+  } else if (h->h0l) {
+    // W = 256 with 65 .. 128 padded features (C5): 128-row panels (two row blocks of 64) so that the feature panel
+    // (128 x 272 bytes) fits in LDS beside the activation panel; featurisation backward fused
+    pa.panels = (int32_t)(Bp / panel_rows(4, 2));
+    with_fused_featbwd();
+    launch_panel<4, 2, true, 1, 128>(h, pa);
   } else {
     pa.panels = (int32_t)(Bp / panel_rows(4, 4));
     launch_panel<4, 4, false>(h, pa);
@@ -1212,7 +1225,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
     // its contraction depth is Fp <= 128: cheaper to redo than to write + gather A_0^T
     h->recompute_a0 = !cfg->forward_only && !h->panel && want == 0 && h->L >= 2 && h->Fp <= 128;
   }
-  h->h0l = h->panel && (h->W == 512 || h->W == 1024) && h->Fp == 64 && !getenv("BNF_PANEL_NO_H0L");
+  h->h0l = h->panel && (((h->W == 512 || h->W == 1024) && h->Fp == 64) || (h->W == 256 && h->Fp == 128)) && !getenv("BNF_PANEL_NO_H0L");
   if (h->h0l &&
       !(getenv("BNF_PANEL_FEATBWD") && atoi(getenv("BNF_PANEL_FEATBWD")) == 0)) {
     // fused featurisation backward of the H0L panel kernel: what each feature column contributes
@@ -1221,17 +1234,18 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
       if (cfg->group_kind[g] == BNF_GROUP_INPUT) in_group = g;
     if (in_group >= 0) {
       std::vector<int32_t>& m = h->fbmeta_h;
-      m.assign(64 * 4 + BNF_MAX_GROUPS, 0);
+      const int Fp = h->Fp;                 // 64 or 128 (h0l); the group offsets follow the column entries
+      m.assign(Fp * 4 + BNF_MAX_GROUPS, 0);
       auto put = [&](int col, int kind, int g, int d1, int d2, int partner, int ucol, float coef) {
         m[4 * col] = kind | (g << 8) | (d1 << 16) | (d2 << 24);
         m[4 * col + 1] = partner | (ucol << 8);
         memcpy(&m[4 * col + 2], &coef, 4);
       };
-      for (int c = 0; c < 64; ++c) put(c, kFbNone, 0xff, 0xff, 0xff, 0, 0, 0.f);
+      for (int c = 0; c < Fp; ++c) put(c, kFbNone, 0xff, 0xff, 0xff, 0, 0, 0.f);
       const int cin = cfg->group_col0[in_group];
       for (int g = 0; g < cfg->n_groups; ++g) {
         const int c0 = cfg->group_col0[g], nc = cfg->group_ncols[g];
-        m[256 + g] = cfg->group_scale_off[g];
+        m[4 * Fp + g] = cfg->group_scale_off[g];
         switch (cfg->group_kind[g]) {
           case BNF_GROUP_INPUT:
             for (int d = 0; d < nc; ++d) put(c0 + d, kFbInput, g, d, 0xff, 0, 0, 0.f);

@@ -178,9 +178,13 @@ constexpr int kPanelPD = 4;       // weight fragments in flight per stream
 __host__ __device__ constexpr int panel_rows(int wn, int rt) { return 32 * rt * (8 / wn); }
 // h0l: the feature panel (Fp = 64: BM x 144 bytes) is staged in LDS as well -- fits for W = 512
 // ch: 64-column slabs per wave (1: W = 64 wn; 2: W = 128 wn -- the width-1024 variant)
-__host__ __device__ constexpr int panel_lds_bytes(int wn, int rt, bool h0l, int ch = 1) {
+// fp: padded feature count of the LDS feature panel (64, or 128 with its own scratch for the fused featurisation
+// backward); the panel image is also the waves' row-dot scratch (8 waves x 64 rows x 36 floats)
+__host__ __device__ constexpr int panel_lds_bytes(int wn, int rt, bool h0l, int ch = 1, int fp = 64) {
   const int W = 64 * wn * ch, BM = panel_rows(wn, rt), RB = 8 / wn;
-  return BM * (W * 2 + 16) + (BM * wn * ch + BM + 2 * RB * W + 128) * 4 + (h0l ? BM * 144 : 0);
+  const int image = BM * (W * 2 + 16), dots = 8 * 64 * 36 * 4;
+  return (image > dots ? image : dots) + (BM * wn * ch + BM + 2 * RB * W + 128) * 4 +
+         (h0l ? BM * (fp * 2 + 16) + (fp > 64 ? 2 * (BM / 32) * fp * 4 : 0) : 0);
 }
 
 // Makes a lane value opaque to the optimiser at this point: everything derived from it (fragment
@@ -293,7 +297,8 @@ __device__ __forceinline__ void l0_mma(f32x16& a0, const L0Blk& bk) {
 // CH = 2: every wave owns TWO 64-column slabs, carried one after the other through every phase (the width-1024
 // variant: 8 waves x 2 x 64 columns, 64-row panels so that the panel still fits in LDS; twice the weight stream per
 // MFMA of the 128-row form).
-template <int WN, int RT, bool H0L, bool DEEP = false, int CH = 1>
+// FP: padded feature count the H0L code is compiled for (64; 128 = the W = 256 form: 128-row panels, two row blocks).
+template <int WN, int RT, bool H0L, bool DEEP = false, int CH = 1, int FP = 64>
 __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   constexpr int W = 64 * WN * CH, RB = 8 / WN, WR = 32 * RT, BM = WR * RB;   // WR = rows per wave
   constexpr int kSlabs = WN * CH;           // 64-column slabs of the layer
@@ -303,13 +308,18 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   constexpr int kHalves = (RT + 1) / 2;     // row dots go through a 64-row scratch image per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
-  float* xs = reinterpret_cast<float*>(smem + BM * kPitchB);
+  constexpr int kImageB = BM * kPitchB > 8 * 64 * kRowDotPitch * 4 ? BM * kPitchB : 8 * 64 * kRowDotPitch * 4;
+  float* xs = reinterpret_cast<float*>(smem + kImageB);
   float* s_part = xs;                       // [BM][kSlabs] row-dot partials
   float* s_dv = s_part + BM * kSlabs;       // [BM]
   float* s_col = s_dv + BM;                 // [2][RB][W] column sums
   float* s_sc = s_col + 2 * RB * W;         // scalars
-  constexpr int kH0Pitch = 144;             // Fp = 64: 128 bytes + 16 of padding
-  const char* h0s = reinterpret_cast<const char*>(s_sc + 128);   // [BM][144 B] feature panel (H0L)
+  constexpr int kH0Pitch = FP * 2 + 16;     // a feature row + 16 bytes of padding
+  constexpr int KS0c = FP / 16;             // k steps of the layer-0 contraction (H0L)
+  const char* h0s = reinterpret_cast<const char*>(s_sc + 128);   // [BM][kH0Pitch] feature panel (H0L)
+  // per (row tile, feature column) sums of the fused featurisation backward, two arrays of [BM / 32][FP]
+  float* s_fb = (FP > 64 || RB > 1 || W < 512) ? reinterpret_cast<float*>(const_cast<char*>(h0s) + BM * kH0Pitch) : s_col + W;
+  static_assert(!H0L || FP > 64 || (RB == 1 && W >= 512), "fused featurisation backward scratch: s_col[W..2W) holds 2 x BM/32 x 64 floats only for one row block and W >= 512");
 
   const int tid_k = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid_k >> 6);
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   if constexpr (H0L) {
     if (tid < BNF_MAX_GROUPS + BNF_MAX_INPUTS) s_grp[tid] = 0.f;   // (ordered by the barriers of the phases below)
     if (a.fbmeta && tid < a.n_groups) {
-      g_off = a.fbmeta[256 + tid];
+      g_off = a.fbmeta[4 * FP + tid];
       g_fac = sigmoidf(th[g_off]) / sc[kScalGroup + tid];
     }
   }
@@ -418,12 +428,13 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   };
 
   if constexpr (H0L) {   // feature panel -> LDS (row-major source, 16-byte chunks, 8 per row)
-    const bf16_t* src = a.H0rm + (int64_t)e * a.h0_batch + (int64_t)m0 * 64;
+    const bf16_t* src = a.H0rm + (int64_t)e * a.h0_batch + (int64_t)m0 * FP;
+    constexpr int kCpr = FP / 8;              // 16-byte chunks per feature row
 #pragma unroll
-    for (int c = 0; c < (BNF_ABL(a, 32) ? 0 : (BM * 8) / 512); ++c) {
+    for (int c = 0; c < (BNF_ABL(a, 32) ? 0 : (BM * kCpr) / 512); ++c) {
       const int q = tid + c * 512;
-      *reinterpret_cast<u32x4*>(const_cast<char*>(h0s) + (q >> 3) * kH0Pitch + (q & 7) * 16) =
-          *reinterpret_cast<const u32x4*>(src + (int64_t)(q >> 3) * 64 + (q & 7) * 8);
+      *reinterpret_cast<u32x4*>(const_cast<char*>(h0s) + (q / kCpr) * kH0Pitch + (q % kCpr) * 16) =
+          *reinterpret_cast<const u32x4*>(src + (int64_t)(q / kCpr) * FP + (q % kCpr) * 8);
     }
   }
   BNF_MARK(a, 0);
@@ -447,11 +458,11 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
     *hr = L.h0row + (size_t)(tt >> 1) * h0blk;
     *w = (tt & 1) ? L.w01 : L.w00;
   };
-  bf16x8 bres[H0L ? 2 : 1][4];     // H0L: this wave's layer-0 weight fragments [column half][k step]
+  bf16x8 bres[H0L ? 2 : 1][H0L ? KS0c : 4];     // H0L: this wave's layer-0 weight fragments [column half][k step]
   auto l0_weights = [&](const LaneCtx& L) {
     if constexpr (H0L) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < KS0c; ++u) {
         bres[0][u] = *reinterpret_cast<const bf16x8*>(L.w00 + (size_t)u * 1024);
         bres[1][u] = *reinterpret_cast<const bf16x8*>(L.w01 + (size_t)u * 1024);
       }
@@ -469,12 +480,15 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
         return;
       }
       const char* ap = h0s + (rbase + i * 32 + L.frow) * kH0Pitch + L.kg * 16;
-      bf16x8 fa[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) fa[u] = *reinterpret_cast<const bf16x8*>(ap + u * 32);
+      for (int u0 = 0; u0 < KS0c; u0 += 4) {
+        bf16x8 fa[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u], bres[j ? (H0L ? 1 : 0) : 0][u], a0, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) fa[u] = *reinterpret_cast<const bf16x8*>(ap + (u0 + u) * 32);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u], bres[j ? (H0L ? 1 : 0) : 0][H0L ? u0 + u : 0], a0, 0, 0, 0);
+      }
       return;
     }
     const int t = 2 * i + j;
@@ -1066,7 +1080,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
     if constexpr (H0L) {
       if (a.fbmeta) {
         md_first = *reinterpret_cast<const int4*>(a.fbmeta + 4 * ((wave % ct) * 32 + frow));
-        if (wave == 0) md_red = *reinterpret_cast<const int4*>(a.fbmeta + 4 * lane);
+        if (wave < FP / 64) md_red = *reinterpret_cast<const int4*>(a.fbmeta + 4 * (wave * 64 + lane));
       }
     }
     BNF_MARK(a, 10);
@@ -1133,8 +1147,8 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
           s1 += __shfl_xor(s1, 32, 64);
           s2 += __shfl_xor(s2, 32, 64);
           if (lane < 32) {   // this wave is the only writer of (mi, f)
-            s_col[W + mi * 64 + f] = s1 * inv_sf;
-            s_col[W + (BM / 32) * 64 + mi * 64 + f] = s2 * inv_sf;
+            s_fb[mi * FP + f] = s1 * inv_sf;
+            s_fb[(BM / 32) * FP + mi * FP + f] = s2 * inv_sf;
           }
           continue;          // dH0^T itself is not needed any more
         }
@@ -1149,16 +1163,15 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   BNF_MARK(a, 11);
   if constexpr (H0L) {
     if (a.fbmeta) {
-      static_assert(!H0L || (RB == 1 && W >= 512), "fused featurisation backward: BM / 32 row tiles x 64 columns, twice, in s_col[W..2W)");
       lds_barrier();
-      if (wave == 0) {
-        const int f = opaque_lane(tid) & 63;
+      if (wave < FP / 64) {                 // one feature column per lane
+        const int f = wave * 64 + (opaque_lane(tid) & 63);
         const int4 md = md_red;
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int mi = 0; mi < BM / 32; ++mi) {
-          t1 += s_col[W + mi * 64 + f];
-          t2 += s_col[W + (BM / 32) * 64 + mi * 64 + f];
+          t1 += s_fb[mi * FP + f];
+          t2 += s_fb[(BM / 32) * FP + mi * FP + f];
         }
         const int kind = md.x & 0xff, g = (md.x >> 8) & 0xff, d1 = (md.x >> 16) & 0xff, d2 = (md.x >> 24) & 0xff;
         const float sp_in = sp_in_u;
@@ -1170,6 +1183,10 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
         if (d2 < BNF_MAX_INPUTS) atomicAdd(&s_grp[BNF_MAX_GROUPS + d2], v);
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS atomics have landed
         __builtin_amdgcn_wave_barrier();
+      }
+      if constexpr (FP > 64) lds_barrier();   // the columns are spread over two waves
+      if (wave == 0) {
+        const int f = opaque_lane(tid) & 63;
         if (f < a.n_groups) {
           atomicAdd(&gr[s_goff[f]], s_gfac[f] * s_grp[f]);
         } else if (f >= BNF_MAX_GROUPS && f < BNF_MAX_GROUPS + a.n_inputs) {

@@ -134,6 +134,54 @@ def test_fused_featurisation_backward_matches_the_separate_kernel(monkeypatch):
   assert not rest, rest
 
 
+@pytest.mark.parametrize('depth,n_rows', [(2, 700), (2, 130), (3, 1000)])
+def test_w256_with_up_to_128_features_keeps_the_feature_panel_in_lds(monkeypatch, depth, n_rows):
+  """W = 256 with 65 .. 128 padded features (the C5 shape: 105 features here): 128-row panels of two 64-row
+  blocks, the feature panel (128 x 272 bytes) staged in LDS for both layer-0 passes, the wave's sixteen layer-0
+  weight fragments in registers, featurisation backward fused (k_panel_fwd_bwd<4, 2, true, ., 1, 128>).
+  Against the float64 oracle and the bf16 layer pipeline -- loss, every gradient leaf, H1, dZ of both ends,
+  output -- and against the two other routes to the same numbers: the separate featurisation-backward kernel
+  (BNF_PANEL_FEATBWD=0) and the 256-row panel kernel without the LDS feature panel (BNF_PANEL_NO_H0L=1)."""
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=256, depth=depth, periods=(52.1775, 365.25), harmonics=(20, 20))
+  assert 64 < net.F <= 128
+  E = 3
+  theta = util.random_theta(model, E, scale=0.3)
+  loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
+  out_o, ch = O.forward(model, theta, X, keep=True)
+  res = {}
+  for route, env in (('lds', {}), ('featbwd_apart', {'BNF_PANEL_FEATBWD': '0'}), ('no_lds', {'BNF_PANEL_NO_H0L': '1'}),
+                     ('layers', {})):
+    for k in ('BNF_PANEL_FEATBWD', 'BNF_PANEL_NO_H0L'):
+      monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)
+    eng = _engine(net, X, y, members=E, compute_dtype='bf16', pipeline='layers' if route == 'layers' else 'panel')
+    eng.set_params(theta)
+    loss, g = eng.debug_loss_and_grad()
+    loss2, g2 = eng.debug_loss_and_grad()           # LDS scratch re-initialised by every workgroup
+    assert util.rel_err(g2, g) < 2e-3
+    res[route] = (loss, g, eng.debug_activation(1), eng.debug_activation(300), eng.debug_activation(300 + depth - 1),
+                  eng.debug_activation(200))
+    eng.close()
+  for route in ('lds', 'featbwd_apart', 'no_lds'):
+    loss, g, H1, dZ0, dZl, out = res[route]
+    np.testing.assert_allclose(loss, loss_o, rtol=5e-3)
+    np.testing.assert_allclose(loss, res['layers'][0], rtol=1e-3)
+    assert util.rel_err(H1, ch['Hs'][1]) < 2e-2 and util.rel_err(H1, res['layers'][2]) < 1e-2
+    assert util.rel_err(dZ0, res['layers'][3]) < 3e-2 and util.rel_err(dZl, res['layers'][4]) < 3e-2
+    assert util.rel_err(out, out_o) < 3e-2
+    bad = {k: v for k, v in _leaf_errs(model, g, g_o).items() if v > 6e-2}
+    assert not bad, (route, 'vs oracle', bad)
+    bad = {k: v for k, v in _leaf_errs(model, g, res['layers'][1]).items() if v > 2e-2}
+    assert not bad, (route, 'vs layers', bad)
+  names = [k for k in model.leaf if k.startswith('feature_inv_sp_scale') or k == 'log_scale_adjustment']
+  errs = util.per_leaf_rel_err(model, res['lds'][1], res['featbwd_apart'][1])
+  bad = {k: errs[k] for k in names if errs[k] > 1e-2}
+  assert not bad, bad
+  rest = {k: v for k, v in errs.items() if k not in names and v > 2e-3}   # nothing else changes
+  assert not rest, rest
+
+
 @pytest.mark.parametrize('n_rows', [300, 1000, 2333])
 def test_weight_gradient_stream_kernels_match_the_two_stage_kernel(n_rows, monkeypatch):
   """gemm_tn_skinny (layer 0 as a 64 x 512 row stream) and gemm_tn_ring (256 x 256 tile, four-stage
