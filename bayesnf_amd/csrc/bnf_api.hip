@@ -12,6 +12,9 @@
 // VI runs the same pipeline on members x S "virtual members" whose parameters
 // are the reparameterised samples, bracketed by k_vi_sample / k_vi_adam.
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>            // the stable key-value sort of jax.random.permutation
+#include <rocprim/device/device_segmented_radix_sort.hpp>  // (bnf_row_keys): the one library primitive in here
 
 #include <dlfcn.h>
 
@@ -121,6 +124,11 @@ struct bnf_handle {
   const uint32_t* vi_draw_keys = nullptr; int64_t vi_draw_rows = 0;
   // caller's epoch shuffles (bnf_row_tables): (n_epochs, members, steps * B) int32 row ids from epoch row_tab_e0 on
   const int32_t* row_tab = nullptr; int64_t row_tab_epochs = 0, row_tab_e0 = 0;
+  // ... or their keys (bnf_row_keys): the epoch's permutations are drawn on the device when the epoch starts
+  const uint32_t* row_keys = nullptr; int64_t row_keys_epochs = 0, row_keys_e0 = 0; int32_t row_key_rounds = 0;
+  uint32_t* perm_bits[2] = {nullptr, nullptr}; int32_t* perm_val[2] = {nullptr, nullptr};   // (members, N) each, hipMalloc'ed
+  unsigned* perm_seg = nullptr; void* perm_tmp = nullptr; size_t perm_tmp_bytes = 0;
+  int32_t* perm = nullptr; int64_t perm_epoch = -1;      // the current epoch's (members, N) row ids
   int32_t* leaf_off = nullptr; uint8_t* leaf_id = nullptr; int32_t n_leaves = 0;
   bool adam_clear_all = false;   // env BNF_ADAM_CLEAR_ALL (A/B of the kept gradient range)
   bool h0l = false;
@@ -942,15 +950,82 @@ static RowSrc make_rowsrc(const bnf_handle* h, int64_t epoch, int64_t step) {
       rs.mode = 3;
       rs.table_ld = (h->N / h->B) * h->B;
       rs.table = h->row_tab + (epoch - h->row_tab_e0) * (int64_t)h->cfg.members * rs.table_ld;
+    } else if (h->row_keys && h->perm && h->perm_epoch == epoch) {   // (ensure_row_perm drew it)
+      rs.mode = 3;
+      rs.table_ld = h->N;
+      rs.table = h->perm;
     }
   }
   return rs;
+}
+
+// jax.random.permutation(key, N) for every member, on the device (jax/_src/random.py `_shuffle`): `rounds` times
+// { bits = random_bits(sub_key_r, (N,)); stable sort of the current order by bits }.  The sub keys are the
+// caller's (bnf_row_keys); the bits are threefry2x32 over iota(N) split in halves (k_jax_perm_bits), the sort is
+// rocPRIM's radix sort of (bits, row id) pairs -- LSD radix, stable -- one segment per member.
+static int ensure_row_perm(bnf_handle* h, int64_t epoch) {
+  if (!h->row_keys || h->B >= h->N || epoch < h->row_keys_e0 || epoch >= h->row_keys_e0 + h->row_keys_epochs) return BNF_OK;
+  if (h->row_tab && epoch >= h->row_tab_e0 && epoch < h->row_tab_e0 + h->row_tab_epochs) return BNF_OK;   // tables win
+  if (h->perm_epoch == epoch) return BNF_OK;
+  const int E = h->cfg.members, R = h->row_key_rounds;
+  const int64_t N = h->N, total = (int64_t)E * N;
+  if (total > 0x7fffffffLL) return fail(BNF_ERR_INVALID, "bnf_row_keys: members x rows exceeds 2^31");
+  const bool segmented = N <= (1 << 17);     // long segments: one device-wide sort per member instead
+  if (!h->perm_bits[0]) {
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipMalloc((void**)&h->perm_bits[k], (size_t)total * 4));
+      HIPCHK(hipMalloc((void**)&h->perm_val[k], (size_t)total * 4));
+    }
+    HIPCHK(hipMalloc((void**)&h->perm_seg, (size_t)(E + 1) * sizeof(unsigned)));
+    std::vector<unsigned> off((size_t)E + 1);
+    for (int e = 0; e <= E; ++e) off[(size_t)e] = (unsigned)((int64_t)e * N);
+    HIPCHK(hipMemcpy(h->perm_seg, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    size_t bytes = 0;
+    hipError_t qe;
+    if (segmented)
+      qe = rocprim::segmented_radix_sort_pairs(nullptr, bytes, h->perm_bits[0], h->perm_bits[1], h->perm_val[0], h->perm_val[1],
+                                               (unsigned)total, (unsigned)E, h->perm_seg, h->perm_seg + 1, 0, 32, h->stream);
+    else
+      qe = rocprim::radix_sort_pairs(nullptr, bytes, h->perm_bits[0], h->perm_bits[1], h->perm_val[0], h->perm_val[1],
+                                     (size_t)N, 0, 32, h->stream);
+    if (qe != hipSuccess) return fail(BNF_ERR_HIP, "radix sort workspace query: %s", hipGetErrorString(qe));
+    h->perm_tmp_bytes = std::max<size_t>(bytes, 16);
+    HIPCHK(hipMalloc(&h->perm_tmp, h->perm_tmp_bytes));
+  }
+  const uint32_t* keys = h->row_keys + ((epoch - h->row_keys_e0) * E) * (int64_t)R * 2;   // (members, rounds, 2)
+  int cur = 0;
+  for (int r = 0; r < R; ++r) {
+    const unsigned half = (unsigned)((N + 1) / 2);
+    hipLaunchKernelGGL(k_jax_perm_bits, dim3(cdiv(half, 256), (unsigned)E), dim3(256), 0, h->stream, keys, R, r,
+                       (uint32_t)N, h->perm_bits[0], r == 0 ? h->perm_val[cur] : (int32_t*)nullptr);
+    hipError_t se = hipSuccess;
+    if (segmented) {
+      size_t bytes = h->perm_tmp_bytes;
+      se = rocprim::segmented_radix_sort_pairs(h->perm_tmp, bytes, h->perm_bits[0], h->perm_bits[1], h->perm_val[cur],
+                                               h->perm_val[cur ^ 1], (unsigned)total, (unsigned)E, h->perm_seg,
+                                               h->perm_seg + 1, 0, 32, h->stream);
+    } else {
+      for (int e = 0; e < E && se == hipSuccess; ++e) {
+        size_t bytes = h->perm_tmp_bytes;
+        se = rocprim::radix_sort_pairs(h->perm_tmp, bytes, h->perm_bits[0] + (int64_t)e * N, h->perm_bits[1] + (int64_t)e * N,
+                                       h->perm_val[cur] + (int64_t)e * N, h->perm_val[cur ^ 1] + (int64_t)e * N, (size_t)N,
+                                       0, 32, h->stream);
+      }
+    }
+    if (se != hipSuccess) return fail(BNF_ERR_HIP, "radix sort: %s", hipGetErrorString(se));
+    cur ^= 1;
+  }
+  h->perm = h->perm_val[cur];
+  h->perm_epoch = epoch;
+  HIPCHK(hipGetLastError());
+  return BNF_OK;
 }
 
 // One MAP/MLE step.  apply=false: leave params untouched, grad holds the full
 // gradient (likelihood + prior), loss_raw the step loss.
 template <typename T>
 static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& sink, bool apply) {
+  if (const int prc = ensure_row_perm(h, epoch)) return prc;
   const RowSrc rs = make_rowsrc(h, epoch, step);
   const int E = h->cfg.members;
   const float c = (float)((double)h->N / (double)h->B);
@@ -1296,6 +1371,12 @@ void bnf_destroy(bnf_handle* h) {
     }
     (void)hipFree(h->prof_buf);
   }
+  for (int k = 0; k < 2; ++k) {
+    if (h->perm_bits[k]) (void)hipFree(h->perm_bits[k]);
+    if (h->perm_val[k]) (void)hipFree(h->perm_val[k]);
+  }
+  if (h->perm_seg) (void)hipFree(h->perm_seg);
+  if (h->perm_tmp) (void)hipFree(h->perm_tmp);
   delete h;
 }
 
@@ -1356,6 +1437,7 @@ int bnf_bind(bnf_handle* h, void* params, void* opt_state, void* workspace, cons
   // key tables address rows by (adam_t - vi_key_t0): a re-bound handle starts again without them
   h->vi_keys = h->vi_draw_keys = nullptr; h->vi_key_rows = h->vi_draw_rows = 0; h->vi_key_t0 = 0;
   h->row_tab = nullptr; h->row_tab_epochs = 0;
+  h->row_keys = nullptr; h->row_keys_epochs = 0; h->perm_epoch = -1;
   return BNF_OK;
 }
 
@@ -1603,6 +1685,7 @@ int bnf_debug_loss_and_grad(bnf_handle* h, int64_t epoch, int64_t step, float* g
 int bnf_debug_row_index(bnf_handle* h, int64_t epoch, int64_t step, int32_t* out) {
   if (!h || !h->bound || !out) return fail(BNF_ERR_STATE, "not bound / null");
   HIPCHK(hipSetDevice(h->cfg.device));
+  if (const int prc = ensure_row_perm(h, epoch)) return prc;
   RowSrc rs = make_rowsrc(h, epoch, step);
   rs.S = 1;  // indexed by real member
   dim3 grid(cdiv(h->B, 256), (unsigned)h->cfg.members);
@@ -1643,6 +1726,19 @@ int bnf_row_tables(bnf_handle* h, const int32_t* tables, int64_t epoch0, int64_t
   if (!tables) { h->row_tab = nullptr; h->row_tab_epochs = 0; return BNF_OK; }
   if (n_epochs < 1 || epoch0 < 0) return fail(BNF_ERR_INVALID, "epoch0 / n_epochs");
   h->row_tab = tables; h->row_tab_e0 = epoch0; h->row_tab_epochs = n_epochs;
+  return BNF_OK;
+}
+
+int bnf_row_keys(bnf_handle* h, const uint32_t* keys, int64_t epoch0, int64_t n_epochs, int32_t rounds) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "not bound");
+  if (h->cfg.mode != BNF_MODE_MAP) return fail(BNF_ERR_STATE, "row keys serve MAP / MLE epochs");
+  h->perm_epoch = -1;
+  if (!keys) { h->row_keys = nullptr; h->row_keys_epochs = 0; return BNF_OK; }
+  if (n_epochs < 1 || epoch0 < 0 || rounds < 1 || rounds > 8) return fail(BNF_ERR_INVALID, "epoch0 / n_epochs / rounds");
+  // jax: ceil(3 ln N / ln(2^32 - 1)) rounds -- anything else would be another permutation
+  const int want = (int)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, h->N)) / std::log(4294967295.0));
+  if (rounds != want) return fail(BNF_ERR_INVALID, "rounds = %d, jax.random.permutation of %lld rows takes %d", rounds, (long long)h->N, want);
+  h->row_keys = keys; h->row_keys_e0 = epoch0; h->row_keys_epochs = n_epochs; h->row_key_rounds = rounds;
   return BNF_OK;
 }
 

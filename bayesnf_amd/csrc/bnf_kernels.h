@@ -931,6 +931,28 @@ __global__ void k_fill(float* p, int64_t n, float v) {
   if (i < n) p[i] = v;
 }
 
+// sort keys of one round of jax.random.permutation: bits[e][i] = random_bits(keys[e][round], (n,))[i] -- threefry2x32
+// over iota(n) split in halves (an odd n pads the second half with counter 0), first outputs then second outputs;
+// vals (round 0): the identity order.   grid (ceil(ceil(n/2)/256), members)
+__global__ __launch_bounds__(256) void k_jax_perm_bits(const uint32_t* __restrict__ keys, int32_t rounds, int32_t round,
+                                                       uint32_t n, uint32_t* __restrict__ bits, int32_t* __restrict__ vals) {
+  const int e = blockIdx.y;
+  const uint32_t half = (n + 1u) >> 1;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= half) return;
+  const uint32_t* k = keys + ((int64_t)e * rounds + round) * 2;
+  uint32_t y0, y1;
+  threefry2x32(k[0], k[1], j, j + half < n ? j + half : 0u, &y0, &y1);
+  uint32_t* b = bits + (int64_t)e * n;
+  b[j] = y0;
+  if (j + half < n) b[j + half] = y1;
+  if (vals) {
+    int32_t* v = vals + (int64_t)e * n;
+    v[j] = (int32_t)j;
+    if (j + half < n) v[j + half] = (int32_t)(j + half);
+  }
+}
+
 __global__ void k_row_index(RowSrc rs, int64_t B, int32_t* out) {
   const int e = blockIdx.y;
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

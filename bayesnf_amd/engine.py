@@ -166,6 +166,21 @@ class Engine:
     self._row_tables = (getattr(self, '_row_tables', []) + [t])[-2:]
     _native.check(self.lib.bnf_row_tables(self.handle, _ptr(t), int(epoch0), int(t.shape[0])), 'bnf_row_tables')
 
+  def set_row_keys(self, subkeys, epoch0=0):
+    """The reference's epoch shuffles drawn on the device (include/bnf.h bnf_row_keys): uint32 (n_epochs, members,
+    rounds, 2) sub keys of `jax.random.permutation`'s sort rounds (jaxseed.map_shuffle_subkeys) for the epochs
+    [epoch0, epoch0 + n_epochs); uploaded and kept alive here.  None switches it off."""
+    if subkeys is None:
+      self._row_keys = None
+      _native.check(self.lib.bnf_row_keys(self.handle, None, 0, 0, 0), 'bnf_row_keys')
+      return
+    k = np.ascontiguousarray(subkeys, dtype=np.uint32)
+    if k.ndim != 4 or k.shape[1] != self.members or k.shape[3] != 2:
+      raise ValueError(f'row keys must be uint32 (n_epochs, {self.members}, rounds, 2); got {k.shape}')
+    t = torch.from_numpy(k.view(np.int32)).to(self.device)
+    self._row_keys = t
+    _native.check(self.lib.bnf_row_keys(self.handle, _ptr(t), int(epoch0), int(k.shape[0]), int(k.shape[2])), 'bnf_row_keys')
+
   def vi_posterior_draws(self, n_draws: int) -> torch.Tensor:
     out = torch.empty((n_draws, self.members, self.net.P), dtype=torch.float32,
                       device=self.device)

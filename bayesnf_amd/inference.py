@@ -55,7 +55,7 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
   init_rng: 'jax' (default; env BNF_INIT_RNG) starts every member from the initial parameters the
   reference itself would draw for `seed` (threefry + TFP seed chain restated on the host,
   `jaxseed`) and, for minibatch fits, shuffles every epoch with the reference's own per-member
-  `jax.random.permutation` stream (`jaxseed.map_row_tables` -> `bnf_row_tables`): same seed => the fit
+  `jax.random.permutation` stream (`jaxseed.map_shuffle_subkeys` -> `bnf_row_keys`: drawn on the device): same seed => the fit
   follows the reference's trajectory.  'philox' draws the initial parameters from the device generator
   (`bnf_init_params`) and shuffles with the device's keyed Feistel permutation (no index arrays).
 
@@ -102,8 +102,12 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
         eng.init_params(log_noise_init)
       if pkeys is None:
         return eng, eng.train(0, num_epochs)
-      # the shuffles are drawn on the host (threefry bits + stable sort per member and epoch) in chunks of
-      # <= ~64 MB of row ids; chunk c + 1 is drawn while the device runs the epochs of chunk c
+      # the shuffles are drawn on the device, epoch by epoch, from the sub keys of their sort rounds
+      # (BNF_ROW_TABLES=host: drawn here instead -- threefry bits + stable sort per member and epoch -- and uploaded
+      # in chunks of <= ~64 MB of row ids, chunk c + 1 while the device runs the epochs of chunk c)
+      if os.environ.get('BNF_ROW_TABLES', 'device') != 'host':
+        eng.set_row_keys(jaxseed.map_shuffle_subkeys(pkeys[sh.index], n_rows), epoch0=0)
+        return eng, eng.train(0, num_epochs)
       keep = (n_rows // batch_size) * batch_size
       per_chunk = int(max(1, min(num_epochs, (64 << 20) // max(1, 4 * per_device * keep))))
       parts = []

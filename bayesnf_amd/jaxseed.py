@@ -216,7 +216,7 @@ def permutations(keys: np.ndarray, n: int) -> np.ndarray:
   jax/_src/random.py `_shuffle`: ceil(3 ln n / ln(2^32 - 1)) rounds of `key, sub = split(key)`, a STABLE
   sort of the current order by `bits(sub, (n,))`."""
   keys = np.asarray(keys, dtype=_U32).reshape(-1, 2)
-  rounds = int(np.ceil(3 * np.log(max(1, n)) / np.log(np.iinfo(np.uint32).max)))
+  rounds = shuffle_rounds(n)
   x = np.broadcast_to(np.arange(n, dtype=np.int32), (keys.shape[0], n)).copy()
   for _ in range(rounds):
     pair = _split_many(keys, 2)
@@ -240,6 +240,27 @@ def map_permute_keys(seed, world: int, per_device: int, num_epochs: int, split_i
     pair = _split_many(carry, 2)
     carry, out[:, ep] = pair[:, 0], pair[:, 1]
   return out.reshape(world, per_device, num_epochs, 2)
+
+
+def shuffle_rounds(n: int) -> int:
+  """sort rounds of `jax.random.permutation` over n items (jax/_src/random.py `_shuffle`)."""
+  return int(np.ceil(3 * np.log(max(1, n)) / np.log(np.iinfo(np.uint32).max)))
+
+
+def map_shuffle_subkeys(permute_keys: np.ndarray, n_rows: int) -> np.ndarray:
+  """For `bnf_row_keys`: permute_keys (members, n_epochs, 2) -> uint32 (n_epochs, members, rounds, 2), the `sub`
+  of every `key, sub = split(key)` of the permutation's sort rounds -- all the host does per fit; the bits and
+  the stable sorts happen on the device."""
+  pk = np.asarray(permute_keys, dtype=_U32)
+  members, n_epochs = pk.shape[0], pk.shape[1]
+  rounds = shuffle_rounds(n_rows)
+  out = np.empty((n_epochs, members, rounds, 2), dtype=_U32)
+  carry = pk.reshape(-1, 2)
+  for r in range(rounds):
+    pair = _split_many(carry, 2)
+    carry = pair[:, 0]
+    out[:, :, r] = pair[:, 1].reshape(members, n_epochs, 2).transpose(1, 0, 2)
+  return out
 
 
 def map_row_tables(permute_keys: np.ndarray, n_rows: int, batch: int) -> np.ndarray:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BNF_ABI_VERSION 2
+#define BNF_ABI_VERSION 3
 
 /* limits of the static network description */
 #define BNF_MAX_INPUTS   8    /* D  : time + spatial covariates              */
@@ -173,6 +173,19 @@ int bnf_vi_posterior_draws(bnf_handle* h, int32_t n_draws, float* out /*DEVICE*/
  *          those epochs are enqueued AND executing; epochs outside the range use the engine's shuffle.
  * NULL restores the engine's shuffle.  Full-batch handles ignore it (no shuffle there). */
 int bnf_row_tables(bnf_handle* h, const int32_t* tables, int64_t epoch0, int64_t n_epochs);
+
+/* The same shuffles drawn ON THE DEVICE from their keys (what fit() uses: no per-epoch host work, no row-id upload --
+ * at 10^7 rows a host-side table is 40 MB per member and epoch).  jax.random.permutation(permute_seed, N) is
+ * `rounds` = ceil(3 ln N / ln(2^32 - 1)) times { permute_seed, sub = split(permute_seed); stable sort of the current
+ * order by random_bits(sub, (N,)) } (jax/_src/random.py _shuffle); the caller supplies the sub keys
+ * (bayesnf_amd/jaxseed.py map_shuffle_subkeys), the engine draws the bits (threefry2x32) and sorts (radix, stable)
+ * when an epoch starts, on the handle's stream.
+ *   keys DEVICE uint32 (n_epochs, members, rounds, 2) for the epochs [epoch0, epoch0 + n_epochs); caller-owned,
+ *        alive while those epochs are enqueued and executing.  BNF_ERR_INVALID if `rounds` is not jax's count for N.
+ * Work buffers (4 x members x N x 4 bytes + sort scratch) are allocated by the engine at the first such epoch
+ * (the only allocation the engine makes itself) and freed by bnf_destroy.  A table from bnf_row_tables covering
+ * the same epoch wins.  NULL switches it off. */
+int bnf_row_keys(bnf_handle* h, const uint32_t* keys, int64_t epoch0, int64_t n_epochs, int32_t rounds);
 
 /* The reference's OWN random stream for the VI noise (optional; without it the noise comes from the
  * engine's counter-based generator -- same law, other numbers).  tfp.vi.fit_surrogate_posterior_stateless

@@ -227,3 +227,42 @@ def test_layout_parity_c3_vi_fp32():
   bad = {k: v for k, v in util.per_leaf_rel_err(model, g_d[1], grho_o).items() if v > 5e-4}
   assert not bad, ('grho', bad)
   eng.close()
+
+
+@pytest.mark.parametrize('n_rows,batch', [(1700, 512), (101, 10), (140001, 65536)])
+def test_reference_shuffles_drawn_on_the_device(n_rows, batch):
+  """bnf_row_keys: `jax.random.permutation` of every member and epoch drawn by the engine itself -- threefry bits of
+  the round's sub key (k_jax_perm_bits), stable radix sort of (bits, row id) pairs, one segment per member (a
+  device-wide sort per member above 2^17 rows) -- against the oracle's restatement of the reference chain
+  (oracle/jax_rng.py, inference.py:35-39,571-575,593-597) and against the host-drawn tables (bnf_row_tables).
+  One and two sort rounds, odd row counts (the padded counter), ragged tails."""
+  from oracle import jax_rng as R
+  from bayesnf_amd import jaxseed as J
+  from bayesnf_amd.engine import Engine
+  from tests import util
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=1)
+  E, epochs = 3, 3
+  key = np.array([5, 9], dtype=np.uint32)
+  ref = R.reference_map_permutations(key, E, epochs, n_rows)              # (members, epochs, n)
+  pk = J.map_permute_keys(key, 1, E, epochs)[0]
+  steps = n_rows // batch
+  eng = Engine(net, X=X, y=y, members=E, batch=batch, seed=0)
+  eng.init_params(0.0)
+  eng.set_row_keys(J.map_shuffle_subkeys(pk, n_rows), epoch0=0)
+  for ep in (0, 2, 1, 1):                                                 # any order: an epoch is drawn when it is asked for
+    rows = np.concatenate([eng.debug_row_index(ep, s) for s in range(steps)], axis=1)
+    np.testing.assert_array_equal(rows, ref[:, ep, :steps * batch])
+  # training through them == training through the host-drawn tables
+  l_dev = eng.train(0, epochs).cpu().numpy()
+  th_dev = eng.get_params()
+  eng.close()
+  eng = Engine(net, X=X, y=y, members=E, batch=batch, seed=0)
+  eng.init_params(0.0)
+  eng.set_row_tables(J.map_row_tables(pk, n_rows, batch), epoch0=0)
+  l_host = eng.train(0, epochs).cpu().numpy()
+  np.testing.assert_allclose(l_dev, l_host, rtol=1e-5)
+  np.testing.assert_allclose(th_dev, eng.get_params(), rtol=1e-4, atol=1e-6)
+  # a wrong round count is refused (it would be another permutation)
+  with pytest.raises(Exception, match='rounds'):
+    eng.set_row_keys(np.zeros((1, E, J.shuffle_rounds(n_rows) + 1, 2), dtype=np.uint32))
+  eng.close()

@@ -168,7 +168,18 @@ def test_product_minibatch_shuffles_equal_the_oracle_chain():
       tab = J.map_row_tables(pk[d], n, batch)                            # (epochs, members / device, keep)
       assert tab.shape == (3, 3, keep) and tab.dtype == np.int32
       np.testing.assert_array_equal(np.transpose(tab, (1, 0, 2)), ref[3 * d:3 * d + 3, :, :keep])
+      # what the device is given instead of tables (bnf_row_keys): the sub keys of the sort rounds; the engine's
+      # part -- bits of the sub key, stable sort of the current order -- emulated here
+      sub = J.map_shuffle_subkeys(pk[d], n)
+      assert sub.shape == (3, 3, J.shuffle_rounds(n), 2) and sub.dtype == np.uint32
+      for ep in range(3):
+        for m in range(3):
+          x = np.arange(n, dtype=np.int32)
+          for r in range(sub.shape[2]):
+            x = x[np.argsort(J._bits_many(sub[ep, m, r][None], n)[0], kind='stable')]
+          np.testing.assert_array_equal(x, ref[3 * d + m, ep])
     assert sorted(ref[0, 0].tolist()) == list(range(n)) and not np.array_equal(ref[0, 0], ref[0, 1])
+  assert [J.shuffle_rounds(n) for n in (1, 100, 1625, 1626, 10**7)] == [0, 1, 1, 2, 3]
   # num_splits > 1: fold_in(seed, i) first (fit_map, inference.py:432-441)
   np.testing.assert_array_equal(J.map_row_tables(J.map_permute_keys(key, 1, 2, 2, split_index=1)[0], 50, 50)[1, 0],
                                 R.reference_map_permutations(key, 2, 2, 50, split_index=1)[0, 1])
