@@ -432,13 +432,18 @@ static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep
     if (kind == WG_RING) {   // the 256 x 256 tile with the K loop as a four-stage ring
       g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
       if (g.splitk < 1) g.splitk = 1;
-      static uint64_t attr_done = 0;
-      allow_lds(h, &gemm_tn_ring<TAG>, kRgLds, &attr_done);
+      static uint64_t attr_done = 0, attr_done_s = 0;
       const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk * (g.n_multi > 1 ? g.n_multi : 1));
       EpiArgs ep2 = ep;
       ep2.ablate = h->ablate;
       LaunchScope ls(h, kid, st, true);
-      hipLaunchKernelGGL((gemm_tn_ring<TAG>), dim3(blocks), dim3(512), kRgLds, st, g, ep2);
+      if (g.splitk == 1) {   // plain stores: accumulators transposed, 16-byte stores
+        allow_lds(h, &gemm_tn_ring<TAG, true>, kRgLds, &attr_done_s);
+        hipLaunchKernelGGL((gemm_tn_ring<TAG, true>), dim3(blocks), dim3(512), kRgLds, st, g, ep2);
+      } else {
+        allow_lds(h, &gemm_tn_ring<TAG, false>, kRgLds, &attr_done);
+        hipLaunchKernelGGL((gemm_tn_ring<TAG, false>), dim3(blocks), dim3(512), kRgLds, st, g, ep2);
+      }
       return;
     }
   }

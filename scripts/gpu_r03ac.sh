@@ -1,0 +1,17 @@
+#!/bin/bash
+# r03 visit AC: ring weight-gradient kernel with swapped MFMA operand roles (16-byte output stores): tests, C3 / C2 / C4 A/B
+set -u; ulimit -c 0
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/${1:-r03ac}; mkdir -p "$OUT"; cd "$ROOT"
+echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > "$OUT/pytest.txt" 2>&1; echo "rc=$?"; grep -E "passed|failed|^FAILED|^E  " "$OUT/pytest.txt" | tail -12 | cut -c1-250
+cfg() { timeout 400 python scripts/bench_configs.py $2 2>/dev/null | python -c "import sys,json
+for l in sys.stdin:
+  d=json.loads(l); print('$1', d['config'][:5], round(d['member_steps_per_s'],1), round(d['algorithmic_tflops'],1), round(d['final_loss_mean'],1))"; }
+for rep in 1 2; do
+  BNF_LIB=$ROOT/ab/libbnf_head.so cfg head C3
+  cfg new C3
+done 2>&1 | tee "$OUT/ab_c3.txt"
+echo "== C3 per-kernel"; timeout 200 python scripts/profile_config.py "C3/8 air_quality-like VI" 2>/dev/null | tee "$OUT/c3_profile.txt"
+BNF_LIB=$ROOT/ab/libbnf_head.so cfg head C4; cfg new C4
+BNF_LIB=$ROOT/ab/libbnf_head.so cfg head C5; cfg new C5
+echo "== C2"; VARIANTS="head:ab/libbnf_head.so new:" REPS=3 STEPS=20 bash scripts/gpu_abn.sh 2>&1 | tee "$OUT/ab_c2.txt"
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline --profile-all 2>&1 | grep "\[bench\]" | tee "$OUT/c2_kernels.txt"
