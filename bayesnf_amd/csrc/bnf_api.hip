@@ -200,7 +200,7 @@ static size_t carve(bnf_handle* h, char* base) {
   // no transposed copies (the weight-gradient contraction reads row-major, gemm_tn); the row-panel
   // kernel reads the features as MFMA A fragments from a second, fragment-major copy (H0t slot)
   // (the H0L variant -- W = 512, Fp = 64 -- stages the row-major copy in LDS instead and skips it)
-  h->h0l = h->panel && (((h->W == 512 || h->W == 1024) && h->Fp == 64) || (h->W == 256 && h->Fp == 128)) && !getenv("BNF_PANEL_NO_H0L");
+  h->h0l = h->panel && (((h->W == 512 || h->W == 1024) && h->Fp == 64) || (h->W == 256 && (h->Fp == 64 || h->Fp == 128))) && !getenv("BNF_PANEL_NO_H0L");
   h->H0t = (h->panel && !h->h0l) ? take((size_t)Ev * Bp * Fp * es) : nullptr;
   for (int l = 0; l < h->L; ++l) {
     h->A[l] = (h->panel || (h->fuse_last && l == h->L - 1) || (h->recompute_a0 && l == 0)) ? nullptr : take((size_t)Ev * W * (Bp + kAtPad) * es);  // A_l^T (W, Bp + pad)
@@ -901,11 +901,12 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
       launch_panel<8, 4, false>(h, pa);
     }
   } else if (h->h0l) {
-    // W = 256 with 65 .. 128 padded features (C5): 128-row panels (two row blocks of 64) so that the feature panel
-    // (128 x 272 bytes) fits in LDS beside the activation panel; featurisation backward fused
+    // W = 256 (C5: 65 .. 128 padded features; C1: 64): 128-row panels (two row blocks of 64) so that the feature panel
+    // (128 x 272 or 144 bytes) fits in LDS beside the activation panel; featurisation backward fused
     pa.panels = (int32_t)(Bp / panel_rows(4, 2));
     with_fused_featbwd();
-    launch_panel<4, 2, true, 1, 128>(h, pa);
+    if (h->Fp == 128) launch_panel<4, 2, true, 1, 128>(h, pa);
+    else launch_panel<4, 2, true, 1, 64>(h, pa);
   } else {
     pa.panels = (int32_t)(Bp / panel_rows(4, 4));
     launch_panel<4, 4, false>(h, pa);
@@ -1305,7 +1306,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
     // its contraction depth is Fp <= 128: cheaper to redo than to write + gather A_0^T
     h->recompute_a0 = !cfg->forward_only && !h->panel && want == 0 && h->L >= 2 && h->Fp <= 128;
   }
-  h->h0l = h->panel && (((h->W == 512 || h->W == 1024) && h->Fp == 64) || (h->W == 256 && h->Fp == 128)) && !getenv("BNF_PANEL_NO_H0L");
+  h->h0l = h->panel && (((h->W == 512 || h->W == 1024) && h->Fp == 64) || (h->W == 256 && (h->Fp == 64 || h->Fp == 128))) && !getenv("BNF_PANEL_NO_H0L");
   if (h->h0l &&
       !(getenv("BNF_PANEL_FEATBWD") && atoi(getenv("BNF_PANEL_FEATBWD")) == 0)) {
     // fused featurisation backward of the H0L panel kernel: what each feature column contributes

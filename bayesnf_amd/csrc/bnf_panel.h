@@ -183,8 +183,9 @@ __host__ __device__ constexpr int panel_rows(int wn, int rt) { return 32 * rt * 
 __host__ __device__ constexpr int panel_lds_bytes(int wn, int rt, bool h0l, int ch = 1, int fp = 64) {
   const int W = 64 * wn * ch, BM = panel_rows(wn, rt), RB = 8 / wn;
   const int image = BM * (W * 2 + 16), dots = 8 * 64 * 36 * 4;
+  const bool own_fb = fp > 64 || RB > 1 || W < 512;   // (else the sums of the fused featurisation backward fit in s_col)
   return (image > dots ? image : dots) + (BM * wn * ch + BM + 2 * RB * W + 128) * 4 +
-         (h0l ? BM * (fp * 2 + 16) + (fp > 64 ? 2 * (BM / 32) * fp * 4 : 0) : 0);
+         (h0l ? BM * (fp * 2 + 16) + (own_fb ? 2 * (BM / 32) * fp * 4 : 0) : 0);
 }
 
 // Makes a lane value opaque to the optimiser at this point: everything derived from it (fragment
@@ -319,7 +320,6 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   const char* h0s = reinterpret_cast<const char*>(s_sc + 128);   // [BM][kH0Pitch] feature panel (H0L)
   // per (row tile, feature column) sums of the fused featurisation backward, two arrays of [BM / 32][FP]
   float* s_fb = (FP > 64 || RB > 1 || W < 512) ? reinterpret_cast<float*>(const_cast<char*>(h0s) + BM * kH0Pitch) : s_col + W;
-  static_assert(!H0L || FP > 64 || (RB == 1 && W >= 512), "fused featurisation backward scratch: s_col[W..2W) holds 2 x BM/32 x 64 floats only for one row block and W >= 512");
 
   const int tid_k = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid_k >> 6);

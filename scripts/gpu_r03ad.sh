@@ -6,5 +6,5 @@ echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovid
 cfg() { timeout 400 python scripts/bench_configs.py $2 2>/dev/null | python -c "import sys,json
 for l in sys.stdin:
   d=json.loads(l); print('$1', d['config'][:5], round(d['member_steps_per_s'],1), round(d['algorithmic_tflops'],1), round(d['final_loss_mean'],1))"; }
-for c in C3 C5; do BNF_LIB=$ROOT/ab/libbnf_head.so cfg head $c; cfg new $c; done 2>&1 | tee "$OUT/ab.txt"
+for c in C5; do BNF_LIB=$ROOT/ab/libbnf_head.so cfg head $c; cfg new $c; done 2>&1 | tee "$OUT/ab.txt"
 echo "== C2"; VARIANTS="head:ab/libbnf_head.so new:" REPS=2 STEPS=20 bash scripts/gpu_abn.sh 2>&1 | tee "$OUT/ab_c2.txt"
