@@ -1,7 +1,7 @@
 #!/bin/bash
 # r03 evidence visit: -m gpu suite, smoke, bench (+cpu_baseline), rocprof kernel stats, PMC HBM traffic, SQ counters
 # (-> profiles/sq_counters.json, pmc_traffic.json), per-config benches + per-kernel tables of C3 / C4 / C5, phase clocks
-set -u
+set -u; ulimit -c 0
 TAG=${1:-r03z}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; cd "$ROOT"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -22,3 +22,7 @@ python scripts/counter_summary.py "$OUT/../${TAG}_ctr" "$OUT/sq_counters.json" >
 echo "== configs"; for c in C3 C4 C5; do timeout 600 python scripts/bench_configs.py $c 2>/dev/null | tail -1; done > "$OUT/configs_bench.jsonl"; cut -c1-330 "$OUT/configs_bench.jsonl"
 for c in "C3/8 air_quality-like VI" "C4/8 synthetic minibatch MLE" "C5/8 wind-like MAP (bf16)"; do echo "== $c"; timeout 200 python scripts/profile_config.py "$c" 2>/dev/null; done > "$OUT/config_profiles.txt"
 echo "== phase clocks"; THREADS="0 448" bash scripts/gpu_phase_clocks.sh 2>&1 | tee "$OUT/phase_clocks.txt"
+echo "== C1 step time"; timeout 300 python scripts/c1_step_time.py 2>/dev/null | tee "$OUT/c1_step_time.txt"
+echo "== C1 without the LDS feature panel"; BNF_PANEL_NO_H0L=1 timeout 300 python scripts/c1_step_time.py 2>/dev/null | grep bf16 | tee -a "$OUT/c1_step_time.txt"
+echo "== shuffle draw cost"; timeout 600 python scripts/shuffle_cost.py 2>/dev/null | tee "$OUT/shuffle_cost.txt"
+echo "== PMC traffic of C3 / C5"; bash scripts/gpu_pmc_cfg.sh ${TAG}_pmc C3 C5 2>&1 | cut -c1-200 | tail -28
