@@ -1370,12 +1370,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_skinny(const GemmArgs g, const
 constexpr int kRgRows = 32, kRgStages = 4, kRgOp = kRgRows * 512, kRgStage = 2 * kRgOp;
 constexpr int kRgLds = kRgStages * kRgStage;
 // SWAP (split-K = 1, plain stores): the MFMA operands in swapped roles, see mma_k
-template <int TAG, bool SWAP>
-__global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const EpiArgs ep) {
+// NW = 4 (not instantiated: measured slower): FOUR waves of 128 x 128 (4 x 4 accumulators pinned in the 256 accumulation
+// registers, one wave per SIMD): 16 transpose reads per 16 MFMAs instead of 12 per 8 -- a third less LDS traffic per MFMA,
+// clean loop (32 MFMAs, 32 reads, one barrier, no moves, no scratch), parity green, and 419 us against 376 - 384 us at C2,
+// C3/8 6,380 against 6,460, C4/8 677 against 692 (gpurun_out/r03af): with one wave per SIMD nothing hides a wave's own
+// LDS and barrier latencies.
+template <int TAG, bool SWAP, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gemm_tn_ring(const GemmArgs g, const EpiArgs ep) {
+  constexpr int TJ = NW == 8 ? 2 : 4;        // 32-column accumulator tiles per wave (x 4 row tiles of 32)
+  constexpr int QN = 16 / NW;                // 1 KiB wave-loads per operand, stage and wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave / (NW / 2), wc = wave % (NW / 2);
 
   const int n_multi = g.n_multi > 1 ? g.n_multi : 1;
   const uint32_t per_layer = (uint32_t)(g.tiles_m * g.tiles_n * g.splitk);
@@ -1390,9 +1397,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const E
   w -= (uint32_t)split * tiles;
   const int tm = (int)(w / (uint32_t)g.tiles_n), tn = (int)(w % (uint32_t)g.tiles_n);
   const int m0 = tm * 256, n0 = tn * 256;
-  const void* gA = g.n_multi > 1 ? g.A_multi[which] : g.A;
-  const void* gB = g.n_multi > 1 ? g.B_multi[which] : g.B;
-  const int32_t off_out = g.n_multi > 1 ? g.off_out_multi[which] : ep.off_out;
+  // (selected by uniform compares: a dynamically indexed by-value argument array is copied to scratch)
+  const void* gA = g.A;
+  const void* gB = g.B;
+  int32_t off_out = ep.off_out;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (g.n_multi > 1 && which == k) { gA = g.A_multi[k]; gB = g.B_multi[k]; off_out = g.off_out_multi[k]; }
 
   const int nk_total = g.K / kRgRows;
   const int nk_per = (nk_total + g.splitk - 1) / g.splitk;
@@ -1402,10 +1413,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const E
   const char* Ab = reinterpret_cast<const char*>(gA) + (int64_t)e * g.a_batch * 2 + m0 * 2;
   const char* Bb = reinterpret_cast<const char*>(gB) + (int64_t)e * g.b_batch * 2 + n0 * 2;
 
-  uint32_t src_a[2], src_b[2];
+  uint32_t src_a[QN], src_b[QN];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int srow = (wave * 2 + q) * 2 + (lane >> 5);
+  for (int q = 0; q < QN; ++q) {
+    const int srow = (wave * QN + q) * 2 + (lane >> 5);
     const uint32_t schunk = (uint32_t)(((lane & 31) ^ ((srow & 3) << 2)) * 16);
     src_a[q] = (uint32_t)srow * (uint32_t)g.a_ld * 2u + schunk;
     src_b[q] = (uint32_t)srow * (uint32_t)g.b_ld * 2u + schunk;
@@ -1424,17 +1435,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const E
     const char* pa = pin(Ab + (int64_t)kt * kRgRows * g.a_ld * 2);
     const char* pb = pin(Bb + (int64_t)kt * kRgRows * g.b_ld * 2);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + src_a[q]), (lds_void_t*)(sA + (wave * 2 + q) * 1024), 16, 0, BNF_TN_AUX);
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + src_b[q]), (lds_void_t*)(sB + (wave * 2 + q) * 1024), 16, 0, BNF_TN_AUX);
+    for (int q = 0; q < QN; ++q) {
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + src_a[q]), (lds_void_t*)(sA + (wave * QN + q) * 1024), 16, 0, BNF_TN_AUX);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + src_b[q]), (lds_void_t*)(sB + (wave * QN + q) * 1024), 16, 0, BNF_TN_AUX);
     }
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][TJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -1444,7 +1455,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const E
   typedef __attribute__((address_space(3))) char lds_char_t;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char_t*)smem;
   // byte offsets of the transpose reads in a stage for t = 0, k step 0 (t = 1: + 4 rows, k step 1: + 16 rows)
-  uint32_t off_a[4], off_b[2];
+  uint32_t off_a[4], off_b[TJ];
   {
     const int row = kg * 8 + prow;
 #pragma unroll
@@ -1453,13 +1464,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const E
       off_a[i] = lds0 + (uint32_t)(row * 512 + ((ba & ~63) ^ ((row & 3) << 6)) + (ba & 63));
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int bb = (wc * 64 + j * 32 + pcol) * 2;
+    for (int j = 0; j < TJ; ++j) {
+      const int bb = (wc * (32 * TJ) + j * 32 + pcol) * 2;
       off_b[j] = lds0 + (uint32_t)(kRgOp + row * 512 + ((bb & ~63) ^ ((row & 3) << 6)) + (bb & 63));
     }
   }
   struct Frags {
-    u32x2_t a[2][4], b[2][2];   // [t][tile]
+    u32x2_t a[2][4], b[2][TJ];   // [t][tile]
   };
   auto read_k = [&](Frags& f, int sb, auto ks_tag) {
     constexpr int ks = decltype(ks_tag)::value;
@@ -1469,29 +1480,35 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const E
       f.a[1][i] = lds_tr16_b64<ks * 16 * 512 + 4 * 512>(off_a[i] + sb * kRgStage);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TJ; ++j) {
       f.b[0][j] = lds_tr16_b64<ks * 16 * 512>(off_b[j] + sb * kRgStage);
       f.b[1][j] = lds_tr16_b64<ks * 16 * 512 + 4 * 512>(off_b[j] + sb * kRgStage);
     }
   };
   auto fence = [&](Frags& f) {
+    if constexpr (TJ == 4)
+      asm volatile("" : "+v"(f.b[0][2]), "+v"(f.b[0][3]), "+v"(f.b[1][2]), "+v"(f.b[1][3]));
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[0][2]), "+v"(f.a[0][3]), "+v"(f.a[1][0]), "+v"(f.a[1][1]),
                    "+v"(f.a[1][2]), "+v"(f.a[1][3]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1]));
+    if constexpr (TJ == 4)
+      asm volatile("" : "+v"(f.b[0][2]), "+v"(f.b[0][3]), "+v"(f.b[1][2]), "+v"(f.b[1][3]));
   };
   auto touch = [&](Frags& f) {
     asm volatile("" : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[0][2]), "+v"(f.a[0][3]), "+v"(f.a[1][0]), "+v"(f.a[1][1]),
                       "+v"(f.a[1][2]), "+v"(f.a[1][3]), "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1]));
+    if constexpr (TJ == 4)
+      asm volatile("" : "+v"(f.b[0][2]), "+v"(f.b[0][3]), "+v"(f.b[1][2]), "+v"(f.b[1][3]));
   };
   auto mma_k = [&](const Frags& f) {
-    bf16x8 fa[4], fb[2];
+    bf16x8 fa[4], fb[TJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const u32x4 wa = {f.a[0][i].x, f.a[0][i].y, f.a[1][i].x, f.a[1][i].y};
       fa[i] = __builtin_bit_cast(bf16x8, wa);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TJ; ++j) {
       const u32x4 wb = {f.b[0][j].x, f.b[0][j].y, f.b[1][j].x, f.b[1][j].y};
       fb[j] = __builtin_bit_cast(bf16x8, wb);
     }
@@ -1502,21 +1519,27 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const E
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TJ; ++j)
         acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0)
                          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    if constexpr (NW == 4) {   // all sixteen accumulators in the accumulation registers here: nothing else may live there
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]));
+    }
   };
   using K0 = std::integral_constant<int, 0>;
   using K1 = std::integral_constant<int, 1>;
 
-  constexpr int kPerWave = 4;
-  constexpr int kWait1 = (kPerWave & 15) | 0x0F70;
+  constexpr int kPerWave = 2 * QN;          // LDS-DMA loads of one stage per wave
+  auto vm = [](int n) constexpr { return (n & 15) | ((n >> 4) << 14) | 0x0F70; };   // s_waitcnt vmcnt(n) only
+  constexpr int kWait1 = vm(kPerWave);
   constexpr int kWaitAll = 0x0F70;
 #pragma unroll
   for (int s = 0; s < kRgStages - 1; ++s)
     if (kt0 + s < kt1) stage(s, kt0 + s);
   if (kt0 + 1 < kt1) {
-    if (kt0 + 2 < kt1) __builtin_amdgcn_s_waitcnt((2 * kPerWave & 15) | 0x0F70);
+    if (kt0 + 2 < kt1) __builtin_amdgcn_s_waitcnt(vm(2 * kPerWave));
     else __builtin_amdgcn_s_waitcnt(kWait1);
   } else {
     __builtin_amdgcn_s_waitcnt(kWaitAll);
@@ -1528,7 +1551,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const E
     read_k(f1, 0, K1{});
   }
   for (int ktb = kt0; ktb < kt1; ktb += kRgStages) {
-#pragma unroll
+#pragma unroll(NW == 8 ? kRgStages : 1)
     for (int sb = 0; sb < kRgStages; ++sb) {
       const int kt = ktb + sb;
       if (kt >= kt1) break;
@@ -1551,12 +1574,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const E
                           : ep.grad + (int64_t)e * ep.grad_stride + off_out;
   if constexpr (SWAP) {
     const int mw = m0 + wr * 128 + frow;
-    const int nw = n0 + wc * 64 + 4 * kg;
+    const int nw = n0 + wc * (32 * TJ) + 4 * kg;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float* orow = out + (int64_t)(mw + i * 32) * ep.ld_f32 + nw;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TJ; ++j)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const float v[4] = {acc[i][j][rg * 4] * ep.scale, acc[i][j][rg * 4 + 1] * ep.scale,
@@ -1566,9 +1589,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring(const GemmArgs g, const E
     }
   } else {
     const int mw = m0 + wr * 128 + 4 * kg;
-    const int nw = n0 + wc * 64 + frow;
+    const int nw = n0 + wc * (32 * TJ) + frow;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TJ; ++j) {
       const int n = nw + j * 32;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
