@@ -482,8 +482,9 @@ struct LastBwdArgs {
   int32_t tiles_per_task;
 };
 
+// (f32: 64 registers of tile + 64 of loads in flight -- two waves per SIMD would spill 198 of them)
 template <typename T>
-__global__ __launch_bounds__(256, 2) void k_last_bwd(NetDev nd, const LastBwdArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void k_last_bwd(NetDev nd, const LastBwdArgs a) {
   constexpr bool FAST = Elem<T>::kFast;
   const int e = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
