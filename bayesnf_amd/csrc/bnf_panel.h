@@ -1,4 +1,9 @@
-// bnf_panel.h -- row-panel forward + backward of a depth-2 BayesNF member in ONE kernel (bf16).
+// bnf_panel.h -- row-panel forward + backward of a BayesNF member in ONE kernel (bf16; the two-layer network is
+// described here, DEEP adds the middle layers in the same pattern).  Instances (template <WN, RT, H0L, DEEP, CH, FP>):
+//   <8, 4, H0L, ., 1, 64>   W = 512: 128-row panels                                   (C2, C3)
+//   <8, 2, H0L, ., 2, 64>   W = 1024: 64-row panels, two 64-column slabs per wave      (C4)
+//   <4, 2, true, ., 1, FP>  W = 256: 128-row panels of two 64-row blocks, FP = 64 | 128 (C1, C5)
+//   <4, 4, false, ., 1, 64> W = 256 without the LDS feature panel: 256-row panels
 //
 // A workgroup (8 waves, one per CU: 256 registers per lane) owns a panel of BM batch rows of one
 // ensemble member and carries it through the network and back (reference models.py:212-273,
@@ -12,8 +17,8 @@
 //
 // What leaves the chip is exactly what the weight-gradient contractions (gemm_tn) and the feature
 // backward kernel read afterwards: H1, dZ1, dZ0 (bf16, row-major) and dH0^T -- the latter only for
-// the variants that still run k_feat_bwd: <8, 4, true> (C2) finishes the featurisation backward
-// itself from the dH0 tiles in registers and the feature panel in LDS (phase 9).  It replaces
+// the variants that still run k_feat_bwd: the H0L forms finish the featurisation backward
+// themselves from the dH0 tiles in registers and the feature panel in LDS (phase 9).  It replaces
 // gemm_fwd_l0 + gemm_fwd_last + gemm_dgrad + gemm_dgrad0 of the layer pipeline (and their HBM
 // round trips of H1 / dZ1 / dZ0 as contraction operands: 2.0 GB of the 8.0 GB per C2 step).
 //
