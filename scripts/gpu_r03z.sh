@@ -22,6 +22,7 @@ python scripts/counter_summary.py "$OUT/../${TAG}_ctr" "$OUT/sq_counters.json" >
 echo "== configs"; for c in C3 C4 C5; do timeout 600 python scripts/bench_configs.py $c 2>/dev/null | tail -1; done > "$OUT/configs_bench.jsonl"; cut -c1-330 "$OUT/configs_bench.jsonl"
 for c in "C3/8 air_quality-like VI" "C4/8 synthetic minibatch MLE" "C5/8 wind-like MAP (bf16)"; do echo "== $c"; timeout 200 python scripts/profile_config.py "$c" 2>/dev/null; done > "$OUT/config_profiles.txt"
 echo "== phase clocks"; THREADS="0 448" bash scripts/gpu_phase_clocks.sh 2>&1 | tee "$OUT/phase_clocks.txt"
+echo "== bench fp32"; timeout 600 python bench.py --dtype fp32 --steps 10 --warmup 2 --no-cpu-baseline --profile-all > "$OUT/bench_fp32.json" 2> "$OUT/bench_fp32.err"; cut -c1-400 "$OUT/bench_fp32.json"; grep "\[bench\]" "$OUT/bench_fp32.err" > "$OUT/bench_fp32_hip_events.txt"
 echo "== C1 step time"; timeout 300 python scripts/c1_step_time.py 2>/dev/null | tee "$OUT/c1_step_time.txt"
 echo "== C1 without the LDS feature panel"; BNF_PANEL_NO_H0L=1 timeout 300 python scripts/c1_step_time.py 2>/dev/null | grep bf16 | tee -a "$OUT/c1_step_time.txt"
 echo "== shuffle draw cost"; timeout 600 python scripts/shuffle_cost.py 2>/dev/null | tee "$OUT/shuffle_cost.txt"
