@@ -51,7 +51,7 @@ KERNEL_SYMBOL = {   # gemm_nt<T, epilogue, tag, wave rows, wave cols>
     'gemm_dgrad0': 'void bnf::gemm_nt<{T}, 2, 0, 2, 2>(bnf::GemmArgs, bnf::EpiArgs)',
     # the benchmark shape (bf16, W = 512, Fp = 64) runs the HBM-stream forms of the weight gradients
     'gemm_wgrad_l0': 'bnf::gemm_tn_skinny(bnf::GemmArgs, bnf::EpiArgs)',
-    'gemm_wgrad': 'void bnf::gemm_tn_ring<1, true>(bnf::GemmArgs, bnf::EpiArgs)',
+    'gemm_wgrad': 'void bnf::gemm_tn_ring<1, true',   # (+ the wave count)
     'last_bwd': 'void bnf::k_last_bwd<{T}>',
     'panel_fwd_bwd': 'void bnf::k_panel_fwd_bwd<8, 4, true',   # (+ the DEEP flag: false at the benchmark depth)
 }
