@@ -167,13 +167,24 @@ def allgather(send, recv, world: int, rank: int, lib=None):
   dev = send.device.index if send.is_cuda else -1
   key = (world, rank, dev, id(lib))
   if key not in _comm_cache:
-    ident = torch.zeros(128, dtype=torch.uint8)
-    if rank == 0:
-      buf = (C.c_char * 128)()
-      check(lib.bnf_comm_unique_id(buf), 'bnf_comm_unique_id')
-      ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    # Every rank first finds out LOCALLY whether the library can reach RCCL at all (an id costs nothing), and the
+    # ranks agree on it before anything that only some of them would enter: a rank that raised here while the others
+    # waited in the broadcast / in ncclCommInitRank would hang the job instead of failing it.
+    on_dev = send.is_cuda and world > 1 and torch.distributed.get_backend() == 'nccl'
+    buf = (C.c_char * 128)()
+    rc = lib.bnf_comm_unique_id(buf)
+    err = None if rc == 0 else (last_error() if hasattr(lib, 'bnf_last_error') else f'code {rc}')
     if world > 1:
-      carrier = ident.to(send.device) if send.is_cuda and torch.distributed.get_backend() == 'nccl' else ident
+      flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32)
+      flag = flag.to(send.device) if on_dev else flag
+      torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+      if int(flag.item()) == 0:
+        raise RuntimeError('bnf_comm_unique_id failed on at least one rank' + (f' (here: {err})' if err else ''))
+    elif rc != 0:
+      raise RuntimeError(f'bnf_comm_unique_id: {err}')
+    ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    if world > 1:
+      carrier = ident.to(send.device) if on_dev else ident
       torch.distributed.broadcast(carrier, src=0)
       ident = carrier.cpu()
     comm = C.c_void_p()
