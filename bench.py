@@ -21,6 +21,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
   cpu_baseline  the oracle's algorithm on torch CPU float32 with torch.bmm over members (a port of
                 the reference algorithm, NOT JAX) timed on this box's host cores on a bounded
                 sample (N=1 only).
+  device_preheat  ms of untimed steps on a SCRATCH engine before the W warm-up steps of the measured one
+                (--preheat-ms, default 100, 0 = off): after an idle period the device ramps for ~8 steps
+                whatever engine runs on it (profiles/r03_device_ramp.txt); a fit is thousands of steps.
 `--gpus N` without a launcher starts the N ranks itself (torch.distributed.run, 127.0.0.1) and
 refuses to run when fewer than N devices are visible; the line carries `rccl_world_size` (from an
 actual all_reduce), every rank's ms/step and, for N > 1, the one posterior all-gather.
@@ -413,6 +416,11 @@ def main(argv=None):
                        "BNF_GATHER) or torch.distributed's all_gather_into_tensor")
   ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--preheat-ms', type=float, default=100.0,
+                  help='bring the DEVICE to the power / clock state a long fit runs in: this many ms of untimed steps on a '
+                       'scratch engine (other parameters, other buffers) before the W warm-up steps of the measured engine; '
+                       '0 = off.  A 20-step sample that starts on an idle device reads ~3 %% above the 200-step rate '
+                       '(profiles/r03z_bench_200_steps.txt, r03_device_ramp.txt)')
   ap.add_argument('--profile-all', action='store_true',
                   help='also print the per-kernel HIP-event table to stderr')
   ap.add_argument('--selftest-cpu', action='store_true',
@@ -468,6 +476,19 @@ def main(argv=None):
     eng = Engine(net, mode='map', X=X, y=y, members=E, member_offset=rank * E, seed=0,
                  learning_rate=0.005, prior_weight=1.0, compute_dtype=args.dtype)
     eng.init_params(float(np.log(np.nanstd(y) / 2)))
+    # the device ramps for ~8 steps (16 ms) after an idle period, whatever engine runs on it: a fresh engine's steps
+    # 2..8 take 2.6 -> 2.03 ms, a second engine's in the same process 2.11 -> 2.0 (profiles/r03_device_ramp.txt)
+    if args.preheat_ms > 0:
+      scratch = Engine(net, mode='map', X=X, y=y, members=E, member_offset=rank * E, seed=1,
+                       learning_rate=0.005, prior_weight=1.0, compute_dtype=args.dtype)
+      scratch.init_params(0.0)
+      t_h = time.perf_counter()
+      ep_h = 0
+      while (time.perf_counter() - t_h) * 1e3 < args.preheat_ms:
+        scratch.train(ep_h, 8)
+        torch.cuda.synchronize(device)
+        ep_h += 8
+      scratch.close()
     # ---- warm-up (also finds the dominant kernel) --------------------------------
     eng.profile('*')
     eng.train(0, max(args.warmup, 1))
@@ -557,6 +578,8 @@ def main(argv=None):
     if args.selftest_cpu:
       line['selftest'] = True
     else:
+      line['device_preheat'] = {'ms': args.preheat_ms, 'what': 'untimed steps of a scratch engine (other parameters and buffers) '
+                                'before the W warm-up steps of the measured engine: device power / clock state; --preheat-ms 0 = off'}
       d = prof[dominant]
       achieved = d['flops'] / (d['avg_ms'] * 1e-3) / 1e12 if d['flops'] else 0.0
       peak = PEAK_TFLOPS[args.dtype]
