@@ -10,6 +10,7 @@ echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== bench"; timeout 900 python bench.py --steps 30 --warmup 5 --profile-all ${BENCH_ARGS:-} > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 cat "$OUT/bench.json"; grep "\[bench\]" "$OUT/bench.err" | tee "$OUT/bench_hip_events.txt"
 echo "== bench x3 (20 steps, the driver's command)"; for i in 1 2 3; do python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), round(d['value']), round(d['roofline']['frac'],4), round(d['roofline']['avg_launch_us'],1))"; done | tee "$OUT/bench_repeat.txt"
+echo "== bench without the device preheat (20 steps)"; python bench.py --steps 20 --warmup 3 --no-cpu-baseline --preheat-ms 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), round(d['value']), round(d['roofline']['frac'],4), round(d['roofline']['avg_launch_us'],1), 'preheat 0')" | tee -a "$OUT/bench_repeat.txt"
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/rocprof_bench.json" 2> "$OUT/rocprof.err"; echo "rocprof rc=$?"
 cd "$ROOT"
