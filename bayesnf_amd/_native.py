@@ -17,7 +17,7 @@ from . import spec as _spec
 _LIB_NAME = 'libbnf_hip.so'
 _lib = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_INPUTS, MAX_GROUPS, MAX_LAYERS, MAX_FREQS, MAX_INTERACT = 8, 12, 8, 96, 16
 DTYPE = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
 OBS = {'NORMAL': 0, 'NB': 1, 'ZINB': 2}
@@ -27,7 +27,7 @@ PIPELINE = {'auto': 0, 'layers': 1, 'panel': 3}
 EXPORTS = (
     'bnf_abi_version', 'bnf_last_error', 'bnf_create', 'bnf_destroy',
     'bnf_workspace_bytes', 'bnf_state_bytes', 'bnf_param_bytes', 'bnf_bind',
-    'bnf_init_params', 'bnf_train', 'bnf_row_tables', 'bnf_row_keys', 'bnf_vi_posterior_draws', 'bnf_vi_noise_keys', 'bnf_forward',
+    'bnf_init_params', 'bnf_init_params_keys', 'bnf_train', 'bnf_row_tables', 'bnf_row_keys', 'bnf_vi_posterior_draws', 'bnf_vi_noise_keys', 'bnf_forward',
     'bnf_normal_mixture_quantiles', 'bnf_count_mixture_quantiles', 'bnf_debug_loss_and_grad',
     'bnf_debug_row_index', 'bnf_debug_vi_eps', 'bnf_debug_vi_noise', 'bnf_debug_activation',
     'bnf_debug_gemm_nt', 'bnf_debug_gemm_tn', 'bnf_debug_poison_lds', 'bnf_profile_enable', 'bnf_profile_read',
@@ -121,6 +121,7 @@ def load():
   lib.bnf_debug_poison_lds.argtypes = [vp, C.c_uint32]
   lib.bnf_row_tables.argtypes = [vp, vp, i64, i64]
   lib.bnf_row_keys.argtypes = [vp, vp, i64, i64, C.c_int32]
+  lib.bnf_init_params_keys.argtypes = [vp, vp, C.POINTER(C.c_int32), C.c_int32, C.c_float]
   lib.bnf_vi_noise_keys.argtypes = [vp, vp, i64, vp, i64, vp, C.c_int32]
   lib.bnf_debug_activation.argtypes = [vp, i32, vp]
   lib.bnf_debug_gemm_nt.argtypes = [vp, vp, vp, i32, i32, i32, vp]

@@ -1469,6 +1469,34 @@ int bnf_init_params(bnf_handle* h, float log_noise_init) {
   return BNF_OK;
 }
 
+int bnf_init_params_keys(bnf_handle* h, const uint32_t* leaf_keys, const int32_t* leaf_offsets, int32_t n_leaves,
+                         float log_noise_init) {
+  if (!h || !h->bound) return fail(BNF_ERR_STATE, "bnf_init_params_keys before bnf_bind");
+  if (h->cfg.forward_only || !h->params) return fail(BNF_ERR_STATE, "forward_only handle");
+  if (!leaf_keys || !leaf_offsets || n_leaves < 1 || n_leaves > 64) return fail(BNF_ERR_INVALID, "leaf_keys / leaf_offsets / n_leaves (1..64)");
+  if (leaf_offsets[0] != 0 || leaf_offsets[n_leaves] != h->P) return fail(BNF_ERR_INVALID, "leaf_offsets must cover [0, P)");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  LeafTable lt{};
+  lt.n = n_leaves;
+  for (int k = 0; k <= n_leaves; ++k) lt.off[k] = leaf_offsets[k];
+  const int E = h->cfg.members;
+  // bounds of the uniform: erf(-+2 / sqrt2) in f32, as jax.random.truncated_normal forms them
+  const float ua = (float)std::erf((double)(-2.0f / 1.41421356237309504880f));
+  const float ub = (float)std::erf((double)(2.0f / 1.41421356237309504880f));
+  dim3 grid(cdiv(h->P, 256), (unsigned)E);
+  hipLaunchKernelGGL(k_init_params_keys, grid, dim3(256), 0, h->stream, h->params, h->P, h->is_matrix, lt, leaf_keys,
+                     h->nd.off_lns, log_noise_init, ua, ub);
+  if (h->cfg.mode == BNF_MODE_VI) {
+    const int64_t n = (int64_t)E * h->P;
+    hipLaunchKernelGGL(k_fill, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, h->params + n, n, -1.0502256128148466f);
+  }
+  HIPCHK(hipMemsetAsync(h->state, 0, bnf_state_bytes(h), h->stream));
+  HIPCHK(hipGetLastError());
+  h->adam_t = 0;
+  h->vi_keys = h->vi_draw_keys = nullptr; h->vi_key_rows = h->vi_draw_rows = 0; h->vi_key_t0 = 0;
+  return BNF_OK;
+}
+
 int bnf_train(bnf_handle* h, int64_t epoch0, int64_t num_epochs, float* losses) {
   if (!h || !h->bound) return fail(BNF_ERR_STATE, "bnf_train before bnf_bind");
   if (!losses || num_epochs < 0) return fail(BNF_ERR_INVALID, "losses / num_epochs");

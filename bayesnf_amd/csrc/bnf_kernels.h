@@ -927,6 +927,43 @@ __global__ __launch_bounds__(256) void k_init_params(float* __restrict__ theta, 
   theta[(int64_t)e * P + p] = v;
 }
 
+// The reference's OWN initial Dense kernels for a member key chain (bnf_init_params_keys): element i of leaf lf of
+// member e = sqrt2 erfinv(u) clipped to (-2, 2), u uniform on [erf(-sqrt2), erf(sqrt2)) from
+// random_bits(leaf_keys[e][lf], (size,))[i] -- jax.random.truncated_normal as TFP's TruncatedNormal(0, 1, -2, 2) sampler
+// calls it (inference.py:399-427, 203-231); every other leaf 0, log_noise_scale = lns_init.  The f32 erfinv is XLA's
+// polynomial (erfinv_f32); the host restatement (jaxseed.truncated_normal_std: scipy f64 erfinv rounded to f32)
+// differs from it by at most one ulp in a few elements.
+struct LeafTable {
+  int32_t n;
+  int32_t off[65];        // n + 1 offsets of the packed leaves
+};
+__global__ __launch_bounds__(256) void k_init_params_keys(float* __restrict__ theta, int32_t P,
+                                                          const uint8_t* __restrict__ is_matrix, LeafTable lt,
+                                                          const uint32_t* __restrict__ leaf_keys, int32_t off_lns,
+                                                          float lns_init, float ua, float ub) {
+  const int e = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float v = 0.f;
+  if (is_matrix[p]) {
+    int lf = 0;
+    for (int k = 1; k < lt.n; ++k) lf = (p >= lt.off[k]) ? k : lf;
+    const uint32_t n = (uint32_t)(lt.off[lf + 1] - lt.off[lf]), idx = (uint32_t)(p - lt.off[lf]);
+    const uint32_t half = (n + 1u) >> 1;
+    const uint32_t* k = leaf_keys + ((int64_t)e * lt.n + lf) * 2;
+    uint32_t y0, y1;
+    if (idx < half) threefry2x32(k[0], k[1], idx, idx + half < n ? idx + half : 0u, &y0, &y1);
+    else { threefry2x32(k[0], k[1], idx - half, idx, &y0, &y1); y0 = y1; }
+    const float f = __builtin_bit_cast(float, (y0 >> 9) | 0x3F800000u) - 1.0f;
+    const float u = fmaxf(ua, f * (ub - ua) + ua);
+    const float x = 1.41421356237309504880f * erfinv_f32(u);
+    v = fminf(fmaxf(x, -1.99999988f), 1.99999988f);      // nextafter(-+2, 0)
+  } else if (p == off_lns) {
+    v = lns_init;
+  }
+  theta[(int64_t)e * P + p] = v;
+}
+
 __global__ void k_fill(float* p, int64_t n, float v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

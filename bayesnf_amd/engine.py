@@ -128,6 +128,22 @@ class Engine:
     _native.check(self.lib.bnf_init_params(self.handle, C.c_float(log_noise_init)),
                   'bnf_init_params')
 
+  def init_params_keys(self, leaf_keys, log_noise_init: float = 0.0):
+    """The reference's own initial parameters (VI: surrogate means) drawn on the device from the members' per-leaf
+    keys (include/bnf.h bnf_init_params_keys): uint32 (members, n_leaves, 2) from jaxseed.map_leaf_keys /
+    vi_mean_leaf_keys."""
+    from . import jaxseed
+    k = np.ascontiguousarray(leaf_keys, dtype=np.uint32)
+    n_leaves = len(self.net.leaves)
+    if k.shape != (self.members, n_leaves, 2):
+      raise ValueError(f'leaf keys must be uint32 ({self.members}, {n_leaves}, 2); got {k.shape}')
+    t = torch.from_numpy(k.view(np.int32)).to(self.device)
+    off = jaxseed.leaf_offsets(self.net)
+    arr = (C.c_int32 * len(off))(*[int(v) for v in off])
+    _native.check(self.lib.bnf_init_params_keys(self.handle, _ptr(t), arr, n_leaves, float(log_noise_init)),
+                  'bnf_init_params_keys')
+    torch.cuda.synchronize(self.device)     # `t` is released on return
+
   def set_params(self, theta):
     """theta: array (members, P) [MAP] or (2, members, P) = (mu, rho) [VI]."""
     t = torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float32))

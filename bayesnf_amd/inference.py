@@ -97,7 +97,8 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
                    learning_rate=learning_rate, prior_weight=prior_weight,
                    compute_dtype=compute_dtype, device_index=sh.device)
       if keys is not None:
-        eng.set_params(jaxseed.map_initial_params(net, keys[sh.index], log_noise_init))
+        # the reference's own initial particles for this seed: key chain on the host, values drawn on the device
+        eng.init_params_keys(jaxseed.map_leaf_keys(net, keys[sh.index]), log_noise_init)
       else:
         eng.init_params(log_noise_init)
       if pkeys is None:
@@ -167,7 +168,7 @@ def fit_vi(features, target, seed, observation_model, model_args, ensemble_size,
   if per_device < 1:
     raise ValueError('fewer than one surrogate per device')
   full_batch = batch_size is None or batch_size >= n_rows
-  mu0_all = jaxseed.vi_initial_means(net, seed, world, per_device) if init_rng == 'jax' else None
+  mu_keys = jaxseed.vi_mean_leaf_keys(net, seed, world, per_device) if init_rng == 'jax' else None
 
   def train_shard(sh):
     eng = Engine(net, mode='vi', X=features, y=target,
@@ -176,12 +177,11 @@ def fit_vi(features, target, seed, observation_model, model_args, ensemble_size,
                  seed=_native.seed_to_u64(seed), learning_rate=learning_rate,
                  kl_weight=kl_weight, vi_samples=sample_size_divergence,
                  compute_dtype=compute_dtype, device_index=sh.device)
-    eng.init_params(0.0)
-    if mu0_all is not None:
-      # the reference's own initial surrogate means for this seed
-      p0 = eng.get_params()
-      p0[0] = mu0_all[sh.index]
-      eng.set_params(p0)
+    if mu_keys is None:
+      eng.init_params(0.0)
+    else:
+      # the reference's own initial surrogate means for this seed (key chain on the host, values on the device)
+      eng.init_params_keys(mu_keys[sh.index], 0.0)
       if full_batch:
         # full batch: the optimisation noise and the posterior draws come from the reference's stream too
         # (keys on the host once per fit, normals on the device), so the whole fit follows the reference;

@@ -120,6 +120,19 @@ def map_initial_params(net, keys: np.ndarray, log_noise_init: float) -> np.ndarr
   return theta
 
 
+def map_leaf_keys(net, keys: np.ndarray) -> np.ndarray:
+  """For `bnf_init_params_keys`: the per-leaf sample seeds of `map_initial_params`' chain, (len(keys), n_leaves, 2)
+  uint32 -- all the host does; bits, erfinv and clipping happen on the device."""
+  keys = np.asarray(keys, dtype=_U32).reshape(-1, 2)
+  out = np.empty((keys.shape[0], len(net.leaves), 2), dtype=_U32)
+  for e, key in enumerate(keys):
+    key = fold_in(key, _JD_SALT)
+    for i in range(len(net.leaves)):
+      pair = split(key, 2)
+      out[e, i], key = pair[0], pair[1]
+  return out
+
+
 _IID_SALT = int(__import__('hashlib').sha512(b'iid_sample_stateless').hexdigest(), 16) & 0xFFFFFFFF
 
 
@@ -142,6 +155,21 @@ def vi_initial_means(net, seed, world: int, per_device: int) -> np.ndarray:
       if len(lf.shape) == 2:
         mu[e, lf.offset:lf.offset + lf.size] = truncated_normal_std(mean_seed, lf.size)
   return mu.reshape(world, per_device, net.P)
+
+
+def vi_mean_leaf_keys(net, seed, world: int, per_device: int) -> np.ndarray:
+  """For `bnf_init_params_keys` on a VI handle: the per-leaf mean seeds of `vi_initial_means`' chain,
+  (world, per_device, n_leaves, 2) uint32."""
+  init_seed = split(as_key(seed), 2)[0]
+  keys = split(fold_in(init_seed, _IID_SALT), world * per_device)
+  out = np.empty((world * per_device, len(net.leaves), 2), dtype=_U32)
+  for e, key in enumerate(keys):
+    key = fold_in(key, _JD_SALT)
+    for i in range(len(net.leaves)):
+      pair = split(key, 2)
+      out[e, i], key = pair[0], pair[1]
+      key = split(key, 2)[1]            # the leaf's second yield (deterministic rho) consumes a split too
+  return out.reshape(world, per_device, len(net.leaves), 2)
 
 
 # ----------------------------------------------------------------------------- VI noise keys

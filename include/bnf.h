@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BNF_ABI_VERSION 3
+#define BNF_ABI_VERSION 4
 
 /* limits of the static network description */
 #define BNF_MAX_INPUTS   8    /* D  : time + spatial covariates              */
@@ -148,6 +148,18 @@ int bnf_bind(bnf_handle* h, void* params /*DEVICE*/, void* opt_state /*DEVICE*/,
  * index); log_noise_scale = log_noise_init (MAP: log(nanstd(y)/2), VI: 0);
  * everything else 0; VI rho = softplus^-1(0.3).  Resets optimiser state + step. */
 int bnf_init_params(bnf_handle* h, float log_noise_init);
+
+/* The reference's OWN initial parameters for the user's seed, drawn on the device from their keys (what fit() uses;
+ * bnf_init_params above draws same-law values from the engine's generator).  MAP / MLE (inference.py:399-427) and
+ * the VI surrogate means (:203-231) are one JointDistribution sample per member: one key per leaf
+ * (bayesnf_amd/jaxseed.py map_leaf_keys / vi_mean_leaf_keys restate the split chain on the host), Dense kernels
+ * ~ TruncatedNormal(0, 1, -2, 2) through jax.random.truncated_normal -- threefry2x32 bits, uniform on
+ * [erf(-sqrt2), erf(sqrt2)), sqrt2 erfinv, clip -- every other leaf 0, log_noise_scale = log_noise_init;
+ * VI: rho = softplus^-1(0.3).  Resets the optimiser state and the step counter like bnf_init_params.
+ *   leaf_keys    DEVICE uint32 (members, n_leaves, 2)
+ *   leaf_offsets HOST int32 (n_leaves + 1): offsets of the packed leaves, [0] = 0, [n_leaves] = P; n_leaves <= 64 */
+int bnf_init_params_keys(bnf_handle* h, const uint32_t* leaf_keys, const int32_t* leaf_offsets, int32_t n_leaves,
+                         float log_noise_init);
 
 /* ensemble_map._run / tfp.vi.fit_surrogate_posterior_stateless (inference.py:
  * 577-619 / 727-738): `num_epochs` x (N // B) Adam steps for every local member,

@@ -183,3 +183,28 @@ def test_product_minibatch_shuffles_equal_the_oracle_chain():
   # num_splits > 1: fold_in(seed, i) first (fit_map, inference.py:432-441)
   np.testing.assert_array_equal(J.map_row_tables(J.map_permute_keys(key, 1, 2, 2, split_index=1)[0], 50, 50)[1, 0],
                                 R.reference_map_permutations(key, 2, 2, 50, split_index=1)[0, 1])
+
+
+def test_leaf_keys_of_the_device_side_initialiser_reproduce_the_host_chain():
+  """`fit()` draws the reference's initial parameters on the device from per-leaf keys (bnf_init_params_keys); the
+  keys (jaxseed.map_leaf_keys / vi_mean_leaf_keys) are the sample seeds of the very chain `map_initial_params` /
+  `vi_initial_means` walk on the host -- which tests above pin to the oracle / the goldens."""
+  from bayesnf_amd import jaxseed as J
+  from tests import util
+  net, model, X, y = util.make_problem(n_rows=50, width=64, depth=3)
+  keys = J.member_keys(3, 2, 3, None)
+  for d in range(2):
+    lk = J.map_leaf_keys(net, keys[d])
+    th = J.map_initial_params(net, keys[d], 0.5)
+    assert lk.shape == (3, len(net.leaves), 2) and lk.dtype == np.uint32
+    for e in range(3):
+      for i, lf in enumerate(net.leaves):
+        if len(lf.shape) == 2:
+          np.testing.assert_array_equal(J.truncated_normal_std(lk[e, i], lf.size), th[e, lf.offset:lf.offset + lf.size])
+  vk = J.vi_mean_leaf_keys(net, 3, 2, 3)
+  mu = J.vi_initial_means(net, 3, 2, 3)
+  for d in range(2):
+    for e in range(3):
+      for i, lf in enumerate(net.leaves):
+        if len(lf.shape) == 2:
+          np.testing.assert_array_equal(J.truncated_normal_std(vk[d, e, i], lf.size), mu[d, e, lf.offset:lf.offset + lf.size])
