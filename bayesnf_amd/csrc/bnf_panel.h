@@ -177,7 +177,10 @@ __global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ t
 #ifndef BNF_PANEL_NT
 #define BNF_PANEL_NT 1   // H1 / dZ1 / dZ0 leave with non-temporal stores (they are read once, by the weight-gradient kernels)
 #endif
-constexpr int kPanelPD = 4;       // weight fragments in flight per stream
+#ifndef BNF_PANEL_PD
+#define BNF_PANEL_PD 4
+#endif
+constexpr int kPanelPD = BNF_PANEL_PD;       // weight fragments in flight per stream; must divide W / 16 (2: +2 % panel time, 8: equal -- gpurun_out/r03ar)
 
 // RT = 32-row tiles per wave (4: one workgroup per CU, 256 registers; 2: two workgroups per CU, 128)
 __host__ __device__ constexpr int panel_rows(int wn, int rt) { return 32 * rt * (8 / wn); }
