@@ -17,7 +17,7 @@ from . import spec as _spec
 _LIB_NAME = 'libbnf_hip.so'
 _lib = None
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_INPUTS, MAX_GROUPS, MAX_LAYERS, MAX_FREQS, MAX_INTERACT = 8, 12, 8, 96, 16
 DTYPE = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
 OBS = {'NORMAL': 0, 'NB': 1, 'ZINB': 2}
@@ -26,7 +26,7 @@ PIPELINE = {'auto': 0, 'layers': 1, 'panel': 3}
 
 EXPORTS = (
     'bnf_abi_version', 'bnf_last_error', 'bnf_create', 'bnf_destroy',
-    'bnf_workspace_bytes', 'bnf_state_bytes', 'bnf_param_bytes', 'bnf_bind',
+    'bnf_workspace_bytes', 'bnf_state_bytes', 'bnf_param_bytes', 'bnf_owned_bytes', 'bnf_bind',
     'bnf_init_params', 'bnf_init_params_keys', 'bnf_train', 'bnf_row_tables', 'bnf_row_keys', 'bnf_vi_posterior_draws', 'bnf_vi_noise_keys', 'bnf_forward',
     'bnf_normal_mixture_quantiles', 'bnf_count_mixture_quantiles', 'bnf_debug_loss_and_grad',
     'bnf_debug_row_index', 'bnf_debug_vi_eps', 'bnf_debug_vi_noise', 'bnf_debug_activation',
@@ -97,7 +97,7 @@ def load():
   lib.bnf_create.argtypes = [C.POINTER(BnfConfig), C.POINTER(vp)]
   lib.bnf_destroy.argtypes = [vp]
   lib.bnf_destroy.restype = None
-  for name in ('bnf_workspace_bytes', 'bnf_state_bytes', 'bnf_param_bytes'):
+  for name in ('bnf_workspace_bytes', 'bnf_state_bytes', 'bnf_param_bytes', 'bnf_owned_bytes'):
     getattr(lib, name).argtypes = [vp]
     getattr(lib, name).restype = C.c_size_t
   lib.bnf_bind.argtypes = [vp, vp, vp, vp, vp, vp, vp]

@@ -128,6 +128,8 @@ struct bnf_handle {
   const uint32_t* row_keys = nullptr; int64_t row_keys_epochs = 0, row_keys_e0 = 0; int32_t row_key_rounds = 0;
   uint32_t* perm_bits[2] = {nullptr, nullptr}; int32_t* perm_val[2] = {nullptr, nullptr};   // (members, N) each, hipMalloc'ed
   unsigned* perm_seg = nullptr; void* perm_tmp = nullptr; size_t perm_tmp_bytes = 0;
+  bool perm_ready = false;       // every buffer above exists (set last: a failed allocation leaves none behind)
+  size_t owned_bytes = 0;        // device memory the engine allocated itself (bnf_owned_bytes)
   int32_t* perm = nullptr; int64_t perm_epoch = -1;      // the current epoch's (members, N) row ids
   int32_t* leaf_off = nullptr; uint8_t* leaf_id = nullptr; int32_t n_leaves = 0;
   bool adam_clear_all = false;   // env BNF_ADAM_CLEAR_ALL (A/B of the kept gradient range)
@@ -969,34 +971,58 @@ static RowSrc make_rowsrc(const bnf_handle* h, int64_t epoch, int64_t step) {
 // { bits = random_bits(sub_key_r, (N,)); stable sort of the current order by bits }.  The sub keys are the
 // caller's (bnf_row_keys); the bits are threefry2x32 over iota(N) split in halves (k_jax_perm_bits), the sort is
 // rocPRIM's radix sort of (bits, row id) pairs -- LSD radix, stable -- one segment per member.
+static size_t row_perm_bytes(int64_t members, int64_t n_rows) {   // without the sort's own scratch (a few MB)
+  return 4 * (size_t)members * (size_t)n_rows * 4 + (size_t)(members + 1) * sizeof(unsigned);
+}
 static int ensure_row_perm(bnf_handle* h, int64_t epoch) {
   if (!h->row_keys || h->B >= h->N || epoch < h->row_keys_e0 || epoch >= h->row_keys_e0 + h->row_keys_epochs) return BNF_OK;
   if (h->row_tab && epoch >= h->row_tab_e0 && epoch < h->row_tab_e0 + h->row_tab_epochs) return BNF_OK;   // tables win
   if (h->perm_epoch == epoch) return BNF_OK;
   const int E = h->cfg.members, R = h->row_key_rounds;
   const int64_t N = h->N, total = (int64_t)E * N;
-  if (total > 0x7fffffffLL) return fail(BNF_ERR_INVALID, "bnf_row_keys: members x rows exceeds 2^31");
+  // (members x rows < 2^31 was checked by bnf_row_keys)
   const bool segmented = N <= (1 << 17);     // long segments: one device-wide sort per member instead
-  if (!h->perm_bits[0]) {
-    for (int k = 0; k < 2; ++k) {
-      HIPCHK(hipMalloc((void**)&h->perm_bits[k], (size_t)total * 4));
-      HIPCHK(hipMalloc((void**)&h->perm_val[k], (size_t)total * 4));
+  if (!h->perm_ready) {
+    // all or nothing: the handle's fields are set only when every buffer exists, so a failed allocation
+    // leaves the handle as it was (the next epoch retries) instead of half-initialised
+    uint32_t* bits[2] = {nullptr, nullptr}; int32_t* val[2] = {nullptr, nullptr};
+    unsigned* seg = nullptr; void* tmp = nullptr; size_t tmp_bytes = 0;
+    auto release = [&]() {
+      for (int k = 0; k < 2; ++k) { if (bits[k]) (void)hipFree(bits[k]); if (val[k]) (void)hipFree(val[k]); }
+      if (seg) (void)hipFree(seg);
+      if (tmp) (void)hipFree(tmp);
+    };
+    hipError_t ae = hipSuccess;
+    for (int k = 0; k < 2 && ae == hipSuccess; ++k) {
+      ae = hipMalloc((void**)&bits[k], (size_t)total * 4);
+      if (ae == hipSuccess) ae = hipMalloc((void**)&val[k], (size_t)total * 4);
     }
-    HIPCHK(hipMalloc((void**)&h->perm_seg, (size_t)(E + 1) * sizeof(unsigned)));
-    std::vector<unsigned> off((size_t)E + 1);
-    for (int e = 0; e <= E; ++e) off[(size_t)e] = (unsigned)((int64_t)e * N);
-    HIPCHK(hipMemcpy(h->perm_seg, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-    size_t bytes = 0;
-    hipError_t qe;
-    if (segmented)
-      qe = rocprim::segmented_radix_sort_pairs(nullptr, bytes, h->perm_bits[0], h->perm_bits[1], h->perm_val[0], h->perm_val[1],
-                                               (unsigned)total, (unsigned)E, h->perm_seg, h->perm_seg + 1, 0, 32, h->stream);
-    else
-      qe = rocprim::radix_sort_pairs(nullptr, bytes, h->perm_bits[0], h->perm_bits[1], h->perm_val[0], h->perm_val[1],
-                                     (size_t)N, 0, 32, h->stream);
-    if (qe != hipSuccess) return fail(BNF_ERR_HIP, "radix sort workspace query: %s", hipGetErrorString(qe));
-    h->perm_tmp_bytes = std::max<size_t>(bytes, 16);
-    HIPCHK(hipMalloc(&h->perm_tmp, h->perm_tmp_bytes));
+    if (ae == hipSuccess) ae = hipMalloc((void**)&seg, (size_t)(E + 1) * sizeof(unsigned));
+    if (ae == hipSuccess) {
+      std::vector<unsigned> off((size_t)E + 1);
+      for (int e = 0; e <= E; ++e) off[(size_t)e] = (unsigned)((int64_t)e * N);
+      ae = hipMemcpy(seg, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    }
+    if (ae == hipSuccess) {
+      size_t bytes = 0;
+      if (segmented)
+        ae = rocprim::segmented_radix_sort_pairs(nullptr, bytes, bits[0], bits[1], val[0], val[1], (unsigned)total,
+                                                 (unsigned)E, seg, seg + 1, 0, 32, h->stream);
+      else
+        ae = rocprim::radix_sort_pairs(nullptr, bytes, bits[0], bits[1], val[0], val[1], (size_t)N, 0, 32, h->stream);
+      tmp_bytes = std::max<size_t>(bytes, 16);
+    }
+    if (ae == hipSuccess) ae = hipMalloc(&tmp, tmp_bytes);
+    if (ae != hipSuccess) {
+      release();
+      (void)hipGetLastError();
+      return fail(BNF_ERR_HIP, "bnf_row_keys: work buffers for %d members x %lld rows (%.1f MB): %s", E, (long long)N,
+                  (double)row_perm_bytes(E, N) / 1e6, hipGetErrorString(ae));
+    }
+    for (int k = 0; k < 2; ++k) { h->perm_bits[k] = bits[k]; h->perm_val[k] = val[k]; }
+    h->perm_seg = seg; h->perm_tmp = tmp; h->perm_tmp_bytes = tmp_bytes;
+    h->owned_bytes += 4 * (size_t)total * 4 + (size_t)(E + 1) * sizeof(unsigned) + tmp_bytes;
+    h->perm_ready = true;
   }
   const uint32_t* keys = h->row_keys + ((epoch - h->row_keys_e0) * E) * (int64_t)R * 2;   // (members, rounds, 2)
   int cur = 0;
@@ -1387,6 +1413,7 @@ void bnf_destroy(bnf_handle* h) {
 }
 
 size_t bnf_workspace_bytes(const bnf_handle* h) { return h ? h->ws_bytes : 0; }
+size_t bnf_owned_bytes(const bnf_handle* h) { return h ? h->owned_bytes : 0; }
 size_t bnf_param_bytes(const bnf_handle* h) {
   if (!h) return 0;
   return (size_t)h->cfg.members * h->P * 4 * (h->cfg.mode == BNF_MODE_VI ? 2 : 1);
@@ -1772,6 +1799,10 @@ int bnf_row_keys(bnf_handle* h, const uint32_t* keys, int64_t epoch0, int64_t n_
   // jax: ceil(3 ln N / ln(2^32 - 1)) rounds -- anything else would be another permutation
   const int want = (int)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, h->N)) / std::log(4294967295.0));
   if (rounds != want) return fail(BNF_ERR_INVALID, "rounds = %d, jax.random.permutation of %lld rows takes %d", rounds, (long long)h->N, want);
+  // the sort addresses (member, row) pairs with 32-bit offsets; refuse here, where the caller can still choose the
+  // index-free shuffle instead (bayesnf_amd/inference.py does, with a warning), not in the middle of bnf_train
+  if ((int64_t)h->cfg.members * h->N > 0x7fffffffLL)
+    return fail(BNF_ERR_INVALID, "bnf_row_keys: members x rows = %lld exceeds 2^31 - 1", (long long)((int64_t)h->cfg.members * h->N));
   h->row_keys = keys; h->row_keys_e0 = epoch0; h->row_keys_epochs = n_epochs; h->row_key_rounds = rounds;
   return BNF_OK;
 }

@@ -109,6 +109,10 @@ class Engine:
                           _ptr(self.workspace), _ptr(self.X), _ptr(self.y),
                           C.c_void_p(self.stream.cuda_stream)), 'bnf_bind')
 
+  def owned_bytes(self) -> int:
+    """Device memory the engine allocated itself (include/bnf.h bnf_owned_bytes): the row-key work buffers."""
+    return int(self.lib.bnf_owned_bytes(self.handle))
+
   # -- lifecycle ---------------------------------------------------------------
   def close(self):
     if getattr(self, 'handle', None) is not None:

@@ -16,6 +16,7 @@ per torchrun rank -- is `distributed.local_shards()`.
 from __future__ import annotations
 
 import os
+import warnings
 from typing import Any
 
 import numpy as np
@@ -86,8 +87,16 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
 
     # minibatch epochs under init_rng='jax': every member's per-epoch `jax.random.permutation` of the
     # reference (inference.py:593-597), keys on the host once per fit
+    want_ref_shuffles = init_rng == 'jax' and batch_size < n_rows and num_epochs > 0
+    if (want_ref_shuffles and per_device * n_rows >= 2**31
+        and os.environ.get('BNF_ROW_TABLES', 'device') != 'host'):
+      # the device-side sort addresses (member, row) pairs with 32-bit offsets (include/bnf.h bnf_row_keys)
+      warnings.warn(f'{per_device} members x {n_rows} rows per device exceed 2^31 - 1: the epoch shuffles of this fit come '
+                    "from the engine's index-free generator (same law as jax.random.permutation, other numbers); "
+                    'BNF_ROW_TABLES=host keeps the reference stream at the price of host-drawn tables.')
+      want_ref_shuffles = False
     pkeys = (jaxseed.map_permute_keys(seed, world, per_device, num_epochs, i if num_splits > 1 else None)
-             if init_rng == 'jax' and batch_size < n_rows and num_epochs > 0 else None)
+             if want_ref_shuffles else None)
 
     def train_shard(sh):
       # device sh.index of the job owns the members [index * per_device, (index + 1) * per_device): the

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BNF_ABI_VERSION 4
+#define BNF_ABI_VERSION 5
 
 /* limits of the static network description */
 #define BNF_MAX_INPUTS   8    /* D  : time + spatial covariates              */
@@ -133,6 +133,11 @@ void bnf_destroy(bnf_handle* h);
 size_t bnf_workspace_bytes(const bnf_handle* h);  /* activations, gradients, packed weights */
 size_t bnf_state_bytes(const bnf_handle* h);      /* optimiser state: MAP 2*E*P f32 (m,v); VI 4*E*P */
 size_t bnf_param_bytes(const bnf_handle* h);      /* MAP E*P f32 ; VI 2*E*P (mu then rho) */
+/* Device memory the engine has allocated ITSELF so far (everything else is the caller's): today only the work
+ * buffers of bnf_row_keys -- 4 x members x n_rows x 4 bytes + (members + 1) x 4 + the radix sort's scratch --
+ * allocated at the first epoch that draws its shuffles on the device, all or nothing (a failed allocation
+ * returns BNF_ERR_HIP from bnf_train and leaves nothing behind), freed by bnf_destroy.  0 before that. */
+size_t bnf_owned_bytes(const bnf_handle* h);
 
 /* Attach device buffers.  X: (N, D) f32 row-major, y: (N,) f32 (replicated
  * closed-over constants of ensemble_map, inference.py:553-554).  Zeroes the
@@ -195,8 +200,9 @@ int bnf_row_tables(bnf_handle* h, const int32_t* tables, int64_t epoch0, int64_t
  *   keys DEVICE uint32 (n_epochs, members, rounds, 2) for the epochs [epoch0, epoch0 + n_epochs); caller-owned,
  *        alive while those epochs are enqueued and executing.  BNF_ERR_INVALID if `rounds` is not jax's count for N.
  * Work buffers (4 x members x N x 4 bytes + sort scratch) are allocated by the engine at the first such epoch
- * (the only allocation the engine makes itself) and freed by bnf_destroy.  A table from bnf_row_tables covering
- * the same epoch wins.  NULL switches it off. */
+ * (the only allocation the engine makes itself: bnf_owned_bytes reports it) and freed by bnf_destroy.
+ * BNF_ERR_INVALID when members x N exceeds 2^31 - 1 (32-bit sort offsets): use bnf_row_tables or the engine's
+ * index-free shuffle for such fits.  A table from bnf_row_tables covering the same epoch wins.  NULL switches it off. */
 int bnf_row_keys(bnf_handle* h, const uint32_t* keys, int64_t epoch0, int64_t n_epochs, int32_t rounds);
 
 /* The reference's OWN random stream for the VI noise (optional; without it the noise comes from the

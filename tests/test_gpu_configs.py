@@ -249,9 +249,13 @@ def test_reference_shuffles_drawn_on_the_device(n_rows, batch):
   eng = Engine(net, X=X, y=y, members=E, batch=batch, seed=0)
   eng.init_params(0.0)
   eng.set_row_keys(J.map_shuffle_subkeys(pk, n_rows), epoch0=0)
+  assert eng.owned_bytes() == 0                                           # nothing is allocated before an epoch needs it
   for ep in (0, 2, 1, 1):                                                 # any order: an epoch is drawn when it is asked for
     rows = np.concatenate([eng.debug_row_index(ep, s) for s in range(steps)], axis=1)
     np.testing.assert_array_equal(rows, ref[:, ep, :steps * batch])
+  # the one allocation the engine makes itself is reported (include/bnf.h bnf_owned_bytes): 4 (members, rows) arrays + scratch
+  own = eng.owned_bytes()
+  assert 4 * E * n_rows * 4 <= own < 4 * E * n_rows * 4 + (64 << 20)
   # training through them == training through the host-drawn tables
   l_dev = eng.train(0, epochs).cpu().numpy()
   th_dev = eng.get_params()
