@@ -31,7 +31,8 @@ EXPORTS = (
     'bnf_normal_mixture_quantiles', 'bnf_count_mixture_quantiles', 'bnf_debug_loss_and_grad',
     'bnf_debug_row_index', 'bnf_debug_vi_eps', 'bnf_debug_vi_noise', 'bnf_debug_activation',
     'bnf_debug_gemm_nt', 'bnf_debug_gemm_tn', 'bnf_debug_poison_lds', 'bnf_profile_enable', 'bnf_profile_read',
-    'bnf_kernel_flops', 'bnf_comm_unique_id', 'bnf_comm_create', 'bnf_allgather', 'bnf_comm_destroy')
+    'bnf_kernel_flops', 'bnf_comm_available', 'bnf_comm_unique_id', 'bnf_comm_create', 'bnf_allgather',
+    'bnf_comm_create_local', 'bnf_allgather_group', 'bnf_comm_destroy')
 
 
 class BnfConfig(C.Structure):
@@ -106,6 +107,9 @@ def load():
   lib.bnf_comm_unique_id.argtypes = [vp]
   lib.bnf_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
   lib.bnf_allgather.argtypes = [vp, vp, vp, C.c_size_t, vp]
+  lib.bnf_comm_available.argtypes = []
+  lib.bnf_comm_create_local.argtypes = [i32, C.POINTER(C.c_int32), C.POINTER(vp)]
+  lib.bnf_allgather_group.argtypes = [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_size_t, C.POINTER(vp)]
   lib.bnf_comm_destroy.argtypes = [vp]
   lib.bnf_comm_destroy.restype = None
   lib.bnf_vi_posterior_draws.argtypes = [vp, i32, f32p]
@@ -154,6 +158,18 @@ def check(rc: int, what: str):
 
 
 _comm_cache = {}
+_local_comm_cache = {}
+
+
+def _agree(ok: bool, world: int, device, on_dev: bool) -> bool:
+  """True iff `ok` on EVERY rank (one all_reduce MIN): whatever follows is entered by all ranks or by none."""
+  import torch
+  if world <= 1:
+    return ok
+  flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+  flag = flag.to(device) if on_dev else flag
+  torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+  return int(flag.item()) == 1
 
 
 def allgather(send, recv, world: int, rank: int, lib=None):
@@ -161,28 +177,26 @@ def allgather(send, recv, world: int, rank: int, lib=None):
   bnf_allgather): `send` (…) and `recv` (world, …) are contiguous device tensors.  The
   communicator is created once per (world, rank, device): rank 0 makes the id, the existing
   torch.distributed process group only carries those 128 bytes to the other ranks.
-  (`lib`: the loaded library; bench.py's CPU self-test passes a stand-in with the same three
+  Raises RuntimeError on EVERY rank when any rank cannot take part (the ranks agree before and
+  after the communicator is made), so a caller may fall back to another collective without the
+  ranks ending up in different ones.
+  (`lib`: the loaded library; bench.py's CPU self-test passes a stand-in with the same
   entry points to exercise this plumbing without a GPU.)"""
   import torch
   lib = load() if lib is None else lib
   dev = send.device.index if send.is_cuda else -1
   key = (world, rank, dev, id(lib))
-  if key not in _comm_cache:
-    # Every rank first finds out LOCALLY whether the library can reach RCCL at all (an id costs nothing), and the
-    # ranks agree on it before anything that only some of them would enter: a rank that raised here while the others
-    # waited in the broadcast / in ncclCommInitRank would hang the job instead of failing it.
+  if _comm_cache.get(key) is None:
     on_dev = send.is_cuda and world > 1 and torch.distributed.get_backend() == 'nccl'
+    # Every rank finds out LOCALLY whether the library can reach RCCL (symbol resolution: no id, no bootstrap
+    # listener on the ranks that will never serve one); only rank 0 makes the id.
     buf = (C.c_char * 128)()
-    rc = lib.bnf_comm_unique_id(buf)
+    rc = lib.bnf_comm_available() if hasattr(lib, 'bnf_comm_available') else 0
+    if rc == 0 and rank == 0:
+      rc = lib.bnf_comm_unique_id(buf)
     err = None if rc == 0 else (last_error() if hasattr(lib, 'bnf_last_error') else f'code {rc}')
-    if world > 1:
-      flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32)
-      flag = flag.to(send.device) if on_dev else flag
-      torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-      if int(flag.item()) == 0:
-        raise RuntimeError('bnf_comm_unique_id failed on at least one rank' + (f' (here: {err})' if err else ''))
-    elif rc != 0:
-      raise RuntimeError(f'bnf_comm_unique_id: {err}')
+    if not _agree(rc == 0, world, send.device, on_dev):
+      raise RuntimeError('RCCL is not reachable through libbnf_hip.so on at least one rank' + (f' (here: {err})' if err else ''))
     ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
     if world > 1:
       carrier = ident.to(send.device) if on_dev else ident
@@ -190,11 +204,50 @@ def allgather(send, recv, world: int, rank: int, lib=None):
       ident = carrier.cpu()
     comm = C.c_void_p()
     raw = (C.c_char * 128).from_buffer_copy(bytes(ident.numpy().tobytes()))
-    check(lib.bnf_comm_create(raw, world, rank, max(dev, 0), C.byref(comm)), 'bnf_comm_create')
-    _comm_cache[key] = comm
+    rc = lib.bnf_comm_create(raw, world, rank, max(dev, 0), C.byref(comm))
+    err = None if rc == 0 else (last_error() if hasattr(lib, 'bnf_last_error') else f'code {rc}')
+    if rc == 0:
+      _comm_cache[key] = comm
+    # (a rank whose ncclCommInitRank failed early leaves the others inside theirs until RCCL's own timeout: nothing a
+    # caller can do about that; what CAN be guaranteed is that afterwards all ranks take the same branch)
+    if not _agree(rc == 0, world, send.device, on_dev):
+      if rc == 0:
+        lib.bnf_comm_destroy(_comm_cache.pop(key))
+      raise RuntimeError('bnf_comm_create failed on at least one rank' + (f' (here: {err})' if err else ''))
   stream = torch.cuda.current_stream(send.device).cuda_stream if send.is_cuda else 0
   check(lib.bnf_allgather(_comm_cache[key], C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
                           C.c_size_t(send.numel() * send.element_size()), C.c_void_p(stream)), 'bnf_allgather')
+
+
+def allgather_local(sends, recvs, lib=None):
+  """ONE process, one tensor per local device: every device's block to every device with one grouped RCCL
+  all-gather (include/bnf.h bnf_comm_create_local / bnf_allgather_group -- the single-process mode is the
+  reference's own shape, inference.py:573-579).  sends[i] (…) on device i of the job, recvs[i] (n, …) on the
+  same device.  The communicator set is made once per device list.  Raises RuntimeError when RCCL cannot
+  serve the list (e.g. a device named twice: BNF_DEVICES=0,0)."""
+  import torch
+  lib = load() if lib is None else lib
+  n = len(sends)
+  devs = tuple((t.device.index if t.is_cuda else i) for i, t in enumerate(sends))
+  key = (devs, id(lib))
+  if key not in _local_comm_cache:
+    arr = (C.c_int32 * n)(*devs)
+    comms = (C.c_void_p * n)()
+    rc = lib.bnf_comm_create_local(n, arr, comms)
+    if rc != 0:
+      raise RuntimeError('bnf_comm_create_local: ' + (last_error() if hasattr(lib, 'bnf_last_error') else f'code {rc}'))
+    _local_comm_cache[key] = comms
+  comms = _local_comm_cache[key]
+  nbytes = sends[0].numel() * sends[0].element_size()
+  for s_, r_ in zip(sends, recvs):
+    if s_.numel() * s_.element_size() != nbytes or r_.numel() * r_.element_size() != n * nbytes:
+      raise ValueError('allgather_local: every rank contributes the same byte count')
+  sp = (C.c_void_p * n)(*[t.data_ptr() for t in sends])
+  rp = (C.c_void_p * n)(*[t.data_ptr() for t in recvs])
+  st = (C.c_void_p * n)(*[(torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0) for t in sends])
+  rc = lib.bnf_allgather_group(n, comms, sp, rp, C.c_size_t(nbytes), st)
+  if rc != 0:
+    raise RuntimeError('bnf_allgather_group: ' + (last_error() if hasattr(lib, 'bnf_last_error') else f'code {rc}'))
 
 
 def seed_to_u64(seed) -> int:

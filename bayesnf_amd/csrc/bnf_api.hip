@@ -18,6 +18,7 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -326,14 +327,15 @@ static void phase_prof_end(bnf_handle* h, int kid, unsigned blocks, int threads)
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: remember per
 // (kernel instantiation, device) that it has been raised (a process may drive several GPUs).
 template <typename K>
-static void allow_lds(bnf_handle* h, K kernel, int bytes, uint64_t* done_mask) {
+static void allow_lds(bnf_handle* h, K kernel, int bytes, std::atomic<uint64_t>* done_mask) {
+  // (atomic: one host thread per device enqueues through the same launchers -- distributed.run_shards)
   const uint64_t bit = 1ull << (h->cfg.device & 63);
-  if (*done_mask & bit) return;
+  if (done_mask->load(std::memory_order_relaxed) & bit) return;
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess)
     fprintf(stderr, "[bnf] hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed: %s\n", bytes, hipGetErrorString(e));
-  *done_mask |= bit;
+  done_mask->fetch_or(bit, std::memory_order_relaxed);
 }
 
 template <typename T, int EPI, int TAG, int WGM, int WGN>
@@ -343,7 +345,7 @@ static void launch_gemm_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep
   g.tiles_m = (g.M + 64 * WGM - 1) / (64 * WGM);
   g.tiles_n = (g.N + 64 * WGN - 1) / (64 * WGN);
   if (g.splitk < 1) g.splitk = 1;
-  static uint64_t attr_done = 0;
+  static std::atomic<uint64_t> attr_done{0};
   allow_lds(h, &gemm_nt<T, EPI, TAG, WGM, WGN>, kLds, &attr_done);
   const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
   EpiArgs ep2 = ep;
@@ -403,7 +405,7 @@ static void launch_gemm_tn_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs&
   g.tiles_m = (g.M + 64 * WG - 1) / (64 * WG);
   g.tiles_n = (g.N + 64 * WG - 1) / (64 * WG);
   if (g.splitk < 1) g.splitk = 1;
-  static uint64_t attr_done = 0;
+  static std::atomic<uint64_t> attr_done{0};
   allow_lds(h, &gemm_tn<T, TAG, WG>, kLds, &attr_done);
   const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
   LaunchScope ls(h, kid, st, true);
@@ -415,7 +417,7 @@ static void launch_gemm_tn_skinny(bnf_handle* h, int kid, GemmArgs g, const EpiA
   g.tiles_m = 1;
   g.tiles_n = g.N / 512;
   if (g.splitk < 1) g.splitk = 1;
-  static uint64_t attr_done = 0;
+  static std::atomic<uint64_t> attr_done{0};
   allow_lds(h, &gemm_tn_skinny, kSkLds, &attr_done);
   const unsigned blocks = (unsigned)((int64_t)g.members * g.tiles_n * g.splitk);
   LaunchScope ls(h, kid, st, true);
@@ -434,7 +436,7 @@ static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep
     if (kind == WG_RING) {   // the 256 x 256 tile with the K loop as a four-stage ring
       g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
       if (g.splitk < 1) g.splitk = 1;
-      static uint64_t attr_done = 0, attr_done_s = 0;
+      static std::atomic<uint64_t> attr_done{0}, attr_done_s{0};
       const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk * (g.n_multi > 1 ? g.n_multi : 1));
       EpiArgs ep2 = ep;
       ep2.ablate = h->ablate;
@@ -486,7 +488,7 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
     LaunchScope ls(h, KID_FEAT);
     dim3 grid(cdiv(rows, kFeatRows) * (unsigned)nmem);
     const size_t lds = (size_t)kFeatRows * (h->Fp + 16 / h->es) * h->es;
-    static uint64_t attr_done = 0;
+    static std::atomic<uint64_t> attr_done{0};
     allow_lds(h, &k_featurize<T>, 160 * 1024, &attr_done);
     hipLaunchKernelGGL((k_featurize<T>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, X, stab,
                        y, h->scal, rows, (T*)h->H0, Bp * h->Fp,
@@ -820,7 +822,7 @@ template <int WN, int RT, bool H0L, bool DEEP, int CH, int FP>
 static void launch_panel_d(bnf_handle* h, const PanelArgs& pa) {
   constexpr int kLds = panel_lds_bytes(WN, RT, H0L, CH, FP);
   static_assert(kLds <= 160 * 1024, "LDS per workgroup");
-  static uint64_t attr_done = 0;
+  static std::atomic<uint64_t> attr_done{0};
   allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH, FP>, kLds, &attr_done);
   PanelArgs pa2 = pa;
   pa2.ablate = h->ablate;
@@ -851,7 +853,7 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
     LaunchScope ls(h, KID_FEAT);
     dim3 grid(cdiv(h->B, kFeatRows) * (unsigned)nmem);
     const size_t lds = (size_t)kFeatRows * (h->Fp + 8) * 2;
-    static uint64_t attr_done = 0;
+    static std::atomic<uint64_t> attr_done{0};
     allow_lds(h, &k_featurize<bf16_t>, 160 * 1024, &attr_done);
     hipLaunchKernelGGL((k_featurize<bf16_t>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, h->X, h->stab,
                        h->y, h->scal, h->B, (bf16_t*)h->H0, Bp * h->Fp, (bf16_t*)h->H0t,
@@ -1942,7 +1944,7 @@ __global__ __launch_bounds__(1024) void k_poison_lds(uint32_t pattern, uint32_t*
 int bnf_debug_poison_lds(bnf_handle* h, uint32_t pattern) {
   if (!h || !h->bound) return fail(BNF_ERR_STATE, "not bound");
   HIPCHK(hipSetDevice(h->cfg.device));
-  static uint64_t attr_done = 0;
+  static std::atomic<uint64_t> attr_done{0};
   allow_lds(h, &k_poison_lds, 160 * 1024, &attr_done);
   // one workgroup per CU at a time (all of its LDS): several rounds so that every CU is visited
   hipLaunchKernelGGL(k_poison_lds, dim3((unsigned)h->num_cus * 4), dim3(1024), 160 * 1024, h->stream, pattern,
@@ -1996,6 +1998,9 @@ struct RcclApi {
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommInitAll)(void**, int, const int*) = nullptr;     // one process, several devices (bnf_comm_create_local)
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
 };
 RcclApi g_rccl;
 int rccl_load() {
@@ -2010,6 +2015,9 @@ int rccl_load() {
   g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
   g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  g_rccl.CommInitAll = (int (*)(void**, int, const int*))dlsym(lib, "ncclCommInitAll");
+  g_rccl.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
+  g_rccl.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
     return fail(BNF_ERR_STATE, "librccl.so lacks an expected nccl* symbol");
   g_rccl.lib = lib;
@@ -2024,6 +2032,10 @@ struct bnf_comm {
   void* comm = nullptr;
   int32_t world = 0, rank = 0, device = 0;
 };
+
+int bnf_comm_available(void) {   // local and cheap: dlopen + symbol resolution, no communicator id, no listener thread
+  return rccl_load();
+}
 
 int bnf_comm_unique_id(void* id) {
   if (!id) return fail(BNF_ERR_INVALID, "null");
@@ -2057,6 +2069,57 @@ int bnf_allgather(bnf_comm* c, const void* send, void* recv, size_t bytes_per_ra
   // ncclChar = 0: byte count is dtype-agnostic
   if (int rc = g_rccl.AllGather(send, recv, bytes_per_rank, 0, c->comm, (hipStream_t)stream))
     return rccl_fail("ncclAllGather", rc);
+  return BNF_OK;
+}
+
+// One process driving n devices (the reference's own shape: jax.pmap over jax.local_devices()): one communicator
+// per device from ONE ncclCommInitAll -- no id, no side channel.  RCCL refuses a device listed twice.
+int bnf_comm_create_local(int32_t n, const int32_t* devices, bnf_comm** out) {
+  if (!devices || !out || n < 1 || n > 64) return fail(BNF_ERR_INVALID, "argument");
+  for (int i = 0; i < n; ++i) out[i] = nullptr;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < i; ++j)
+      if (devices[i] == devices[j]) return fail(BNF_ERR_INVALID, "device %d listed twice: one RCCL rank per device", devices[i]);
+  if (int rc = rccl_load()) return rc;
+  if (!g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+    return fail(BNF_ERR_STATE, "librccl.so lacks ncclCommInitAll / ncclGroupStart / ncclGroupEnd");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  std::vector<void*> comms((size_t)n, nullptr);
+  std::vector<int> devs(devices, devices + n);
+  const int rc = g_rccl.CommInitAll(comms.data(), n, devs.data());
+  (void)hipSetDevice(prev);
+  if (rc) return rccl_fail("ncclCommInitAll", rc);
+  for (int i = 0; i < n; ++i) {
+    bnf_comm* c = new bnf_comm();
+    c->comm = comms[(size_t)i]; c->world = n; c->rank = i; c->device = devices[i];
+    out[i] = c;
+  }
+  return BNF_OK;
+}
+
+// The all-gather of every local rank in ONE group call (a single host thread cannot issue them one by one: each
+// would wait for its peers).  send[i] / recv[i] / stream[i] belong to comms[i]'s device.
+int bnf_allgather_group(int32_t n, bnf_comm* const* comms, const void* const* send, void* const* recv,
+                        size_t bytes_per_rank, void* const* streams) {
+  if (!comms || !send || !recv || n < 1) return fail(BNF_ERR_INVALID, "null");
+  for (int i = 0; i < n; ++i)
+    if (!comms[i] || !send[i] || !recv[i]) return fail(BNF_ERR_INVALID, "null entry %d", i);
+  if (!g_rccl.GroupStart || !g_rccl.GroupEnd) return fail(BNF_ERR_STATE, "librccl.so not loaded");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (int rc = g_rccl.GroupStart()) return rccl_fail("ncclGroupStart", rc);
+  int first = 0;
+  for (int i = 0; i < n; ++i) {
+    (void)hipSetDevice(comms[i]->device);
+    const int rc = g_rccl.AllGather(send[i], recv[i], bytes_per_rank, 0, comms[i]->comm,
+                                    (hipStream_t)(streams ? streams[i] : nullptr));
+    if (rc && !first) first = rc;
+  }
+  const int rc_end = g_rccl.GroupEnd();
+  (void)hipSetDevice(prev);
+  if (first) return rccl_fail("ncclAllGather (group)", first);
+  if (rc_end) return rccl_fail("ncclGroupEnd", rc_end);
   return BNF_OK;
 }
 

@@ -36,10 +36,19 @@ def local_devices() -> list[int]:
     return [local_device_index()]
   env = os.environ.get('BNF_DEVICES', '').strip()
   if env:
-    devs = [int(x) for x in env.split(',') if x.strip()]
+    try:
+      devs = [int(x) for x in env.split(',') if x.strip()]
+    except ValueError:
+      raise ValueError(f'BNF_DEVICES={env!r}: comma separated device ordinals expected') from None
     if not devs:
       raise ValueError(f'BNF_DEVICES={env!r} names no device')
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    bad = [d for d in devs if d < 0 or (n > 0 and d >= n)]
+    if bad:
+      raise ValueError(f'BNF_DEVICES={env!r}: ordinal(s) {bad} out of range, {n} device(s) visible')
     return devs
+  if 'LOCAL_RANK' in os.environ:      # under a launcher, before (or without) the process group: this rank's device
+    return [local_device_index()]
   return list(range(max(1, torch.cuda.device_count())))
 
 
@@ -75,6 +84,9 @@ def run_shards(fn: Callable[[Shard], object], shards: list[Shard] | None = None)
     return [fn(shards[0])]
   out: list = [None] * len(shards)
   err: list = [None] * len(shards)
+  if torch.cuda.is_available():
+    from . import _native
+    _native.load()          # once, before the threads (the loader's module global is not guarded)
 
   def work(i, sh):
     try:
@@ -95,15 +107,43 @@ def run_shards(fn: Callable[[Shard], object], shards: list[Shard] | None = None)
   return out
 
 
+_gather_note = {}
+
+
 def gather_shards(parts: list[torch.Tensor]) -> torch.Tensor:
   """One tensor (...) per local shard -> (device_count, ...) : the reference's implicit pmap output
-  gather.  In-process devices: peer copies to the first shard's device.  torch.distributed: one
-  all-gather (`all_gather_stack`)."""
+  gather (inference.py:452,486-492).  torch.distributed: one all-gather (`all_gather_stack`).  One process with
+  several DISTINCT devices: ONE grouped RCCL all-gather over the local communicator set (`_native.allgather_local`:
+  bnf_comm_create_local + bnf_allgather_group -- every device receives every block, the first device's copy is
+  returned); `BNF_GATHER=peer`, a device named twice (BNF_DEVICES=0,0), CPU tensors or an RCCL set-up failure
+  fall back to peer copies to the first shard's device (`last_gather()` says which ran)."""
   if is_distributed():
     assert len(parts) == 1
     return all_gather_stack(parts[0])
   dev0 = parts[0].device
+  devs = [p.device for p in parts]
+  if (len(parts) > 1 and all(d.type == 'cuda' for d in devs) and len(set(devs)) == len(devs)
+      and os.environ.get('BNF_GATHER', 'rccl') != 'peer'):
+    try:
+      from . import _native
+      sends = [p.contiguous() for p in parts]
+      for p in sends:
+        torch.cuda.current_stream(p.device).synchronize()   # producers ran on other host threads' streams
+      recvs = [torch.empty((len(parts),) + tuple(p.shape), dtype=p.dtype, device=p.device) for p in sends]
+      _native.allgather_local(sends, recvs)
+      for p in sends:
+        torch.cuda.current_stream(p.device).synchronize()
+      _gather_note['impl'] = 'rccl-group'
+      return recvs[0]
+    except (RuntimeError, OSError) as exc:
+      _gather_note['error'] = f'{type(exc).__name__}: {exc}'[:300]
+  _gather_note['impl'] = 'peer-copies'
   return torch.stack([p if p.device == dev0 else p.to(dev0) for p in parts])
+
+
+def last_gather() -> dict:
+  """{'impl': 'rccl-group' | 'peer-copies', 'error': ...} of the last in-process `gather_shards`."""
+  return dict(_gather_note)
 
 
 def local_device_index() -> int:

@@ -63,7 +63,9 @@ class Engine:
     self.net = net
     self.mode = mode
     self.dtype = default_dtype(compute_dtype)
-    self.dev_index = (distributed.local_device_index()
+    # default device: the first one this process drives (LOCAL_RANK's under torch.distributed, else the first of
+    # BNF_DEVICES / of the visible devices) -- the same list fit() / predict() deal members over
+    self.dev_index = (distributed.local_devices()[0]
                       if device_index is None else int(device_index))
     self.device = torch.device(f'cuda:{self.dev_index}')
     torch.cuda.set_device(self.device)

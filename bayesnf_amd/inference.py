@@ -56,8 +56,9 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
   init_rng: 'jax' (default; env BNF_INIT_RNG) starts every member from the initial parameters the
   reference itself would draw for `seed` (threefry + TFP seed chain restated on the host,
   `jaxseed`) and, for minibatch fits, shuffles every epoch with the reference's own per-member
-  `jax.random.permutation` stream (`jaxseed.map_shuffle_subkeys` -> `bnf_row_keys`: drawn on the device): same seed => the fit
-  follows the reference's trajectory.  'philox' draws the initial parameters from the device generator
+  `jax.random.permutation` stream (`jaxseed.map_shuffle_subkeys` -> `bnf_row_keys`: drawn on the device): same seed => the same
+  initial particles and shuffles as the reference (pinned by its goldens for full-batch fits; the shuffle chain rests on
+  the reference's source + the pinned split / bits restatements -- no golden exercises a minibatch fit).  'philox' draws the initial parameters from the device generator
   (`bnf_init_params`) and shuffles with the device's keyed Feistel permutation (no index arrays).
 
   Returns (params, losses): params is a StructTuple whose leaves have shape
@@ -193,7 +194,8 @@ def fit_vi(features, target, seed, observation_model, model_args, ensemble_size,
       eng.init_params_keys(mu_keys[sh.index], 0.0)
       if full_batch:
         # full batch: the optimisation noise and the posterior draws come from the reference's stream too
-        # (keys on the host once per fit, normals on the device), so the whole fit follows the reference;
+        # (keys on the host once per fit, normals on the device), so a full-batch fit uses the reference's numbers
+        # (pinned by the reference's VI golden: 2 optimisation steps; longer fits extrapolate the same key recurrence);
         # minibatch fits also need its per-step row permutation and stay on the engine's generator
         eng.set_vi_noise_keys(jaxseed.vi_noise_keys(net, seed, world, sh.index, num_epochs, sample_size_divergence),
                               jaxseed.vi_draw_keys(net, seed, world, sh.index, sample_size_posterior),

@@ -6,9 +6,10 @@ every Dense kernel with `tfd.TruncatedNormal(0, 1, -2, 2)` through
 `jax.random.split(split(seed)[0], (devices, members))` (/root/reference/src/bayesnf/
 inference.py:399-427, 432-441, 571-575).  This module computes those numbers on the host (numpy,
 uint32 arithmetic), so that a fit with the same seed starts from the reference's own initial
-parameters -- with full-batch training (no shuffles) the whole fit then follows the reference's
-trajectory, and the reference's golden predictions are reproduced through the GPU engine
-(tests/test_gpu_estimator.py).  It is host glue executed once per fit (E x P numbers), not part
+parameters -- with full-batch training (no shuffles) the fit then runs on the reference's own numbers, and the
+reference's golden predictions are reproduced through the GPU engine (tests/test_gpu_estimator.py; what the goldens
+pin: 5 full-batch Adam steps for MAP / MLE, 2 optimisation steps for VI -- `vi_noise_keys`' step recurrence beyond
+step 2 and the minibatch shuffle chain are extrapolations of the same source-read recurrences).  It is host glue executed once per fit (E x P numbers), not part
 of the per-step hot path; the device generator (Philox, `bnf_init_params`) remains available with
 `init_rng='philox'` / BNF_INIT_RNG=philox and is what bench.py uses.
 

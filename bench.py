@@ -60,19 +60,48 @@ KERNEL_SYMBOL = {   # gemm_nt<T, epilogue, tag, wave rows, wave cols>
 }
 
 
-def sq_counters(kernel, dtype, members):
-  """Per-launch SQ counters of `kernel` from the committed rocprofv3 --pmc passes of this same command
-  (profiles/sq_counters.json, made by scripts/gpu_counters.sh + scripts/counter_summary.py), or None."""
-  path = os.path.join(ROOT, 'profiles', 'sq_counters.json')
-  if members != 64 or kernel not in KERNEL_SYMBOL or not os.path.exists(path):
-    return None
-  sym = KERNEL_SYMBOL[kernel].format(T='bnf::bf16_t' if dtype == 'bf16' else 'float')
+def kernel_source_sha16():
+  """sha256 (first 16 hex digits) over the engine's device sources: the committed counter files carry the value they
+  were measured with (`_meta.kernel_source_sha16`, written by scripts/pmc_summary.py / counter_summary.py on the GPU
+  box); a file taken with other kernel sources is STALE and is not quoted."""
+  import hashlib
+  h = hashlib.sha256()
+  d = os.path.join(ROOT, 'bayesnf_amd', 'csrc')
+  for name in sorted(os.listdir(d)):
+    if name.endswith(('.h', '.hip')):
+      with open(os.path.join(d, name), 'rb') as f:
+        h.update(name.encode() + b'\0' + f.read() + b'\0')
+  return h.hexdigest()[:16]
+
+
+def _committed_counters(fname, kernel, dtype, members):
+  """-> (record of `kernel` | None, provenance dict).  None + the reason when there is no measurement of THIS build:
+  file absent, other member count, kernel symbol not in it, or taken with other kernel sources (stale)."""
+  rel = os.path.join('profiles', fname)
+  path = os.path.join(ROOT, rel)
+  src = {'file': rel, 'measured': 'separate rocprofv3 --pmc passes of this command, committed; NOT re-measured in this run'}
+  if members != 64 or kernel not in KERNEL_SYMBOL:
+    return None, dict(src, used=False, why='no committed measurement for this kernel / member count')
+  if not os.path.exists(path):
+    return None, dict(src, used=False, why='file absent')
   with open(path) as f:
     table = json.load(f)
+  meta = table.get('_meta') or {}
+  src.update({k: meta[k] for k in ('commit', 'kernel_source_sha16', 'taken') if k in meta})
+  here = kernel_source_sha16()
+  if meta.get('kernel_source_sha16') != here:
+    return None, dict(src, used=False, why=f'stale: taken with kernel sources {meta.get("kernel_source_sha16")}, this build is {here}')
+  sym = KERNEL_SYMBOL[kernel].format(T='bnf::bf16_t' if dtype == 'bf16' else 'float').split('(')[0]
   for name, rec in table.items():
-    if name.startswith(sym.split('(')[0]):
-      return rec
-  return None
+    if name != '_meta' and name.startswith(sym):
+      return rec, dict(src, used=True, symbol=name)
+  return None, dict(src, used=False, why=f'no kernel symbol starting with {sym!r} in the file')
+
+
+def sq_counters(kernel, dtype, members):
+  """Per-launch SQ counters of `kernel` from the committed rocprofv3 --pmc passes of this same command
+  (profiles/sq_counters.json, made by scripts/gpu_counters.sh + scripts/counter_summary.py) + provenance."""
+  return _committed_counters('sq_counters.json', kernel, dtype, members)
 
 
 def issue_floors(ctr, launch_us, n_simd=1024):
@@ -96,18 +125,10 @@ def issue_floors(ctr, launch_us, n_simd=1024):
 def pmc_traffic(kernel, dtype, members):
   """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this
   same command (profiles/pmc_traffic.json, made by scripts/gpu_pmc.sh; FETCH_SIZE and
-  WRITE_SIZE in separate passes, 2*FETCH + WRITE KiB, see scripts/pmc_summary.py).
-  None when no matching measurement is committed."""
-  path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-  if members != 64 or kernel not in KERNEL_SYMBOL or not os.path.exists(path):
-    return None
-  sym = KERNEL_SYMBOL[kernel].format(T='bnf::bf16_t' if dtype == 'bf16' else 'float')
-  with open(path) as f:
-    table = json.load(f)
-  for name, rec in table.items():
-    if name.startswith(sym):
-      return rec['hbm_bytes']
-  return None
+  WRITE_SIZE in separate passes, 2*FETCH + WRITE KiB, see scripts/pmc_summary.py) + provenance.
+  None when no measurement of this build is committed."""
+  rec, src = _committed_counters('pmc_traffic.json', kernel, dtype, members)
+  return (rec['hbm_bytes'] if rec else None), src
 
 
 def synthetic_grid(seed=1234):
@@ -272,17 +293,25 @@ def _free_port():
     return sk.getsockname()[1]
 
 
+def devices_visible():
+  import torch
+  return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def require_devices(n):
+  visible = devices_visible()
+  if visible < n:
+    raise SystemExit(f'[bench] --gpus {n} requested but devices visible: {visible}; refusing to run '
+                     'a smaller job under that label')
+
+
 def self_launch(args, argv):
   """`python bench.py --gpus N` without a launcher: start N ranks of this file under
   torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and pass their output through.
   Fails loudly when fewer than N devices are visible (never measures 1 GPU and calls it N)."""
   import subprocess
   if not args.selftest_cpu:
-    import torch
-    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if visible < args.gpus:
-      raise SystemExit(f'[bench] --gpus {args.gpus} requested but devices visible: {visible}; refusing to run '
-                       'a smaller job under that label')
+    require_devices(args.gpus)
   env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
          '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
@@ -358,6 +387,25 @@ class _SelftestCommLib:
     self.calls.append(('allgather', n))
     return 0
 
+  def bnf_comm_available(self):
+    return 0
+
+  # one process, several devices (--launcher inproc): the communicator set and the grouped all-gather
+  def bnf_comm_create_local(self, n, devices, out):
+    self.calls.append(('create_local', int(n), [int(devices[i]) for i in range(int(n))]))
+    for i in range(int(n)):
+      out[i] = 1000 + i
+    return 0
+
+  def bnf_allgather_group(self, n, comms, send, recv, nbytes, streams):
+    import ctypes
+    nb = int(nbytes.value)
+    for i in range(int(n)):          # every local rank receives every block, rank-major
+      for j in range(int(n)):
+        ctypes.memmove(recv[i] + j * nb, send[j], nb)
+    self.calls.append(('allgather_group', int(n), nb))
+    return 0
+
 
 def gather_posterior(world, rank, device, local_means, impl, lib=None):
   """The job's only data collective (reference inference.py:452,486-492: pmap's output gather):
@@ -401,6 +449,120 @@ def gather_checksums(world, device, local_means):
   return [float(v) for v in out.cpu()]
 
 
+def gather_posterior_inproc(parts, lib=None):
+  """--launcher inproc: one tensor per local device -> (n * E_local, R): ONE grouped RCCL all-gather over the local
+  communicator set (`_native.allgather_local`; `lib`: the CPU self-test's stand-in), peer copies when RCCL cannot
+  serve the device list.  -> (tensor on the first device, ms, impl, error | None)."""
+  import torch
+  from bayesnf_amd import _native, distributed
+  parts = [p.contiguous() for p in parts]
+  n = len(parts)
+  err = None
+  on_gpu = parts[0].is_cuda
+  if lib is not None or on_gpu:
+    try:
+      recvs = [torch.empty((n,) + tuple(p.shape), dtype=p.dtype, device=p.device) for p in parts]
+      if on_gpu:
+        warm_s = [torch.zeros(8, dtype=torch.float32, device=p.device) for p in parts]   # communicator set-up outside the timing
+        warm_r = [torch.zeros(8 * n, dtype=torch.float32, device=p.device) for p in parts]
+        _native.allgather_local(warm_s, warm_r, lib=lib)
+        for p in parts:
+          torch.cuda.synchronize(p.device)
+      t0 = time.perf_counter()
+      _native.allgather_local(parts, recvs, lib=lib)
+      if on_gpu:
+        for p in parts:
+          torch.cuda.synchronize(p.device)
+      ms = (time.perf_counter() - t0) * 1e3
+      return recvs[0].view((n * parts[0].shape[0],) + tuple(parts[0].shape[1:])), ms, 'rccl-group', None
+    except (RuntimeError, OSError) as exc:
+      err = f'{type(exc).__name__}: {exc}'[:300]
+  t0 = time.perf_counter()
+  out = torch.cat([p.to(parts[0].device) for p in parts], dim=0)
+  if on_gpu:
+    torch.cuda.synchronize(parts[0].device)
+  return out, (time.perf_counter() - t0) * 1e3, 'peer-copies', err
+
+
+def run_rank(args, rank, device, E, data, sync):
+  """One rank's share of the job (one process per GPU, or one host thread per GPU under --launcher inproc):
+  engine set-up, device preheat, W warm-up steps, then EXACTLY K timed steps between two `sync()` rendezvous.
+  -> dict(elapsed, prof, dominant, final_loss, net, eng, local_means | None)."""
+  import torch
+  X, y, input_scales = data
+  if args.selftest_cpu:
+    # stand-in for the engine: a fixed amount of host work per "step", rank-dependent means
+    work = torch.randn(256, 256)
+    def run_steps(k):
+      for _ in range(k):
+        torch.mm(work, work)
+    run_steps(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    sync()
+    return dict(elapsed=time.perf_counter() - t0, prof=None, dominant='selftest', final_loss=0.0, net=None, eng=None,
+                local_means=torch.full((E, 16), float(rank), device=device), device=str(device))
+  from bayesnf_amd.engine import Engine
+  from bayesnf_amd.spec import NetSpec
+  net = NetSpec(input_scales=input_scales, **MODEL_KW)
+  eng = Engine(net, mode='map', X=X, y=y, members=E, member_offset=rank * E, seed=0,
+               learning_rate=0.005, prior_weight=1.0, compute_dtype=args.dtype, device_index=device.index)
+  eng.init_params(float(np.log(np.nanstd(y) / 2)))
+  # the device ramps for ~8 steps (16 ms) after an idle period, whatever engine runs on it: a fresh engine's steps
+  # 2..8 take 2.6 -> 2.03 ms, a second engine's in the same process 2.11 -> 2.0 (profiles/r03_device_ramp.txt)
+  if args.preheat_ms > 0:
+    scratch = Engine(net, mode='map', X=X, y=y, members=E, member_offset=rank * E, seed=1,
+                     learning_rate=0.005, prior_weight=1.0, compute_dtype=args.dtype, device_index=device.index)
+    scratch.init_params(0.0)
+    t_h = time.perf_counter()
+    ep_h = 0
+    while (time.perf_counter() - t_h) * 1e3 < args.preheat_ms:
+      scratch.train(ep_h, 8)
+      torch.cuda.synchronize(device)
+      ep_h += 8
+    scratch.close()
+  # ---- warm-up (also finds the dominant kernel) --------------------------------
+  eng.profile('*')
+  eng.train(0, max(args.warmup, 1))
+  sync()
+  warm = eng.profile_read()
+  eng.profile(None)
+  total_ms = {k: v['avg_ms'] * v['calls'] for k, v in warm.items()}
+  dominant = max(total_ms, key=total_ms.get)
+  if args.profile_all and rank == 0:
+    for k, v in sorted(warm.items(), key=lambda kv: -total_ms[kv[0]]):
+      tf = v['flops'] / (v['avg_ms'] * 1e-3) / 1e12 if v['flops'] else 0.0
+      print(f'[bench] {k:16s} avg {v["avg_ms"]*1e3:9.1f} us  x{v["calls"]:4d}  '
+            f'{tf:8.1f} TFLOP/s', file=sys.stderr)
+  # ---- timed region: exactly K steps, events only around the dominant kernel ---
+  eng.profile(dominant)
+  sync()
+  t0 = time.perf_counter()
+  losses = eng.train(args.warmup, args.steps)
+  sync()
+  elapsed = time.perf_counter() - t0
+  prof = eng.profile_read()
+  eng.profile(None)
+  final_loss = float(losses[:, -1].mean().item())
+  if not np.isfinite(final_loss):
+    raise RuntimeError('non-finite training loss in the benchmark run')
+  return dict(elapsed=elapsed, prof=prof, dominant=dominant, final_loss=final_loss, net=net, eng=eng, local_means=None,
+              device=str(device))
+
+
+def predictive_means(args, r, device, E, X):
+  """this rank's members on the first 1024 training rows (forward-only handle): what the posterior gather carries"""
+  import torch
+  from bayesnf_amd.engine import Engine
+  fwd = Engine(r['net'], members=E, forward_only=True, row_capacity=1024, compute_dtype=args.dtype, device_index=device.index)
+  Xd = torch.from_numpy(np.ascontiguousarray(X[:1024], dtype=np.float32)).to(device)
+  means, _ = fwd.forward(r['eng'].params.view(E, r['net'].P), Xd)
+  torch.cuda.synchronize(device)
+  fwd.close()
+  return means
+
+
 def main(argv=None):
   argv = list(sys.argv[1:] if argv is None else argv)
   ap = argparse.ArgumentParser()
@@ -411,6 +573,13 @@ def main(argv=None):
   ap.add_argument('--strong', action='store_true',
                   help='strong scaling: --members-per-gpu is the size of the WHOLE ensemble, split evenly over the '
                        'ranks (default: weak scaling, that many members on every GPU)')
+  ap.add_argument('--launcher', default='torchrun', choices=['torchrun', 'inproc'],
+                  help='N > 1: one process per GPU under torch.distributed.run (default; what the driver starts), or '
+                       "ONE process driving every GPU from one host thread each (`inproc`: the reference's own shape, "
+                       'jax.pmap over jax.local_devices(); the gather is one grouped RCCL all-gather)')
+  ap.add_argument('--check', action='store_true',
+                  help='pre-flight for N > 1: create the communicator(s), all-gather 1 KiB per rank, verify, print one '
+                       'JSON line and exit -- an RCCL set-up failure costs seconds, not the lease')
   ap.add_argument('--gather', default=None, choices=['cabi', 'torch'],
                   help="posterior gather through bnf_allgather of the engine library (default on GPUs; env "
                        "BNF_GATHER) or torch.distributed's all_gather_into_tensor")
@@ -427,122 +596,137 @@ def main(argv=None):
                   help='no GPU: exercise launcher, process group (gloo), timing reduction, posterior gather and '
                        'the JSON line with a stand-in step (tests/test_bench_launcher.py)')
   args = ap.parse_args(argv)
+  inproc = args.launcher == 'inproc' and args.gpus > 1 and 'WORLD_SIZE' not in os.environ
 
-  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+  if args.gpus > 1 and not inproc and 'WORLD_SIZE' not in os.environ:
     sys.exit(self_launch(args, argv))
 
   import torch
-  world, rank, device = init_group(args.selftest_cpu)
-  if args.gpus != world:
-    raise SystemExit(f'[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
-  seen = collective_world_size(world, device)
-  if seen != world:
-    raise SystemExit(f'[bench] all_reduce saw {seen} ranks, expected {world}')
+  import threading
+  visible = 0 if args.selftest_cpu else devices_visible()
+  if inproc:
+    # ONE process, one engine + one host thread per device (bayesnf_amd.distributed.run_shards); no process group
+    from bayesnf_amd import distributed
+    if not args.selftest_cpu:
+      require_devices(args.gpus)
+    world, rank = args.gpus, 0
+    devs = (list(range(world)) if args.selftest_cpu else
+            (distributed.local_devices() if os.environ.get('BNF_DEVICES') else list(range(world)))[:world])
+    if len(devs) != world:
+      raise SystemExit(f'[bench] --launcher inproc --gpus {world}: BNF_DEVICES names {len(devs)} device(s)')
+    devices = [torch.device('cpu') if args.selftest_cpu else torch.device(f'cuda:{d}') for d in devs]
+    device = devices[0]
+    seen = world
+  else:
+    world, rank, device = init_group(args.selftest_cpu)
+    if args.gpus != world:
+      raise SystemExit(f'[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    seen = collective_world_size(world, device)
+    if seen != world:
+      raise SystemExit(f'[bench] all_reduce saw {seen} ranks, expected {world}')
+    devices = [device]
 
-  X, y, input_scales = synthetic_grid()
+  gather_impl = args.gather or os.environ.get('BNF_GATHER') or ('torch' if args.selftest_cpu else 'cabi')
+  comm_lib = _SelftestCommLib() if (args.selftest_cpu and (gather_impl == 'cabi' or inproc)) else None
+
+  if args.check:
+    # ---- pre-flight: communicator(s) + a 1 KiB all-gather, nothing else -------------------------------------
+    t0 = time.perf_counter()
+    if inproc:
+      parts = [torch.full((1, 256), float(i), dtype=torch.float32, device=d) for i, d in enumerate(devices)]
+      allm, _, impl, err = gather_posterior_inproc(parts, lib=comm_lib)
+    else:
+      part = torch.full((1, 256), float(rank), dtype=torch.float32, device=device)
+      err = None
+      try:
+        allm, _ = gather_posterior(world, rank, device, part, gather_impl, lib=comm_lib)
+        impl = gather_impl
+      except RuntimeError as exc:   # (raised on every rank together: _native.allgather agrees first)
+        if gather_impl != 'cabi':
+          raise
+        err, impl = f'{type(exc).__name__}: {exc}'[:300], 'torch'
+        allm, _ = gather_posterior(world, rank, device, part, 'torch')
+    ok = allm.view(world, -1)[:, 0].tolist() == [float(r) for r in range(world)]
+    if rank == 0:
+      print(json.dumps({'check': 'ok' if ok else 'FAILED', 'n_gpus': world, 'launcher': 'inproc' if inproc else 'torchrun',
+                        'devices_visible': visible, 'rank_devices': [str(d) for d in devices] if inproc else None,
+                        'gather_impl': impl, 'error': err, 'bytes_per_rank': 1024,
+                        's': round(time.perf_counter() - t0, 3)}), flush=True)
+    if world > 1 and not inproc:
+      torch.distributed.barrier()
+      torch.distributed.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+  data = synthetic_grid()
+  X, y, input_scales = data
   E = args.members_per_gpu
   if args.strong:
     if E % world:
       raise SystemExit(f'[bench] --strong: {E} members do not split evenly over {world} ranks')
     E //= world
-  gather_impl = args.gather or os.environ.get('BNF_GATHER') or ('torch' if args.selftest_cpu else 'cabi')
-
-  def sync():
-    if device.type == 'cuda':
-      torch.cuda.synchronize(device)
-    if world > 1:
-      torch.distributed.barrier()
-      if device.type == 'cuda':
-        torch.cuda.synchronize(device)
-
-  if args.selftest_cpu:
-    # stand-in for the engine: a fixed amount of host work per "step", rank-dependent means
-    work = torch.randn(256, 256)
-    def run_steps(k):
-      for _ in range(k):
-        torch.mm(work, work)
-    run_steps(args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    local_means = torch.full((E, 16), float(rank), device=device)
-    prof, dominant, final_loss, net, eng = None, 'selftest', 0.0, None, None
-  else:
-    from bayesnf_amd.engine import Engine
-    from bayesnf_amd.spec import NetSpec
-    net = NetSpec(input_scales=input_scales, **MODEL_KW)
-    eng = Engine(net, mode='map', X=X, y=y, members=E, member_offset=rank * E, seed=0,
-                 learning_rate=0.005, prior_weight=1.0, compute_dtype=args.dtype)
-    eng.init_params(float(np.log(np.nanstd(y) / 2)))
-    # the device ramps for ~8 steps (16 ms) after an idle period, whatever engine runs on it: a fresh engine's steps
-    # 2..8 take 2.6 -> 2.03 ms, a second engine's in the same process 2.11 -> 2.0 (profiles/r03_device_ramp.txt)
-    if args.preheat_ms > 0:
-      scratch = Engine(net, mode='map', X=X, y=y, members=E, member_offset=rank * E, seed=1,
-                       learning_rate=0.005, prior_weight=1.0, compute_dtype=args.dtype)
-      scratch.init_params(0.0)
-      t_h = time.perf_counter()
-      ep_h = 0
-      while (time.perf_counter() - t_h) * 1e3 < args.preheat_ms:
-        scratch.train(ep_h, 8)
-        torch.cuda.synchronize(device)
-        ep_h += 8
-      scratch.close()
-    # ---- warm-up (also finds the dominant kernel) --------------------------------
-    eng.profile('*')
-    eng.train(0, max(args.warmup, 1))
-    sync()
-    warm = eng.profile_read()
-    eng.profile(None)
-    total_ms = {k: v['avg_ms'] * v['calls'] for k, v in warm.items()}
-    dominant = max(total_ms, key=total_ms.get)
-    if args.profile_all and rank == 0:
-      for k, v in sorted(warm.items(), key=lambda kv: -total_ms[kv[0]]):
-        tf = v['flops'] / (v['avg_ms'] * 1e-3) / 1e12 if v['flops'] else 0.0
-        print(f'[bench] {k:16s} avg {v["avg_ms"]*1e3:9.1f} us  x{v["calls"]:4d}  '
-              f'{tf:8.1f} TFLOP/s', file=sys.stderr)
-    # ---- timed region: exactly K steps, events only around the dominant kernel ---
-    eng.profile(dominant)
-    sync()
-    t0 = time.perf_counter()
-    losses = eng.train(args.warmup, args.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_read()
-    eng.profile(None)
-    final_loss = float(losses[:, -1].mean().item())
-    if not np.isfinite(final_loss):
-      raise RuntimeError('non-finite training loss in the benchmark run')
-    local_means = None
-
-  rank_s = gather_rank_times(world, device, elapsed)
-  elapsed = max(rank_s)
 
   gather = None
+  if inproc:
+    # every device's thread meets the others on both sides of the timed region; its own device is synchronised first
+    meet = threading.Barrier(world)
+    def make_sync(dev):
+      def sync():
+        if dev.type == 'cuda':
+          torch.cuda.synchronize(dev)
+        meet.wait(timeout=1800)
+      return sync
+    shards = [distributed.Shard(i, devs[i]) for i in range(world)]
+    results = distributed.run_shards(lambda sh: run_rank(args, sh.index, devices[sh.index], E, data, make_sync(devices[sh.index])),
+                                     shards)
+    r0 = results[0]
+    rank_s = [r['elapsed'] for r in results]
+    rank_devices = [r['device'] for r in results]
+    parts = [(r['local_means'] if r['local_means'] is not None else predictive_means(args, r, devices[i], E, X))
+             for i, r in enumerate(results)]
+    sums = [float(p.double().sum().item()) for p in parts]
+    allm, ms, impl, err = gather_posterior_inproc(parts, lib=comm_lib)
+    gather_impl = impl
+    cabi_error = err
+  else:
+    def sync():
+      if device.type == 'cuda':
+        torch.cuda.synchronize(device)
+      if world > 1:
+        torch.distributed.barrier()
+        if device.type == 'cuda':
+          torch.cuda.synchronize(device)
+    r0 = run_rank(args, rank, device, E, data, sync)
+    results = [r0]
+    rank_s = gather_rank_times(world, device, r0['elapsed'])
+    rank_devices = None
+    if world > 1:
+      ords = torch.tensor([device.index if device.type == 'cuda' else -1], dtype=torch.int64, device=device)
+      allo = torch.empty(world, dtype=torch.int64, device=device)
+      torch.distributed.all_gather_into_tensor(allo, ords)
+      rank_devices = [('cpu' if v < 0 else f'cuda:{int(v)}') for v in allo.cpu()]
+      local_means = r0['local_means'] if r0['local_means'] is not None else predictive_means(args, r0, device, E, X)
+      sums = gather_checksums(world, device, local_means)
+      cabi_error = None
+      try:
+        allm, ms = gather_posterior(world, rank, device, local_means, gather_impl, lib=comm_lib)
+      except RuntimeError as exc:
+        if gather_impl != 'cabi':
+          raise
+        # the C-ABI communicator could not be set up on this node (every rank raised together: `_native.allgather`
+        # agrees across ranks before it raises): say so in the line and gather with the process group instead (the
+        # timed region is already over; the collective is not part of `value`)
+        cabi_error, gather_impl = f'{type(exc).__name__}: {exc}'[:300], 'torch'
+        allm, ms = gather_posterior(world, rank, device, local_means, gather_impl)
+      parts = [local_means]
+  elapsed = max(rank_s)
+
   if world > 1:
-    if local_means is None:
-      # predictive means of this rank's members on the first 1024 training rows (forward-only handle)
-      fwd = Engine(net, members=E, forward_only=True, row_capacity=1024, compute_dtype=args.dtype)
-      Xd = torch.from_numpy(np.ascontiguousarray(X[:1024], dtype=np.float32)).to(device)
-      local_means, _ = fwd.forward(eng.params.view(E, net.P), Xd)
-      torch.cuda.synchronize(device)
-    comm_lib = _SelftestCommLib() if (args.selftest_cpu and gather_impl == 'cabi') else None
-    sums = gather_checksums(world, device, local_means)
-    cabi_error = None
-    try:
-      allm, ms = gather_posterior(world, rank, device, local_means, gather_impl, lib=comm_lib)
-    except Exception as exc:  # pylint: disable=broad-except
-      if gather_impl != 'cabi':
-        raise
-      # the C-ABI communicator could not be set up on this node: say so in the line and gather with the
-      # process group instead (the timed region is already over; the collective is not part of `value`)
-      cabi_error, gather_impl = f'{type(exc).__name__}: {exc}'[:300], 'torch'
-      allm, ms = gather_posterior(world, rank, device, local_means, gather_impl)
     got = [float(v) for v in allm.view(world, -1).double().sum(dim=1).cpu()]
-    gather = {'impl': ('bnf_allgather (C ABI of libbnf_hip.so -> ncclAllGather, RCCL)' if gather_impl == 'cabi' else
-                       'torch.distributed.all_gather_into_tensor (backend %s)' % torch.distributed.get_backend()),
-              'shape': list(allm.shape), 'bytes_per_rank': local_means.numel() * local_means.element_size(),
+    names = {'cabi': 'bnf_allgather (C ABI of libbnf_hip.so -> ncclAllGather, RCCL)',
+             'rccl-group': 'bnf_comm_create_local + bnf_allgather_group (C ABI of libbnf_hip.so -> ncclCommInitAll, grouped ncclAllGather, RCCL)',
+             'peer-copies': 'peer copies to the first device (RCCL could not serve the device list)'}
+    gather = {'impl': names.get(gather_impl) or 'torch.distributed.all_gather_into_tensor (backend %s)' % torch.distributed.get_backend(),
+              'shape': list(allm.shape), 'bytes_per_rank': parts[0].numel() * parts[0].element_size(),
               'ms': ms, 'finite': bool(torch.isfinite(allm).all().item()),
               'rank_checksums': sums,
               'rank_checksums_ok': all(abs(a - b) <= 1e-9 * max(1.0, abs(a)) for a, b in zip(sums, got))}
@@ -553,9 +737,8 @@ def main(argv=None):
       gather['rank_blocks_ok'] = blocks == [float(r) for r in range(world)]
       if comm_lib is not None:
         gather['cabi_calls'] = comm_lib.calls
-        gather['cabi_id_head'] = list(comm_lib.ident[:4])
-    if not args.selftest_cpu:
-      fwd.close()
+        if comm_lib.ident is not None:
+          gather['cabi_id_head'] = list(comm_lib.ident[:4])
 
   if rank == 0:
     total_members = E * world
@@ -570,14 +753,18 @@ def main(argv=None):
                                'depth=2, NORMAL, full batch, lr=0.005',
                    'members_per_gpu': E, 'ensemble_size': total_members, 'parallelism':
                    f'ensemble-shard x{world} (no data-path collective)'},
+        'launcher': ('inproc: one process, one host thread per GPU' if inproc else
+                     ('torch.distributed.run: one process per GPU' if world > 1 else 'single process')),
+        'devices_visible': visible, 'rank_devices': rank_devices,
         'rccl_world_size': seen, 'per_rank_ms_per_step': [t / args.steps * 1e3 for t in rank_s],
-        'final_loss_mean': final_loss,
+        'final_loss_mean': r0['final_loss'],
     }
     if gather is not None:
       line['posterior_gather'] = gather
     if args.selftest_cpu:
       line['selftest'] = True
     else:
+      prof, dominant, net = r0['prof'], r0['dominant'], r0['net']
       line['device_preheat'] = {'ms': args.preheat_ms, 'what': 'untimed steps of a scratch engine (other parameters and buffers) '
                                 'before the W warm-up steps of the measured engine: device power / clock state; --preheat-ms 0 = off'}
       d = prof[dominant]
@@ -585,18 +772,21 @@ def main(argv=None):
       peak = PEAK_TFLOPS[args.dtype]
       flops_step = net.flops_per_member_step(len(y)) * total_members
       line['algorithmic_tflops'] = flops_step * args.steps / elapsed / 1e12
+      traffic, traffic_src = pmc_traffic(dominant, args.dtype, E)
+      ctr, ctr_src = sq_counters(dominant, args.dtype, E)
       line['roofline'] = {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': peak,
                           'unit': 'TFLOP/s', 'frac': achieved / peak,
-                          'traffic': pmc_traffic(dominant, args.dtype, E),
+                          'traffic': traffic, 'traffic_source': traffic_src,
                           'avg_launch_us': d['avg_ms'] * 1e3, 'launches': d['calls'],
                           'flops_per_launch': d['flops'],
-                          'issue_floors': issue_floors(sq_counters(dominant, args.dtype, E), d['avg_ms'] * 1e3)}
+                          'issue_floors': issue_floors(ctr, d['avg_ms'] * 1e3), 'issue_floors_source': ctr_src}
       if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(X, y, input_scales)
     print(json.dumps(line), flush=True)
-  if eng is not None:
-    eng.close()
-  if world > 1:
+  for r in results:
+    if r['eng'] is not None:
+      r['eng'].close()
+  if world > 1 and not inproc:
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

@@ -316,9 +316,17 @@ double bnf_kernel_flops(const bnf_handle* h, const char* name);
  *   stream   hipStream_t the collective is enqueued on (no host synchronisation) */
 #define BNF_COMM_ID_BYTES 128
 typedef struct bnf_comm bnf_comm;
+int bnf_comm_available(void);   /* 0 when librccl.so and its symbols resolve (local, cheap: no id, no listener) */
 int bnf_comm_unique_id(void* id);
 int bnf_comm_create(const void* id, int32_t world, int32_t rank, int32_t device, bnf_comm** out);
 int bnf_allgather(bnf_comm* c, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+/* ONE process driving n devices -- the reference's own shape (`jax.pmap` over `jax.local_devices()`,
+ * inference.py:573-579,445): `bnf_comm_create_local` makes one communicator per listed device in one call
+ * (ncclCommInitAll; out[n]; a device listed twice is refused), `bnf_allgather_group` enqueues every local rank's
+ * all-gather in one group (send[i] / recv[i] / streams[i] on comms[i]'s device; recv[i] receives all n blocks). */
+int bnf_comm_create_local(int32_t n, const int32_t* devices, bnf_comm** out);
+int bnf_allgather_group(int32_t n, bnf_comm* const* comms, const void* const* send, void* const* recv,
+                        size_t bytes_per_rank, void* const* streams);
 void bnf_comm_destroy(bnf_comm* c);
 
 #ifdef __cplusplus

@@ -37,6 +37,9 @@ def dump_json(out_dir, path):
       for row in csv.DictReader(fh):
         vals[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
   out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in vals.items() if k.startswith(('void bnf', 'bnf::'))}
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from pmc_summary import profile_meta
+  out['_meta'] = profile_meta()
   with open(path, 'w') as fh:
     json.dump(out, fh, indent=1)
 

@@ -13,6 +13,17 @@ import sys
 from collections import defaultdict
 
 
+def profile_meta():
+  """What build the passes belong to (bench.py quotes the file only for a build with the same kernel sources):
+  sha256 over bayesnf_amd/csrc (bench.kernel_source_sha16) + the date; `commit` is stamped when the file is copied
+  into profiles/ (scripts/stamp_profiles.py: the GPU box has no .git)."""
+  import datetime
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  import bench
+  return {'kernel_source_sha16': bench.kernel_source_sha16(), 'taken': datetime.date.today().isoformat(),
+          'command': 'python bench.py --steps 10 --warmup 2 --no-cpu-baseline under rocprofv3 --pmc (one pass per counter set)'}
+
+
 def load(counter_dir, counter):
   per = defaultdict(list)
   for path in glob.glob(os.path.join(counter_dir, '**', '*counter_collection*.csv'), recursive=True):
@@ -39,6 +50,7 @@ def main(out_dir):
     result[k] = dict(launches=max(len(f), len(w)), fetch_kib=fa, write_kib=wa, hbm_bytes=traffic)
     short = k if len(k) < 90 else k[:87] + '...'
     print(f'| `{short}` | {max(len(f), len(w))} | {fa:.0f} | {wa:.0f} | {traffic:.3e} |')
+  result['_meta'] = profile_meta()
   with open(os.path.join(out_dir, 'traffic.json'), 'w') as fjs:
     json.dump(result, fjs, indent=1)
 

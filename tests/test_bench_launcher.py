@@ -68,3 +68,58 @@ def test_more_gpus_than_visible_fails_loudly():
   r = _run(['--gpus', '2', '--steps', '1', '--warmup', '1'])
   assert r.returncode != 0
   assert 'devices visible: 0' in (r.stderr + r.stdout)
+
+
+def test_inproc_launcher_one_process_drives_every_device():
+  """`--launcher inproc` (the reference's own shape: one process, jax.pmap over the local devices): one host thread
+  per device through `distributed.run_shards`, the timed region bracketed by a thread rendezvous + device sync on both
+  sides, max over the devices, and the posterior gathered by ONE grouped all-gather over the local communicator
+  set (`_native.allgather_local` -> bnf_comm_create_local / bnf_allgather_group; here bench.py's stand-in)."""
+  r = _run(['--selftest-cpu', '--gpus', '3', '--launcher', 'inproc', '--steps', '3', '--warmup', '1', '--members-per-gpu', '2'])
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, r.stdout
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 3 and d['launcher'].startswith('inproc') and d['config']['ensemble_size'] == 6
+  assert len(d['per_rank_ms_per_step']) == 3 and len(d['rank_devices']) == 3
+  assert abs(d['ms_per_step'] - max(d['per_rank_ms_per_step'])) < 1e-9
+  g = d['posterior_gather']
+  assert 'bnf_allgather_group' in g['impl'] and g['shape'] == [6, 16] and g['rank_blocks_ok'] and g['rank_checksums_ok']
+  assert g['cabi_calls'] == [['create_local', 3, [0, 1, 2]], ['allgather_group', 3, 2 * 16 * 4]]
+
+
+def test_preflight_check_creates_the_communicator_and_exits():
+  """`--check`: communicator(s) + a 1 KiB all-gather per rank, one JSON line, exit code 0 -- for both launchers; no
+  engine, no data, seconds."""
+  for extra in (['--launcher', 'inproc'], ['--gather', 'cabi'], []):
+    r = _run(['--selftest-cpu', '--gpus', '2', '--check'] + extra)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['check'] == 'ok' and d['n_gpus'] == 2 and d['bytes_per_rank'] == 1024 and d['error'] is None
+    assert d['launcher'] == ('inproc' if extra[:1] == ['--launcher'] else 'torchrun')
+
+
+def test_committed_counter_files_are_quoted_only_for_the_build_they_measured(tmp_path, monkeypatch):
+  """roofline.traffic / issue_floors come from committed rocprofv3 --pmc passes (they cannot be re-taken inside a
+  timed run): the line says so (`traffic_source`), and a file taken with other kernel sources yields null."""
+  import bench
+  sha = bench.kernel_source_sha16()
+  sym = 'void bnf::k_panel_fwd_bwd<8, 4, true, false, 1, 64>(bnf::PanelArgs)'
+  prof = tmp_path / 'profiles'
+  prof.mkdir()
+  monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+  monkeypatch.setattr(bench, 'kernel_source_sha16', lambda: sha)
+  (prof / 'pmc_traffic.json').write_text(json.dumps({sym: {'hbm_bytes': 2.5e9}, '_meta': {'kernel_source_sha16': sha, 'commit': 'abc1234'}}))
+  v, src = bench.pmc_traffic('panel_fwd_bwd', 'bf16', 64)
+  assert v == 2.5e9 and src['used'] and src['commit'] == 'abc1234' and src['file'].endswith('pmc_traffic.json')
+  (prof / 'pmc_traffic.json').write_text(json.dumps({sym: {'hbm_bytes': 2.5e9}, '_meta': {'kernel_source_sha16': 'other'}}))
+  v, src = bench.pmc_traffic('panel_fwd_bwd', 'bf16', 64)
+  assert v is None and not src['used'] and 'stale' in src['why']
+  (prof / 'pmc_traffic.json').write_text(json.dumps({sym: {'hbm_bytes': 2.5e9}}))          # no _meta at all: stale
+  assert bench.pmc_traffic('panel_fwd_bwd', 'bf16', 64)[0] is None
+  assert bench.pmc_traffic('panel_fwd_bwd', 'bf16', 8)[0] is None                           # other member count
+  (prof / 'sq_counters.json').write_text(json.dumps({sym: {'SQ_INSTS_VALU': 2.0e8, 'SQ_INSTS_MFMA': 2.5e7},
+                                                      '_meta': {'kernel_source_sha16': sha}}))
+  ctr, src = bench.sq_counters('panel_fwd_bwd', 'bf16', 64)
+  fl = bench.issue_floors(ctr, 1200.0)
+  assert src['used'] and abs(fl['valu_per_mfma'] - 8.0) < 1e-9 and fl['valu_issue_floor_us'] > 0

@@ -81,3 +81,46 @@ def test_bench_two_ranks_gathers_through_the_c_abi():
   g = d['posterior_gather']
   assert d['n_gpus'] == 2 and d['rccl_world_size'] == 2 and 'cabi_error' not in g, g
   assert 'bnf_allgather' in g['impl'] and g['rank_checksums_ok'] and g['finite'] and g['shape'] == [16, 1024]
+
+
+def test_one_process_two_gpus_gathers_through_the_rccl_group(monkeypatch, golden_dir):
+  """The reference's own shape on two real GPUs: ONE process, one engine handle + host thread per device
+  (`distributed.run_shards`), the fitted parameters / predictive means assembled by one grouped RCCL all-gather over
+  the local communicator set (bnf_comm_create_local + bnf_allgather_group) -- equal to the one-device fit member for
+  member, and to the same gather done with peer copies."""
+  import pandas as pd
+  from bayesnf_amd import BayesianNeuralFieldMAP, distributed
+  df = pd.read_csv(os.path.join(golden_dir, 'chickenpox.8.train.csv'), index_col=0, parse_dates=['datetime'])
+  def fit(devs, gather):
+    monkeypatch.setenv('BNF_DEVICES', devs)
+    monkeypatch.setenv('BNF_GATHER', gather)
+    est = BayesianNeuralFieldMAP(width=64, depth=2, seasonality_periods=np.asarray([4.0, 52.1775]),
+                                 num_seasonal_harmonics=np.asarray([2.0, 4]), observation_model='NORMAL',
+                                 feature_cols=['datetime', 'latitude', 'longitude'], target_col='chickenpox',
+                                 timetype='index', freq='W', standardize=['latitude', 'longitude'])
+    est.fit(df, seed=3, ensemble_size=6, num_epochs=6, learning_rate=0.01)
+    means, _ = est.predict(df, quantiles=(0.5,))
+    return est.losses_.reshape(6, -1), means.reshape(6, -1), distributed.last_gather()
+  l2, m2, note = fit('0,1', 'rccl')
+  assert note.get('impl') == 'rccl-group', note
+  lp, mp, notep = fit('0,1', 'peer')
+  assert notep.get('impl') == 'peer-copies'
+  l1, m1, _ = fit('0', 'rccl')
+  np.testing.assert_array_equal(l2, lp)
+  np.testing.assert_array_equal(m2, mp)
+  np.testing.assert_allclose(l2, l1, rtol=1e-5)
+  np.testing.assert_allclose(m2, m1, rtol=1e-4, atol=1e-5)
+
+
+def test_bench_inproc_launcher_on_two_gpus():
+  for extra in (['--check'], ['--steps', '3', '--warmup', '1', '--members-per-gpu', '8', '--no-cpu-baseline']):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launcher', 'inproc'] + extra,
+                       env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    if extra[0] == '--check':
+      assert d['check'] == 'ok' and d['gather_impl'] == 'rccl-group' and d['devices_visible'] >= 2
+    else:
+      assert d['n_gpus'] == 2 and d['launcher'].startswith('inproc') and d['rank_devices'] == ['cuda:0', 'cuda:1']
+      g = d['posterior_gather']
+      assert 'bnf_allgather_group' in g['impl'] and g['rank_checksums_ok'] and g['finite'] and g['shape'] == [16, 1024]
