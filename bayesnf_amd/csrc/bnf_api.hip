@@ -135,6 +135,7 @@ struct bnf_handle {
   int32_t* leaf_off = nullptr; uint8_t* leaf_id = nullptr; int32_t n_leaves = 0;
   bool adam_clear_all = false;   // env BNF_ADAM_CLEAR_ALL (A/B of the kept gradient range)
   bool h0l = false;
+  bool fold0 = false;   // the panel kernel's F0 forms: layer-0 scale / bias folded into its contraction (needs h0l, F + 2 <= Fp)
   void* A[BNF_MAX_LAYERS]; void* H[BNF_MAX_LAYERS]; void* Ht[BNF_MAX_LAYERS];
   void* dZ[BNF_MAX_LAYERS]; void* dZt[BNF_MAX_LAYERS];
   void* Kn[BNF_MAX_LAYERS]; void* Kt[BNF_MAX_LAYERS];
@@ -493,7 +494,7 @@ static void run_forward(bnf_handle* h, const float* theta, int nmem, const RowSr
     hipLaunchKernelGGL((k_featurize<T>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, X, stab,
                        y, h->scal, rows, (T*)h->H0, Bp * h->Fp,
                        (T*)nullptr, (int64_t)h->Fp * Bp, (int32_t)Bp,
-                       train ? h->ybat : (float*)nullptr, Bp, (int32_t)nmem);
+                       train ? h->ybat : (float*)nullptr, Bp, (int32_t)nmem, (int32_t)0);
   }
   const int n_layers = (train && h->fuse_last) ? h->L - 1 : h->L;   // EPI_LAST runs in run_backward
   for (int l = 0; l < n_layers; ++l) {
@@ -608,6 +609,9 @@ static void run_wgrad_layer(bnf_handle* h, int nmem, int l, hipStream_t st) {
   EpiArgs ep{};
   ep.scale = 1.0f / sqrtf((float)((l == 0) ? h->F : h->Wt));
   ep.grad = h->gradf; ep.grad_stride = h->Pf; ep.off_out = h->nd.off_kernel[l]; ep.ld_f32 = h->W;
+  if (l == 0 && h->panel && h->fold0) {   // the ones column behind the features: its row of the product is d bias0
+    ep.bias_row = 1; ep.off_bias_row = h->nd.off_bias[0];
+  }
   if (l == 0) launch_gemm_tn<T, 0>(h, KID_WGRAD0, g, ep, st, plan.kind);
   else launch_gemm_tn<T, 1>(h, KID_WGRAD, g, ep, st, plan.kind);
 }
@@ -632,6 +636,17 @@ static void wgrad_join(bnf_handle* h) {
   }
 }
 
+// -DBNF_PANEL_DK0=1 builds + env BNF_PANEL_DK0=1: the layer-0 weight gradient inside the panel kernel (experiment;
+// MAP, W = 512, Fp = 64, no width padding: Adam clears that gradient range every step there)
+static bool panel_dk0_fused(const bnf_handle* h) {
+#if BNF_PANEL_DK0
+  static const bool on = getenv("BNF_PANEL_DK0") && atoi(getenv("BNF_PANEL_DK0")) != 0;
+  return on && h->panel && h->h0l && h->W == 512 && h->Fp == 64 && h->cfg.mode == BNF_MODE_MAP && !h->pad;
+#else
+  (void)h;
+  return false;
+#endif
+}
 // the W x W weight gradients of layers 1 .. L-1 as ONE launch of the ring kernel (same shape, same split-K = 1):
 // 3 x 320 tiles at C3/8 are 4 rounds of the chip instead of 3 x 2
 static bool wgrad_multi_ok(const bnf_handle* h, int nmem) {
@@ -649,7 +664,7 @@ template <typename T>
 static void run_wgrad(bnf_handle* h, int nmem) {
   if constexpr (sizeof(T) == 2) {
     if (wgrad_multi_ok(h, nmem)) {
-      wgrad_after_dz<T>(h, nmem, 0);
+      if (!panel_dk0_fused(h)) wgrad_after_dz<T>(h, nmem, 0);
       const int64_t Bp = h->Bp;
       GemmArgs g{};
       g.a_ld = h->W; g.a_batch = Bp * h->W; g.b_ld = h->W; g.b_batch = Bp * h->W;
@@ -666,7 +681,7 @@ static void run_wgrad(bnf_handle* h, int nmem) {
       return;
     }
   }
-  for (int l = 0; l < h->L; ++l) wgrad_after_dz<T>(h, nmem, l);
+  for (int l = (panel_dk0_fused(h) ? 1 : 0); l < h->L; ++l) wgrad_after_dz<T>(h, nmem, l);
   wgrad_join(h);
 }
 
@@ -802,6 +817,7 @@ static PackJobs pack_jobs(const bnf_handle* h, int* n_tiles) {
     jb.wf[l] = h->Wf[l]; jb.wb[l] = h->Wb[l]; jb.batch[l] = h->pack_batch[l];
   }
   jb.tile0[h->L] = tiles;
+  jb.fold0 = h->fold0 ? 1 : 0; jb.F0n = h->F; jb.off_bias0 = h->nd.off_bias[0]; jb.off_ls0 = h->nd.off_ls[0];
   *n_tiles = tiles;
   return jb;
 }
@@ -818,12 +834,12 @@ static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
 // row-panel pipeline (bf16, depth 2): pack fragments -> featurise -> k_panel_fwd_bwd ->
 // featurise backward -> gemm_tn weight gradients
 // ---------------------------------------------------------------------------
-template <int WN, int RT, bool H0L, bool DEEP, int CH, int FP>
-static void launch_panel_d(bnf_handle* h, const PanelArgs& pa) {
+template <int WN, int RT, bool H0L, bool DEEP, int CH, int FP, bool F0>
+static void launch_panel_f(bnf_handle* h, const PanelArgs& pa) {
   constexpr int kLds = panel_lds_bytes(WN, RT, H0L, CH, FP);
   static_assert(kLds <= 160 * 1024, "LDS per workgroup");
   static std::atomic<uint64_t> attr_done{0};
-  allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH, FP>, kLds, &attr_done);
+  allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH, FP, F0>, kLds, &attr_done);
   PanelArgs pa2 = pa;
   pa2.ablate = h->ablate;
   const unsigned blocks = (unsigned)(pa.members * pa.panels);
@@ -834,9 +850,19 @@ static void launch_panel_d(bnf_handle* h, const PanelArgs& pa) {
   }
   {
     LaunchScope ls(h, KID_PANEL);
-    hipLaunchKernelGGL((k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH, FP>), dim3(blocks), dim3(512), kLds, h->stream, pa2);
+    hipLaunchKernelGGL((k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH, FP, F0>), dim3(blocks), dim3(512), kLds, h->stream, pa2);
   }
   phase_prof_end(h, KID_PANEL, blocks, 512);
+}
+template <int WN, int RT, bool H0L, bool DEEP, int CH, int FP>
+static void launch_panel_d(bnf_handle* h, const PanelArgs& pa) {
+  if constexpr (H0L) {
+    if (h->fold0) {
+      launch_panel_f<WN, RT, H0L, DEEP, CH, FP, true>(h, pa);
+      return;
+    }
+  }
+  launch_panel_f<WN, RT, H0L, DEEP, CH, FP, false>(h, pa);
 }
 
 template <int WN, int RT, bool H0L, int CH = 1, int FP = 64>
@@ -857,7 +883,7 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
     allow_lds(h, &k_featurize<bf16_t>, 160 * 1024, &attr_done);
     hipLaunchKernelGGL((k_featurize<bf16_t>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, h->X, h->stab,
                        h->y, h->scal, h->B, (bf16_t*)h->H0, Bp * h->Fp, (bf16_t*)h->H0t,
-                       (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp, (int32_t)nmem);
+                       (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp, (int32_t)nmem, (int32_t)(h->fold0 ? 2 : 0));
   }
   bool feat_bwd_fused = false;
   PanelArgs pa{};
@@ -881,6 +907,8 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   pa.grad = h->gradf; pa.grad_stride = h->Pf;
   pa.loss = sink.loss; pa.loss_raw = sink.raw; pa.loss_stride = sink.stride; pa.S = h->S;
   pa.loss_scale = sink.scale; pa.lik_c = c; pa.st = sink.st;
+  pa.off_k0 = h->nd.off_kernel[0];
+  pa.dk0_fused = panel_dk0_fused(h) ? 1 : 0;
   // 128-row panels at W = 512 (the feature panel staged in LDS when Fp = 64), 256-row panels at W = 256,
   // 64-row panels with two 64-column slabs per wave at W = 1024
   auto with_fused_featbwd = [&]() {
@@ -1335,6 +1363,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
     h->recompute_a0 = !cfg->forward_only && !h->panel && want == 0 && h->L >= 2 && h->Fp <= 128;
   }
   h->h0l = h->panel && (((h->W == 512 || h->W == 1024) && h->Fp == 64) || (h->W == 256 && (h->Fp == 64 || h->Fp == 128))) && !getenv("BNF_PANEL_NO_H0L");
+  h->fold0 = h->h0l && h->F + 2 <= h->Fp && !(getenv("BNF_PANEL_FOLD0") && atoi(getenv("BNF_PANEL_FOLD0")) == 0);
   if (h->h0l &&
       !(getenv("BNF_PANEL_FEATBWD") && atoi(getenv("BNF_PANEL_FEATBWD")) == 0)) {
     // fused featurisation backward of the H0L panel kernel: what each feature column contributes

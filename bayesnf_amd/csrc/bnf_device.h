@@ -361,6 +361,41 @@ __device__ __forceinline__ ActCore2 act_core2(f32x2 t) {
   c.mxt = f32x2{max_with_zero(t.x), max_with_zero(t.y)};
   return c;
 }
+// act_core2 with min(e, 1) of BOTH elements from one packed multiply carrying the clamp modifier (e >= 0, so
+// clamp(e * 1) to [0, 1] = min(e, 1)): hipcc emits one v_max_f32 ... clamp per element for the builtin form, and there is
+// no packed min.  The asm takes `den` as a dummy input: it is then scheduled after den = e e + 1 was issued, i.e. at least
+// one instruction behind the v_exp_f32 that produced e (an asm statement gets no trans-use wait state from hipcc).
+__device__ __forceinline__ ActCore2 act_core2_pkclamp(f32x2 t) {
+  ActCore2 c;
+  const f32x2 e = {BNF_EXP2(t.x), BNF_EXP2(t.y)};
+  f32x2 den = e * e + 1.f;
+  f32x2 dl;
+  asm("v_pk_mul_f32 %0, %1, 1.0 op_sel_hi:[1,0] clamp" : "=v"(dl) : "v"(e), "v"(den));
+  f32x2 r = {BNF_RCP(den.x), BNF_RCP(den.y)};
+  asm volatile("" : "+v"(r));
+  c.r = r;
+  c.dl = dl;
+  c.mxt = f32x2{max_with_zero(t.x), max_with_zero(t.y)};
+  return c;
+}
+// Forward-only core: r and s = elu(a) + 1 with ONE median per element.  For a > 0: a + 1 <= e^a and a + 1 > 1, for
+// a <= 0: a + 1 <= e^a <= 1 -- so elu(a) + 1 = median(a + 1, e^a, 1) on both sides (the backward epilogues also need
+// dl = min(e, 1) on its own and keep act_core2).  Same values as ln2 max(t, 0) + min(e, 1) up to the 1-ulp rounding of
+// v_exp_f32 next to a = 0; the right limits at +-inf (e = inf: a + 1; e = 0: 0).  Two VALU slots per element pair less.
+struct ActFwd2 {
+  f32x2 r, s;
+};
+__device__ __forceinline__ ActFwd2 act_fwd_core2(f32x2 t) {
+  ActFwd2 c;
+  const f32x2 e = {BNF_EXP2(t.x), BNF_EXP2(t.y)};
+  const f32x2 den = e * e + 1.f;
+  f32x2 r = {BNF_RCP(den.x), BNF_RCP(den.y)};
+  asm volatile("" : "+v"(r));   // see act_core2
+  c.r = r;
+  const f32x2 a1 = kLn2 * t + 1.f;
+  c.s = f32x2{__builtin_amdgcn_fmed3f(a1.x, e.x, 1.0f), __builtin_amdgcn_fmed3f(a1.y, e.y, 1.0f)};
+  return c;
+}
 struct ActConst {
   float alpha, c0, c1, c2;
 };
@@ -382,6 +417,13 @@ __device__ __forceinline__ void store_pair_pk(bf16_t* p0, bf16_t* p1, float a, f
   p0->bits = (uint16_t)(pk & 0xffffu);
   p1->bits = (uint16_t)(pk >> 16);
 }
+
+// four bf16 values (consecutive elements of one row) rounded by two v_cvt_pk_bf16_f32 and stored by ONE 8-byte write
+__device__ __forceinline__ void store_quad_pk(bf16_t* p, float a, float b, float c, float d) {
+  typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<u32x2v*>(p) = u32x2v{cvt_pk_bf16(a, b), cvt_pk_bf16(c, d)};
+}
+__device__ __forceinline__ void store_quad_pk(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 
 template <bool FAST>
 __device__ __forceinline__ ActOut act_eval(float a, float alpha) {
@@ -454,6 +496,24 @@ __device__ __forceinline__ ActOut2 act_eval2(f32x2 a, float alpha) {
 // ---------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)
 // ---------------------------------------------------------------------------
+// Sum over the 64 lanes without LDS traffic: four DPP adds inside each row of 16 lanes (quad swaps, half-row and row
+// mirrors: every lane of a row ends up with the row total), then the four row totals through v_readlane -- ~12 issue
+// slots and no memory latency, against six dependent ds_bpermute round trips (~100+ cycles each) of the shuffle form.
+// Used where a reduction sits on a phase's critical path (the panel kernel's row phase and epilogue tails).
+// The result is wave-uniform.  Summation order differs from wave_sum's (pairwise either way).
+template <int CTRL>
+__device__ __forceinline__ float dpp_src(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_src<0xB1>(v);     // quad_perm [1, 0, 3, 2]
+  v += dpp_src<0x4E>(v);     // quad_perm [2, 3, 0, 1]
+  v += dpp_src<0x141>(v);    // row_half_mirror
+  v += dpp_src<0x140>(v);    // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

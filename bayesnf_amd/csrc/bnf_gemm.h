@@ -89,6 +89,9 @@ struct EpiArgs {
   int32_t S;
   float loss_scale, lik_c;   // lik_c = (N / B) * likelihood scale
   int32_t off_os, off_bias_out, off_lns, off_shape, off_infl, obs;
+  // gemm_tn / gemm_tn_skinny, layer 0 of the panel kernel's F0 forms: row M of the (padded) output -- the ones column of
+  // the feature operand -- is d bias0 (un-scaled), accumulated at grad[off_bias_row + n]
+  int32_t bias_row, off_bias_row;
   unsigned long long* prof;   // -DBNF_ENABLE_ABLATE builds: per-workgroup phase clocks (8 marks)
   int32_t ablate;      // perf experiments only (env BNF_ABLATE): 1 no transposed stores,
                        // 2 no row-major stores, 4 no activation math, 8 no row dot,
@@ -1171,6 +1174,8 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 2 ? 2 : 4) void gemm_tn(const G
           const float v = acc[i][j][r] * ep.scale;
           if (g.splitk > 1) atomicAdd(&out[(int64_t)m * ep.ld_f32 + n], v);
           else out[(int64_t)m * ep.ld_f32 + n] = v;
+        } else if (ep.bias_row && m == g.M) {
+          atomicAdd(&ep.grad[(int64_t)e * ep.grad_stride + ep.off_bias_row + n], acc[i][j][r]);
         }
       }
   }
@@ -1345,6 +1350,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_skinny(const GemmArgs g, const
           const float v = acc[i][j][r] * ep.scale;
           if (g.splitk > 1) atomicAdd(&out[(int64_t)m * ep.ld_f32 + n], v);
           else out[(int64_t)m * ep.ld_f32 + n] = v;
+        } else if (ep.bias_row && m == g.M) {
+          atomicAdd(&ep.grad[(int64_t)e * ep.grad_stride + ep.off_bias_row + n], acc[i][j][r]);
         }
       }
   }

@@ -17,7 +17,8 @@ namespace bnf {
 //   [kScalGroup + g]    softplus(feature-group scale g)  [kScalInput + d]     in_scale[d] * exp(log_scale_adjustment[d])
 constexpr int kScalGroup = BNF_MAX_LAYERS + 2;
 constexpr int kScalInput = kScalGroup + BNF_MAX_GROUPS;
-constexpr int kScalStride = kScalInput + BNF_MAX_INPUTS;
+constexpr int kScalGfac = kScalInput + BNF_MAX_INPUTS;      // [kScalGfac + g] sigmoid(scale_g) / softplus(scale_g): d softplus(x) / dx over the value
+constexpr int kScalStride = kScalGfac + BNF_MAX_GROUPS;
 
 // sin / cos of 2 pi x (x in revolutions), evaluated like the reference: ocml sincosf of the
 // float32 product float32(2 pi) * x.  (The hardware v_sin_f32 / v_cos_f32 were tried for the
@@ -109,7 +110,10 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
     NetDev nd, RowSrc rs, const float* __restrict__ X, const float* __restrict__ Stab,
     const float* __restrict__ y, const float* __restrict__ scal, int64_t B,
     T* __restrict__ H0, int64_t h0_batch, T* __restrict__ H0f, int64_t h0f_batch, int32_t ldt,
-    float* __restrict__ ybat, int64_t ybat_batch, int32_t n_members) {
+    float* __restrict__ ybat, int64_t ybat_batch, int32_t n_members, int32_t n_ones) {
+  // n_ones (0 or 2; the panel kernel's F0 forms): that many feature columns behind the F real ones hold 1.0 -- the
+  // contraction partners of the bias rows in the forward-packed layer-0 weights, and the row of the layer-0 weight
+  // gradient that IS the bias gradient
   // H0f (optional, 2-byte T): a second copy in MFMA A-fragment-major order for the row-panel
   // kernel: element (row r, k) at ((r / 32 * Fp / 16 + k / 16) * 64 + (k % 16) / 8 * 32 + r % 32) * 8 + k % 8,
   // so that the 32-row x 16-deep fragment a wave multiplies is ONE contiguous 1 KiB load (a lane
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
         }
       }
     }
-    for (int c = nd.F; c < nd.Fp; ++c) Elem<T>::store(trow + c, 0.f);  // K padding of the contraction
+    for (int c = nd.F; c < nd.Fp; ++c) Elem<T>::store(trow + c, c < nd.F + n_ones ? 1.f : 0.f);  // K padding of the contraction
     if (ybat) ybat[(int64_t)e * ybat_batch + r] = y ? y[row] : 0.f;
   }
   __syncthreads();
@@ -368,6 +372,7 @@ __device__ __forceinline__ void member_scalars_row(const NetDev& nd, const float
   o[BNF_MAX_LAYERS + 1] = softplusf(th[nd.off_os]);
   for (int g = 0; g < nd.n_groups; ++g) o[kScalGroup + g] = softplusf(th[nd.group_scale_off[g]]);
   for (int d = 0; d < nd.D; ++d) o[kScalInput + d] = nd.in_scale[d] * expf(th[nd.off_lsa + d]);
+  for (int g = 0; g < nd.n_groups; ++g) o[kScalGfac + g] = sigmoidf(th[nd.group_scale_off[g]]) / o[kScalGroup + g];
 }
 __global__ void k_member_scalars(NetDev nd, const float* __restrict__ theta, int64_t stride, int32_t n,
                                  float* __restrict__ scal) {

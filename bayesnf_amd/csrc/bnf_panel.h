@@ -36,6 +36,8 @@
 // bf16 MFMA peak) against 0.41-0.50 for the LDS-staged K loops of gemm_nt.
 #pragma once
 
+#include <type_traits>
+
 #include "bnf_gemm.h"
 #include "bnf_kernels.h"
 
@@ -87,6 +89,9 @@ struct PanelArgs {
   // theta offsets of the BNF_MAX_GROUPS group scales (build_featbwd_meta in bnf_api.hip).
   const int32_t* fbmeta;
   int32_t off_lsa, n_groups, n_inputs, fb_in_group;   // fb_in_group: feature group of the raw inputs
+  // -DBNF_PANEL_DK0=1 builds (experiment, profiles/r04_panel_ab.md): layer 0's weight gradient contracted here from the
+  // dZ0 and feature panels in LDS and accumulated with f32 atomics; dZ0 is then not written and gemm_tn_skinny not run
+  int32_t off_k0, dk0_fused;
 };
 constexpr int kFbNone = 0, kFbInput = 1, kFbFourier = 2, kFbInter = 3;
 
@@ -104,14 +109,24 @@ struct PackJobs {
   int32_t tile0[BNF_MAX_LAYERS + 1];   // tile0[l]: first blockIdx.x of layer l
   void* wf[BNF_MAX_LAYERS]; void* wb[BNF_MAX_LAYERS];
   int64_t batch[BNF_MAX_LAYERS];
+  // fold0 (the panel kernel's F0 forms): layer 0's FORWARD fragments carry gamma0 log2(e) / sqrt F, and the K rows F and
+  // F + 1 hold gamma0 log2(e) b0 split into a bf16 hi and lo part (against the two ones columns of k_featurize)
+  int32_t fold0, F0n, off_bias0, off_ls0;
 };
 // Workgroup 0 of a member also fills the member's row of the transformed-scalar table
 // (k_member_scalars folded in: one launch and one dependent-launch gap less per step).
 // the 8 forward and 8 backward fragments of the 64 x 64 tile of layer l's kernel staged in `tile` (origin k0, n0)
 template <typename T>
 __device__ __forceinline__ void pack_tile_fragments(const float (&tile)[64][65], const PackJobs& jb, int l, int64_t e,
-                                                    int k0, int n0, int tid) {
+                                                    int k0, int n0, int tid, const float* th) {
   const int W = jb.W;
+  const bool fold = jb.fold0 && l == 0;
+  float fs = 1.f, fgb = 0.f;       // forward scale of layer 0's kernel, scale of its bias
+  if (fold) {
+    const float g0 = softplusf(th[jb.off_ls0]);
+    fs = g0 * kLog2e / sqrtf((float)jb.F0n);
+    fgb = g0 * kLog2e;
+  }
   T* wf = (T*)jb.wf[l] + e * jb.batch[l];
   T* wb = (T*)jb.wb[l] + e * jb.batch[l];
   const int KSf = jb.n_pad[l] / 16, KSb = W / 16;
@@ -123,7 +138,16 @@ __device__ __forceinline__ void pack_tile_fragments(const float (&tile)[64][65],
     {  // forward: Bt[n][k] = K[k][n]; fragment (n/32, k/16), lane = n%32 + 32*((k%16)/8)
       const int nl = (frag >> 2) * 32 + (fl & 31), kl = (frag & 3) * 16 + (fl >> 5) * 8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = tile[kl + j][nl];
+      for (int j = 0; j < 8; ++j) v[j] = tile[kl + j][nl] * fs;
+      if (fold && k0 + kl + 8 > jb.F0n && k0 + kl <= jb.F0n + 1) {   // this lane's 8 K rows include a bias row
+        const float gbv = fgb * th[jb.off_bias0 + n0 + nl];
+        const float hi = Elem<bf16_t>::round(gbv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (k0 + kl + j == jb.F0n) v[j] = hi;
+          if (k0 + kl + j == jb.F0n + 1) v[j] = gbv - hi;
+        }
+      }
       const int64_t f = (int64_t)((n0 + nl) / 32) * KSf + (k0 + kl) / 16;
       store8(wf + (f * 64 + fl) * 8, v);
     }
@@ -165,7 +189,7 @@ __global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ t
     for (int j = 0; j < 4; ++j) tile[r][c + j] = v[j];
   }
   __syncthreads();
-  pack_tile_fragments<T>(tile, jb, l, e, k0, n0, tid);
+  pack_tile_fragments<T>(tile, jb, l, e, k0, n0, tid, theta + (int64_t)e * theta_stride);
 }
 
 #ifndef BNF_EPI_FENCE_EVERY
@@ -179,6 +203,32 @@ __global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ t
 #endif
 #ifndef BNF_PANEL_PD
 #define BNF_PANEL_PD 4
+#endif
+// round-4 steps of the panel kernel, each behind its own compile-time switch for same-box A/B builds
+// (profiles/r04_panel_ab.md):
+#ifndef BNF_PANEL_FWDS
+#define BNF_PANEL_FWDS 1     // forward epilogues: elu + 1 as ONE median per element (act_fwd_core2)
+#endif
+#ifndef BNF_PANEL_DPPSUM
+#define BNF_PANEL_DPPSUM 1   // wave-wide sums by DPP + v_readlane instead of six ds_bpermute round trips
+#endif
+#ifndef BNF_PANEL_ZPEEL
+#define BNF_PANEL_ZPEEL 1    // contractions start from a zero C operand (no 128 v_mov per contraction and wave)
+#endif
+#ifndef BNF_PANEL_PRE0
+#define BNF_PANEL_PRE0 0     // (measured: no gain, r04a) layer-0 weights and biases requested BEFORE the barrier that completes the staged feature panel
+#endif
+#ifndef BNF_PANEL_SADDR
+#define BNF_PANEL_SADDR 1    // weight fragments of the W x W contractions: uniform base in SGPRs + the lane's 32-bit offset (no 64-bit VALU address per load)
+#endif
+#ifndef BNF_PANEL_CPRIO
+#define BNF_PANEL_CPRIO 1    // (r04d: -0.4 %) 1: the second-dispatched waves run the contractions at priority 1; 2: the first-dispatched ones do
+#endif
+#ifndef BNF_PANEL_DK0
+#define BNF_PANEL_DK0 0      // experiment: dK_0 = H0^T dZ0 inside the panel kernel (f32 atomics), env BNF_PANEL_DK0=1 at run time
+#endif
+#ifndef BNF_PANEL_PKCLAMP
+#define BNF_PANEL_PKCLAMP 1  // backward epilogues: min(e, 1) of an element pair by one packed multiply with the clamp modifier
 #endif
 constexpr int kPanelPD = BNF_PANEL_PD;       // weight fragments in flight per stream; must divide W / 16 (2: +2 % panel time, 8: equal -- gpurun_out/r03ar)
 
@@ -206,6 +256,21 @@ __device__ __forceinline__ int opaque_lane(int x) {
   return x;
 }
 
+__device__ __forceinline__ ActCore2 panel_act_core2(f32x2 t) {   // the backward epilogues' activation core
+#if BNF_PANEL_PKCLAMP
+  return act_core2_pkclamp(t);
+#else
+  return act_core2(t);
+#endif
+}
+__device__ __forceinline__ float panel_wave_sum(float v) {
+#if BNF_PANEL_DPPSUM
+  return wave_sum_dpp(v);
+#else
+  return wave_sum(v);
+#endif
+}
+
 // workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains
 // vmcnt, i.e. would wait for the panel copies to HBM (128 KiB per workgroup) at every phase change
 __device__ __forceinline__ void lds_barrier() {
@@ -224,34 +289,69 @@ __device__ __forceinline__ void lds_barrier() {
 struct PanelRing {
   bf16x8 fb[kPanelPD][2];
 };
+// One weight fragment (16 bytes per lane) at the wave-uniform address wp + soff, lane offset loff.  BNF_PANEL_SADDR: as a
+// raw buffer load -- the resource (base, in SGPRs) is made once per contraction, the fragment index goes into the scalar
+// offset and the lane offset into the 32-bit VGPR offset: no VALU address arithmetic per load (the flat-pointer form
+// costs a 64-bit v_lshl_add_u64 per load, four VALU slots per k step and wave next to eight MFMAs).
+struct PanelW {
+#if BNF_PANEL_SADDR
+  __amdgpu_buffer_rsrc_t rsrc;
+#endif
+  const char* base;
+};
+__device__ __forceinline__ PanelW panel_wbase(const char* wp) {
+  PanelW w;
+  w.base = wp;
+#if BNF_PANEL_SADDR
+  // raw buffer (stride 0), 2 GiB window, gfx9 DATA_FORMAT = 32 (word 3 = 0x00020000)
+  w.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wp), 0, 0x7fffffff, 0x00020000);
+#endif
+  return w;
+}
+__device__ __forceinline__ bf16x8 panel_wload(const PanelW& w, uint32_t soff, uint32_t loff) {
+#if BNF_PANEL_SADDR
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w.rsrc, loff, soff, 0));
+#else
+  return *reinterpret_cast<const bf16x8*>(w.base + soff + loff);
+#endif
+}
 __device__ __forceinline__ void panel_prefetch(PanelRing& ring, const char* wp, int nt0, int KS, int lane) {
-  const char* w0 = wp + (size_t)nt0 * KS * 1024;   // uniform
-  const char* w1 = w0 + (size_t)KS * 1024;
+  const PanelW w = panel_wbase(wp);
+  const uint32_t o0 = (uint32_t)nt0 * (uint32_t)KS * 1024u, o1 = o0 + (uint32_t)KS * 1024u;   // uniform
   const uint32_t loff = (uint32_t)lane * 16u;
 #pragma unroll
   for (int p = 0; p < kPanelPD; ++p) {
-    ring.fb[p][0] = *reinterpret_cast<const bf16x8*>(w0 + p * 1024 + loff);
-    ring.fb[p][1] = *reinterpret_cast<const bf16x8*>(w1 + p * 1024 + loff);
+    ring.fb[p][0] = panel_wload(w, o0 + p * 1024u, loff);
+    ring.fb[p][1] = panel_wload(w, o1 + p * 1024u, loff);
   }
 }
-template <int KPITCH_B, int RT, typename Side>
+// ZERO: the accumulators are written, not accumulated into -- the first k step's MFMAs take a literal zero C operand
+// (an inline constant), which saves the 16 RT v_mov per slab a zeroed accumulator costs before the first MFMA can issue.
+// SWAP: the operands in swapped roles (weights as A, panel as B): acc[i][j] holds the TRANSPOSED tile -- lane <-> panel
+// row i * 32 + lane % 32, register r <-> column j * 32 + 8 (r / 4) + 4 (lane / 32) + r % 4.
+template <int KPITCH_B, int RT, bool ZERO, bool SWAP, typename Side>
 __device__ __forceinline__ void panel_contract(f32x16 (&acc)[RT][2], const char* prow, const char* wp, int nt0, int KS,
                                                int lane, PanelRing& ring, Side side) {
   constexpr int PD = kPanelPD;
-  const char* w0 = wp + (size_t)nt0 * KS * 1024;   // uniform
-  const char* w1 = w0 + (size_t)KS * 1024;
+  const PanelW w = panel_wbase(wp);
+  const uint32_t o0 = (uint32_t)nt0 * (uint32_t)KS * 1024u, o1 = o0 + (uint32_t)KS * 1024u;   // uniform
   const uint32_t loff = (uint32_t)lane * 16u;
   bf16x8 (&fb)[PD][2] = ring.fb;
+  // rows frow + 32 i: TWO base registers keep every offset inside the 16-bit immediate of ds_read_b128 (the second one made
+  // opaque, or hipcc re-derives it with a v_add_u32 per read -- VALU issue slots next to the MFMAs are what this loop lacks)
+  int hi_off = 64 * KPITCH_B;
+  asm volatile("" : "+v"(hi_off));          // (an opaque OFFSET: an opaque pointer would lose the LDS address space)
+  const char* prow_hi = prow + hi_off;
   auto load_a = [&](bf16x8 (&fa)[RT], int ks) {
     const int ko = ks * 32;
 #pragma unroll
-    for (int i = 0; i < RT; ++i)   // rows frow + 32 i  (two base registers keep the offsets in 16 bits)
-      fa[i] = *reinterpret_cast<const bf16x8*>(prow + (i >> 1) * 64 * KPITCH_B + (i & 1) * 32 * KPITCH_B + ko);
+    for (int i = 0; i < RT; ++i)
+      fa[i] = *reinterpret_cast<const bf16x8*>(((i >> 1) ? prow_hi : prow) + (i & 1) * 32 * KPITCH_B + ko);
   };
   bf16x8 fa[2][RT];
   load_a(fa[0], 0);
-#pragma unroll 1
-  for (int ks0 = 0; ks0 < KS; ks0 += PD) {
+  auto group = [&](int ks0, auto first_tag) {
+    constexpr bool kFirst = decltype(first_tag)::value;
     side(ks0 / PD);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -260,16 +360,31 @@ __device__ __forceinline__ void panel_contract(f32x16 (&acc)[RT][2], const char*
       load_a(fa[cur ^ 1], min(ks0 + p + 1, KS - 1));
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[p][0], acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[p][1], acc[i][1], 0, 0, 0);
+        if constexpr (kFirst) {
+          if (p == 0) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[i][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[p][0], fa[cur][i], z, 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[p][0], z, 0, 0, 0);
+            acc[i][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[p][1], fa[cur][i], z, 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[p][1], z, 0, 0, 0);
+            continue;
+          }
+        }
+        acc[i][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[p][0], fa[cur][i], acc[i][0], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[p][0], acc[i][0], 0, 0, 0);
+        acc[i][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[p][1], fa[cur][i], acc[i][1], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[p][1], acc[i][1], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       const int kn = min(ks0 + PD + p, KS - 1);    // (the tail re-reads the last fragment: unused)
-      fb[p][0] = *reinterpret_cast<const bf16x8*>(w0 + (size_t)kn * 1024 + loff);
-      fb[p][1] = *reinterpret_cast<const bf16x8*>(w1 + (size_t)kn * 1024 + loff);
+      fb[p][0] = panel_wload(w, o0 + (uint32_t)kn * 1024u, loff);
+      fb[p][1] = panel_wload(w, o1 + (uint32_t)kn * 1024u, loff);
       __builtin_amdgcn_sched_barrier(0);
     }
-  }
+  };
+  if constexpr (ZERO) group(0, std::true_type{});
+#pragma unroll 1
+  for (int ks0 = ZERO ? PD : 0; ks0 < KS; ks0 += PD) group(ks0, std::false_type{});
 }
 
 // Layer-0 contraction of one 32-row block x this wave's 64 columns, both operands from global
@@ -307,8 +422,16 @@ __device__ __forceinline__ void l0_mma(f32x16& a0, const L0Blk& bk) {
 // variant: 8 waves x 2 x 64 columns, 64-row panels so that the panel still fits in LDS; twice the weight stream per
 // MFMA of the 128-row form).
 // FP: padded feature count the H0L code is compiled for (64; 128 = the W = 256 form: 128-row panels, two row blocks).
-template <int WN, int RT, bool H0L, bool DEEP = false, int CH = 1, int FP = 64>
+// F0 (needs H0L; round 4): layer 0's scale and bias are FOLDED into its contraction -- the forward-packed weights carry
+// gamma0 log2(e) / sqrt F and two extra K rows hold the bias (bf16 hi + lo) against two columns of ones that
+// k_featurize writes behind the F features (needs F + 2 <= FP) -- so t0 = A0 log2(e) IS the accumulator, in the forward
+// pass and in the backward recomputation, and d bias0 comes out of the layer-0 weight-gradient kernel as the row of
+// the ones column.  With no per-column constant left in the two layer-0 epilogues, both run with the MFMA operand
+// roles SWAPPED (weights as A, panel rows as B): a lane then owns ONE row and four consecutive hidden units per
+// register group, and the bf16 panel store is one ds_write_b64 per four elements instead of four ds_write_b16.
+template <int WN, int RT, bool H0L, bool DEEP = false, int CH = 1, int FP = 64, bool F0 = false>
 __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
+  static_assert(!F0 || H0L, "the folded layer 0 needs the LDS feature panel");
   constexpr int W = 64 * WN * CH, RB = 8 / WN, WR = 32 * RT, BM = WR * RB;   // WR = rows per wave
   constexpr int kSlabs = WN * CH;           // 64-column slabs of the layer
   constexpr int kPitchE = W + 8;            // panel row pitch, elements (16 bytes of padding)
@@ -379,9 +502,9 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   float g_fac = 0.f; int32_t g_off = 0;
   if constexpr (H0L) {
     if (tid < BNF_MAX_GROUPS + BNF_MAX_INPUTS) s_grp[tid] = 0.f;   // (ordered by the barriers of the phases below)
-    if (a.fbmeta && tid < a.n_groups) {
-      g_off = a.fbmeta[4 * FP + tid];
-      g_fac = sigmoidf(th[g_off]) / sc[kScalGroup + tid];
+    if (a.fbmeta && tid < a.n_groups) {   // two INDEPENDENT loads (the factor from the member's scalar table: a dependent
+      g_off = a.fbmeta[4 * FP + tid];     // th[g_off] here cost wave 0 a memory latency in front of its feature staging)
+      g_fac = sc[kScalGfac + tid];
     }
   }
   // fragment-major features: the fragment of (32-row block, k step) is 1 KiB, blocks are Fp/16 KiB apart
@@ -435,17 +558,6 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
     }
   };
 
-  if constexpr (H0L) {   // feature panel -> LDS (row-major source, 16-byte chunks, 8 per row)
-    const bf16_t* src = a.H0rm + (int64_t)e * a.h0_batch + (int64_t)m0 * FP;
-    constexpr int kCpr = FP / 8;              // 16-byte chunks per feature row
-#pragma unroll
-    for (int c = 0; c < (BNF_ABL(a, 32) ? 0 : (BM * kCpr) / 512); ++c) {
-      const int q = tid + c * 512;
-      *reinterpret_cast<u32x4*>(const_cast<char*>(h0s) + (q / kCpr) * kH0Pitch + (q % kCpr) * 16) =
-          *reinterpret_cast<const u32x4*>(src + (int64_t)(q / kCpr) * FP + (q % kCpr) * 8);
-    }
-  }
-  BNF_MARK(a, 0);
   f32x16 accs[CH][RT][2];   // [slab][row tile][column tile]; the phases below see one slab at a time as `acc`
   auto zero_acc = [&]() {
 #pragma unroll
@@ -494,8 +606,11 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) fa[u] = *reinterpret_cast<const bf16x8*>(ap + (u0 + u) * 32);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u], bres[j ? (H0L ? 1 : 0) : 0][H0L ? u0 + u : 0], a0, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+          const bf16x8 fw = bres[j ? (H0L ? 1 : 0) : 0][H0L ? u0 + u : 0];
+          a0 = F0 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fa[u], a0, 0, 0, 0)      // transposed tile (see F0)
+                  : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u], fw, a0, 0, 0, 0);
+        }
       }
       return;
     }
@@ -514,19 +629,64 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   };
 
   // =============================== layer 0 forward -> H1 panel ===============================
+  // (BNF_PANEL_PRE0) slab 0's layer-0 weight fragments and biases do not depend on the staged features: requested before
+  // the barrier, their L2 latency runs under the feature panel's HBM latency instead of behind it
+  constexpr bool kPre0 = BNF_PANEL_PRE0 != 0 && H0L;
+  const LaneCtx Lpre = lane_ctx(0);
+  float gb_pre[2] = {0.f, 0.f};
+  if constexpr (kPre0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) gb_pre[j] = th[a.off_bias[0] + slab(0) * 64 + j * 32 + Lpre.frow];
+    l0_weights(Lpre);
+  }
+  if constexpr (H0L) {   // feature panel -> LDS (row-major source, 16-byte chunks, 8 per row)
+    const bf16_t* src = a.H0rm + (int64_t)e * a.h0_batch + (int64_t)m0 * FP;
+    constexpr int kCpr = FP / 8;              // 16-byte chunks per feature row
+#pragma unroll
+    for (int c = 0; c < (BNF_ABL(a, 32) ? 0 : (BM * kCpr) / 512); ++c) {
+      const int q = tid + c * 512;
+      *reinterpret_cast<u32x4*>(const_cast<char*>(h0s) + (q / kCpr) * kH0Pitch + (q % kCpr) * 16) =
+          *reinterpret_cast<const u32x4*>(src + (int64_t)(q / kCpr) * FP + (q % kCpr) * 8);
+    }
+  }
+  BNF_MARK(a, 0);
   if constexpr (H0L) lds_barrier();     // the staged feature panel is complete
 #pragma unroll
   for (int hc = 0; hc < CH; ++hc) {
     const int cbase = slab(hc) * 64;
-    const LaneCtx L = lane_ctx(hc);
+    const LaneCtx L = (kPre0 && hc == 0) ? Lpre : lane_ctx(hc);
     const int frow = L.frow, kg = L.kg;
     const float gs = gamma0 * inv_sf * kLog2e;     // t = A0 log2(e): the activation core works on it (act_core2)
     float gb[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) gb[j] = BNF_ABL(a, 64) ? 0.1f : gamma0 * kLog2e * th[a.off_bias[0] + cbase + j * 32 + frow];
-    if (!BNF_ABL(a, 64)) l0_weights(L);
+    for (int j = 0; j < 2; ++j)
+      gb[j] = BNF_ABL(a, 64) ? 0.1f : gamma0 * kLog2e * ((kPre0 && hc == 0) ? gb_pre[j] : th[a.off_bias[0] + cbase + j * 32 + frow]);
+    if (!BNF_ABL(a, 64) && !(kPre0 && hc == 0)) l0_weights(L);
     // epilogue of one 32 x 32 tile: t = A0 log2(e) -> H1 = act(A0) -> LDS panel
     auto l0_epilogue = [&](const f32x16& a0, int i, int j) {
+      if constexpr (F0) {
+        // transposed tile, scale and bias already inside: lane <-> row, registers 4 rg .. 4 rg + 3 <-> four consecutive
+        // hidden units: one 8-byte panel store per register group
+        bf16_t* rowp = tile + (rbase + i * 32 + frow) * kPitchE + cbase + j * 32 + 4 * kg;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          f32x2 hq[2];
+#pragma unroll
+          for (int q = 0; q < 4; q += 2) {
+            const f32x2 tv = {a0[rg * 4 + q], a0[rg * 4 + q + 1]};
+#if BNF_PANEL_FWDS
+            const ActFwd2 c = act_fwd_core2(tv);
+            hq[q >> 1] = ak.c1 * c.r + (ak.alpha * c.s + ak.c0);
+#else
+            const ActCore2 c = act_core2(tv);
+            const f32x2 s = kLn2 * c.mxt + c.dl;
+            hq[q >> 1] = ak.c1 * c.r + (ak.alpha * s + ak.c0);
+#endif
+          }
+          store_quad_pk(rowp + 8 * rg, hq[0].x, hq[0].y, hq[1].x, hq[1].y);
+        }
+        return;
+      }
       const int lc = cbase + j * 32 + frow;
       const float gbj = j ? gb[1] : gb[0];
 #pragma unroll
@@ -537,9 +697,14 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
           const f32x2 tv = f32x2{a0[rg * 4 + q], a0[rg * 4 + q + 1]} * gs + gbj;
           f32x2 h = tv;
           if (!BNF_ABL(a, 2)) {
+#if BNF_PANEL_FWDS
+            const ActFwd2 c = act_fwd_core2(tv);
+            h = ak.c1 * c.r + (ak.alpha * c.s + ak.c0);
+#else
             const ActCore2 c = act_core2(tv);
             const f32x2 s = kLn2 * c.mxt + c.dl;
             h = ak.c1 * c.r + (ak.alpha * s + ak.c0);
+#endif
           }
           if (!BNF_ABL(a, 4)) store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, h.x, h.y);
         }
@@ -587,12 +752,20 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
 #pragma unroll
     for (int hc = 0; hc < CH; ++hc) panel_prefetch(ring[hc], wp, 2 * slab(hc), KS1, lane);
   };
-  auto contract_all = [&](const char* wp) {              // accs[hc] += panel . W[:, slab hc] for every slab
+  auto contract_all_t = [&](const char* wp, auto swap_tag) {   // accs[hc] (+)= panel . W[:, slab hc] for every slab
     const LaneCtx L = lane_ctx();
+#if BNF_PANEL_CPRIO
+    if ((BNF_PANEL_CPRIO == 1) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int hc = 0; hc < CH; ++hc)
-      panel_contract<kPitchB, RT>(accs[hc], L.prow, wp, 2 * slab(hc), KS1, L.lane, ring[hc], [](int) {});
+      panel_contract<kPitchB, RT, BNF_PANEL_ZPEEL != 0, decltype(swap_tag)::value>(accs[hc], L.prow, wp, 2 * slab(hc), KS1, L.lane,
+                                                                                  ring[hc], [](int) {});
+#if BNF_PANEL_CPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
+  auto contract_all = [&](const char* wp) { contract_all_t(wp, std::false_type{}); };
   ring_prefetch(wfl(1), opaque_lane(tid) & 63);   // in flight across the barrier
   lds_barrier();
   BNF_MARK(a, 2);
@@ -609,7 +782,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   // both directions are whole 1 KiB wave accesses (the layer pipeline stores A_l^T, same rounding).
 #pragma unroll 1
   for (int l = 1; DEEP && l < LL; ++l) {
-    zero_acc();
+    if (!BNF_PANEL_ZPEEL) zero_acc();
     contract_all(wfl(l));
     lds_barrier();
 #pragma unroll
@@ -637,8 +810,13 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
             for (int q = 0; q < 4; q += 2) {
               const f32x2 tv = f32x2{acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]} * gs + gb[j];
               pw[rg * 2 + (q >> 1)] = pack_bf16x2(tv.x, tv.y);
+#if BNF_PANEL_FWDS
+              const ActFwd2 c = act_fwd_core2(tv);
+              const f32x2 s = c.s;
+#else
               const ActCore2 c = act_core2(tv);
               const f32x2 s = kLn2 * c.mxt + c.dl;
+#endif
               const f32x2 h = ak.c1 * c.r + (ak.alpha * s + ak.c0);
               store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, h.x, h.y);
             }
@@ -657,7 +835,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   }
 
   // =============================== last hidden layer forward ==================================
-  zero_acc();
+  if (!BNF_PANEL_ZPEEL) zero_acc();
   contract_all(wfl(LL));
   BNF_MARK(a, 3);
   lds_barrier();     // every wave is done reading H1: the panel doubles as row-dot scratch below
@@ -682,7 +860,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
       ka[j] = kov * ak.alpha; kc1[j] = kov * ak.c1;
       ksum += kov;
     }
-    ksum = wave_sum(kg == 0 ? ksum : 0.f);           // sum of k_o over this slab's 64 columns
+    ksum = panel_wave_sum(kg == 0 ? ksum : 0.f);           // sum of k_o over this slab's 64 columns
     ksum_wave += ksum;
     if (hc == CH - 1 && lane == 0) s_sc[48 + wave] = ksum_wave;   // (read by thread 0 after the barriers below)
     ksum *= ak.c0;
@@ -703,8 +881,13 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
               const f32x2 tv = raw * gs + gb[j];
               acc[i][j][rg * 4 + q] = tv.x;
               acc[i][j][rg * 4 + q + 1] = tv.y;
+#if BNF_PANEL_FWDS
+              const ActFwd2 c = act_fwd_core2(tv);
+              const f32x2 s = c.s;
+#else
               const ActCore2 c = act_core2(tv);
               const f32x2 s = kLn2 * c.mxt + c.dl;
+#endif
               f32x2 pq = {pd[q], pd[q + 1]};
               pq = ka[j] * s + pq;
               pq = kc1[j] * c.r + pq;
@@ -729,6 +912,23 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   }
   BNF_MARK(a, 4);
   lds_barrier();
+  // the panel's scalar sums of the row phase (thread 0): loss and the gradients of the output-layer scalars
+  float dv_all = 0.f;   // thread 0: sum of d loss / d v over the panel's rows
+  auto row_scalars_out = [&]() {
+    float u[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w2 = 0; w2 < (BM + 63) / 64; ++w2)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) u[i] += s_sc[w2 * 5 + i];
+    dv_all = u[2];
+    const float step_loss = -a.lik_c * u[0];
+    atomicAdd(&a.loss[(int64_t)(e / a.S) * a.loss_stride + (a.st ? a.st->col : 0)], a.loss_scale * step_loss);
+    if (a.loss_raw) atomicAdd(&a.loss_raw[e], step_loss);
+    atomicAdd(&gr[a.off_os], dgam_o * u[1]);
+    atomicAdd(&gr[a.off_bias_out], u[2]);
+    atomicAdd(&gr[a.obs == BNF_OBS_NORMAL ? a.off_lns : a.off_shape], u[3]);
+    if (a.obs == BNF_OBS_ZINB) atomicAdd(&gr[a.off_infl], u[4]);
+  };
   // ---- one thread per row: output, likelihood, d out (models.py:269-273,157-191) -----------
   {
     float ll = 0.f, s_doutv = 0.f, s_dvsum = 0.f, s_par = 0.f, s_infl = 0.f;
@@ -758,8 +958,8 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
         s_dvsum = dvv;
       }
       s_dv[tid] = dvv;
-      const float t0 = wave_sum(ll), t1 = wave_sum(s_doutv), t2 = wave_sum(s_dvsum), t3 = wave_sum(s_par),
-                  t4 = wave_sum(s_infl);
+      const float t0 = panel_wave_sum(ll), t1 = panel_wave_sum(s_doutv), t2 = panel_wave_sum(s_dvsum), t3 = panel_wave_sum(s_par),
+                  t4 = panel_wave_sum(s_infl);
       if ((tid & 63) == 0) {
         float* q = s_sc + wave * 5;
         q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; q[4] = t4;
@@ -768,22 +968,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   }
   lds_barrier();
   BNF_MARK(a, 5);
-  float dv_all = 0.f;   // thread 0: sum of d loss / d v over the panel's rows
-  if (tid == 0) {
-    float u[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w2 = 0; w2 < (BM + 63) / 64; ++w2)
-#pragma unroll
-      for (int i = 0; i < 5; ++i) u[i] += s_sc[w2 * 5 + i];
-    dv_all = u[2];
-    const float step_loss = -a.lik_c * u[0];
-    atomicAdd(&a.loss[(int64_t)(e / a.S) * a.loss_stride + (a.st ? a.st->col : 0)], a.loss_scale * step_loss);
-    if (a.loss_raw) atomicAdd(&a.loss_raw[e], step_loss);
-    atomicAdd(&gr[a.off_os], dgam_o * u[1]);
-    atomicAdd(&gr[a.off_bias_out], u[2]);
-    atomicAdd(&gr[a.obs == BNF_OBS_NORMAL ? a.off_lns : a.off_shape], u[3]);
-    if (a.obs == BNF_OBS_ZINB) atomicAdd(&gr[a.off_infl], u[4]);
-  }
+  if (tid == 0) row_scalars_out();
   // ---- dZ1 = gamma1 (dv k_o / sqrt W) act'(A1) -> panel; column sums and scalar gradients ----
   float wsa_all = 0.f, wsg_all = 0.f;
 #pragma unroll
@@ -792,14 +977,17 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
     f32x16 (&acc)[RT][2] = accs[hc];
     const LaneCtx L = lane_ctx();
     const int lane = L.lane, frow = L.frow, kg = L.kg;
-    f32x2 sa[2], sg[2], cp[2], ck[2];
+    f32x2 cr[2], sg[2], cp[2], cs[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) sa[j] = sg[j] = cp[j] = ck[j] = f32x2{0.f, 0.f};
+    for (int j = 0; j < 2; ++j) cr[j] = sg[j] = cp[j] = cs[j] = f32x2{0.f, 0.f};
     // With dZ1 = z = dv (gamma1 k_o / sqrt W) act'(A1) formed directly (the column factor folded into the
     // constants of act'), the sums kept per column half are
-    //   sa = sum dv (elu - tanh + 2)   (the "+ 2" leaves as  -2 (sum_c k_o / sqrt W)(sum_r dv)  by thread 0)
+    //   cr = sum dv r,  cs = sum dv s   (r = 1 / (1 + e^2), s = elu + 1): BOTH other column quantities follow from them --
+    //        sum dv (elu - tanh + 2) = 2 cr + cs   (the "+ 2" leaves as  -2 (sum_c k_o / sqrt W)(sum_r dv)  by thread 0)
+    //        d k_o sqrt W = sum act(A1) dv = c0 sum dv + c1 cr + alpha cs   (act = c0 + c1 r + alpha s)
+    //      -- two accumulations per element pair where forming act and 2 r + s first took five (round 4)
     //   sg = sum z t1                  (d gamma1 ~ sum dA A = (ln 2 / gamma1) sum z t1)
-    //   cp = sum z  (= d bias1),       ck = sum act(A1) dv  (= d k_o sqrt W)
+    //   cp = sum z  (= d bias1)
     const float kvn[2] = {th[a.off_ko + cbase + frow] * inv_sw, th[a.off_ko + cbase + 32 + frow] * inv_sw};
     const float gka[2] = {gamma1 * kvn[0] * ak.alpha, gamma1 * kvn[1] * ak.alpha};
     const float gkc[2] = {gamma1 * kvn[0] * ak.c2, gamma1 * kvn[1] * ak.c2};
@@ -817,39 +1005,43 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
             f32x2 tv = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
             asm volatile("" : "+v"(tv));
             const f32x2 dv2 = {dv4[q], dv4[q + 1]};
-            const ActCore2 c = act_core2(tv);
+            const ActCore2 c = panel_act_core2(tv);
             const f32x2 s = kLn2 * c.mxt + c.dl;
-            const f32x2 h = ak.c1 * c.r + (ak.alpha * s + ak.c0);
             const f32x2 dg = gkc[j] * (c.r - c.r * c.r) + gka[j] * c.dl;
             const f32x2 z = dv2 * dg;
-            sa[j] += dv2 * (2.f * c.r + s);
+            cr[j] += dv2 * c.r;
+            cs[j] += dv2 * s;
             sg[j] += z * tv;
             cp[j] += z;
-            ck[j] += h * dv2;
             store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, z.x, z.y);
           }
         }
-        asm volatile("" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sg[0]), "+v"(sg[1]), "+v"(cp[0]), "+v"(cp[1]),
-                     "+v"(ck[0]), "+v"(ck[1]));
+        asm volatile("" : "+v"(cr[0]), "+v"(cr[1]), "+v"(sg[0]), "+v"(sg[1]), "+v"(cp[0]), "+v"(cp[1]),
+                     "+v"(cs[0]), "+v"(cs[1]));
         if (BNF_EPI_FENCE_EVERY == 1 || (rg & 1)) __builtin_amdgcn_sched_barrier(0);
         if (rg == 1 && i > 0) block_to_global(L, a.dZ[LL], i - 1, cbase);   // (deferred: see the layer-0 forward)
       }
     block_to_global(L, a.dZ[LL], RT - 1, cbase);
     if (hc == CH - 1) ring_prefetch(wbl(LL), lane);   // the accumulators are dead: weights of dH = dZ K^T on their way
-    float wsa = kvn[0] * (sa[0].x + sa[0].y) + kvn[1] * (sa[1].x + sa[1].y);
+    const float crj[2] = {cr[0].x + cr[0].y, cr[1].x + cr[1].y}, csj[2] = {cs[0].x + cs[0].y, cs[1].x + cs[1].y};
+    float wsa = kvn[0] * (2.f * crj[0] + csj[0]) + kvn[1] * (2.f * crj[1] + csj[1]);
     float wsg = (kLn2 / gamma1) * ((sg[0].x + sg[0].y) + (sg[1].x + sg[1].y));
+    float dv_rows = 0.f;     // sum of dv over this wave's WR rows: the row phase's per-wave sums (64 rows each)
+#pragma unroll
+    for (int w2 = 0; w2 < (WR + 63) / 64; ++w2) dv_rows += s_sc[(rbase / 64 + w2) * 5 + 2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      float b = cp[j].x + cp[j].y, k = ck[j].x + ck[j].y;
+      float b = cp[j].x + cp[j].y, k = ak.c1 * crj[j] + ak.alpha * csj[j];
       b += __shfl_xor(b, 32, 64);
       k += __shfl_xor(k, 32, 64);
+      k += ak.c0 * dv_rows;
       if (lane < 32) {
         s_col[rb * W + cbase + j * 32 + lane] = b;
         s_col[(RB + rb) * W + cbase + j * 32 + lane] = k;
       }
     }
-    wsa_all += wave_sum(wsa);
-    wsg_all += wave_sum(wsg);
+    wsa_all += panel_wave_sum(wsa);
+    wsg_all += panel_wave_sum(wsg);
     if (hc == CH - 1 && lane == 0) {
       s_sc[32 + wave * 2] = wsa_all;
       s_sc[33 + wave * 2] = wsg_all;
@@ -887,7 +1079,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   // dZ_l = gamma_l (dH_{l+1} / sqrt W) act'(A_l) with t_l read back from where this wave parked it
 #pragma unroll 1
   for (int l = LL - 1; DEEP && l >= 1; --l) {
-    zero_acc();
+    if (!BNF_PANEL_ZPEEL) zero_acc();
     contract_all(wbl(l + 1));
     const LaneCtx L = lane_ctx();
     const int lane = L.lane, frow = L.frow, kg = L.kg;
@@ -925,7 +1117,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
               const uint32_t w = cur[rg >> 1][(rg & 1) * 2 + (q >> 1)];
               const f32x2 tv = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
               const f32x2 raw = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
-              const ActCore2 c = act_core2(tv);
+              const ActCore2 c = panel_act_core2(tv);
               const f32x2 s = kLn2 * c.mxt + c.dl;
               const f32x2 dg = gzc * (c.r - c.r * c.r) + gza * c.dl;
               const f32x2 z = raw * dg;
@@ -949,8 +1141,8 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
         c += __shfl_xor(c, 32, 64);
         if (lane < 32) s_col[rb * W + cbase + j * 32 + lane] = c;
       }
-      sa_all += wave_sum(inv_sw * ((sa2.x + sa2.y) - 2.f * (sacc.x + sacc.y)));
-      sg_all += wave_sum((kLn2 / gl) * (sg2.x + sg2.y));
+      sa_all += panel_wave_sum(inv_sw * ((sa2.x + sa2.y) - 2.f * (sacc.x + sacc.y)));
+      sg_all += panel_wave_sum((kLn2 / gl) * (sg2.x + sg2.y));
       if (hc == CH - 1 && lane == 0) {
         s_sc[32 + wave * 2] = sa_all;
         s_sc[33 + wave * 2] = sg_all;
@@ -977,8 +1169,8 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
 
   // =============================== dH1 = dZ1 K1^T ============================================
   BNF_MARK(a, 7);
-  zero_acc();
-  contract_all(wbl(1));
+  if (!BNF_PANEL_ZPEEL) zero_acc();
+  contract_all_t(wbl(1), std::integral_constant<bool, F0>{});   // (F0: transposed accumulators for the swapped dZ0 epilogue)
   BNF_MARK(a, 8);
   const LaneCtx L2 = lane_ctx(0);
   l0_weights(L2);                         // first operands of the A0 recomputation, in flight across the barrier
@@ -1021,6 +1213,37 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
             for (int r = 0; r < 16; ++r) a0[r] = 0.25f;
           }
         }
+        if constexpr (F0) {
+          // transposed tiles (dH1 from the swapped contraction, t0 from the swapped recomputation, scale and bias
+          // inside): lane <-> row, four consecutive hidden units per register group -> one 8-byte store; no column sums
+          // (d bias0 is the ones row of the layer-0 weight gradient)
+          bf16_t* rowp = tile + (rbase + i * 32 + frow) * kPitchE + cbase + j * 32 + 4 * kg;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            f32x2 zq[2];
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+              const f32x2 raw = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
+              const f32x2 tv = {a0[rg * 4 + q], a0[rg * 4 + q + 1]};
+              f32x2 z = raw;
+              if (!BNF_ABL(a, 2)) {
+                const ActCore2 c = panel_act_core2(tv);
+                const f32x2 s = kLn2 * c.mxt + c.dl;
+                const f32x2 dg = gzc * (c.r - c.r * c.r) + gza * c.dl;
+                z = raw * dg;
+                sa2 += raw * (2.f * c.r + s);
+              }
+              sacc += raw;
+              sg2 += z * tv;
+              zq[q >> 1] = z;
+            }
+            if (!BNF_ABL(a, 4)) store_quad_pk(rowp + 8 * rg, zq[0].x, zq[0].y, zq[1].x, zq[1].y);
+            asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(sacc));
+            if (BNF_EPI_FENCE_EVERY == 1 || (rg & 1)) __builtin_amdgcn_sched_barrier(0);
+          }
+          if (j == 0 && i > 0 && !(BNF_PANEL_DK0 && a.dk0_fused)) block_to_global(L, a.dZ[0], i - 1, cbase);
+          continue;
+        }
         const int lc = cbase + j * 32 + frow;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
@@ -1031,7 +1254,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
             const f32x2 tv = f32x2{a0[rg * 4 + q], a0[rg * 4 + q + 1]} * gs0 + gb0[j];
             f32x2 z = raw;
             if (!BNF_ABL(a, 2)) {
-              const ActCore2 c = act_core2(tv);
+              const ActCore2 c = panel_act_core2(tv);
               const f32x2 s = kLn2 * c.mxt + c.dl;
               const f32x2 dg = gzc * (c.r - c.r * c.r) + gza * c.dl;
               z = raw * dg;
@@ -1045,19 +1268,21 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
           asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(sacc), "+v"(cs2[0]), "+v"(cs2[1]));
           if (BNF_EPI_FENCE_EVERY == 1 || (rg & 1)) __builtin_amdgcn_sched_barrier(0);
         }
-        if (j == 0 && i > 0) block_to_global(L, a.dZ[0], i - 1, cbase);   // (deferred: see the layer-0 forward)
+        if (j == 0 && i > 0 && !(BNF_PANEL_DK0 && a.dk0_fused)) block_to_global(L, a.dZ[0], i - 1, cbase);   // (deferred: see the layer-0 forward)
       }
     }
-    block_to_global(L, a.dZ[0], RT - 1, cbase);
+    if (!(BNF_PANEL_DK0 && a.dk0_fused)) block_to_global(L, a.dZ[0], RT - 1, cbase);
     BNF_MARK(a, 9);
+    if constexpr (!F0) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float c = cs2[j].x + cs2[j].y;
-      c += __shfl_xor(c, 32, 64);
-      if (lane < 32) s_col[rb * W + cbase + j * 32 + lane] = c;
+      for (int j = 0; j < 2; ++j) {
+        float c = cs2[j].x + cs2[j].y;
+        c += __shfl_xor(c, 32, 64);
+        if (lane < 32) s_col[rb * W + cbase + j * 32 + lane] = c;
+      }
     }
-    sa0_all += wave_sum(inv_sw * ((sa2.x + sa2.y) - 2.f * (sacc.x + sacc.y)));
-    sg0_all += wave_sum((kLn2 / gamma0) * (sg2.x + sg2.y));
+    sa0_all += panel_wave_sum(inv_sw * ((sa2.x + sa2.y) - 2.f * (sacc.x + sacc.y)));
+    sg0_all += panel_wave_sum((kLn2 / gamma0) * (sg2.x + sg2.y));
     if (hc == CH - 1 && lane == 0) {
       s_sc[32 + wave * 2] = sa0_all;
       s_sc[33 + wave * 2] = sg0_all;
@@ -1095,11 +1320,13 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
     lds_barrier();
     // the column sums and scalars of the dZ0 epilogue are complete: their atomics leave now, under the
     // contraction below, instead of in a serial tail after it
-    for (int c = tid; c < W; c += 512) {
-      float b = 0.f;
+    if constexpr (!F0) {
+      for (int c = tid; c < W; c += 512) {
+        float b = 0.f;
 #pragma unroll
-      for (int r = 0; r < RB; ++r) b += s_col[r * W + c];
-      atomicAdd(&gr[a.off_bias[0] + c], b);
+        for (int r = 0; r < RB; ++r) b += s_col[r * W + c];
+        atomicAdd(&gr[a.off_bias[0] + c], b);
+      }
     }
     if (tid == 0) {
       float ta = ta1, tg = 0.f;
@@ -1168,6 +1395,65 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
                (c0[rg * 4 + 2] + c1[rg * 4 + 2]) * inv_sf, (c0[rg * 4 + 3] + c1[rg * 4 + 3]) * inv_sf);
     }
   }
+#if BNF_PANEL_DK0
+  // ---- experiment: dK_0[f][c] += sum_r H0[r][f] dZ0[r][c] / sqrt F for this wave's 64 columns (both panels in LDS) ----
+  // 2 x 2 MFMA tiles (features x columns), K = the panel's BM rows; fragments by ds_read_b64_tr_b16 as in gemm_tn
+  // (within a 16-lane group lane i receives element i % 4 of the 8-byte datum addressed by lane 4 j + i / 4).
+  if constexpr (H0L && CH == 1 && FP == 64 && RB == 1) {
+    if (a.dk0_fused) {
+      const int lane = opaque_lane(tid) & 63;
+      const int kg = lane >> 5, frow = lane & 31, p = lane & 15, half = (lane >> 4) & 1;
+      const int prow = p >> 2, pcol = half * 16 + (p & 3) * 4;
+      const int cbase = slab(0) * 64;
+      typedef __attribute__((address_space(3))) char lds_char_t;
+      const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char_t*)smem;
+      const uint32_t h0o = lds0 + (uint32_t)(h0s - smem);
+      f32x16 dk[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dk[i][j][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < BM / 16; ++ks) {
+        u32x2_t ra[2][2], rb[2][2];   // [t][tile]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int row = ks * 16 + kg * 8 + t * 4 + prow;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            ra[t][i] = lds_tr16_b64<0>(h0o + (uint32_t)(row * kH0Pitch + (i * 32 + pcol) * 2));
+            rb[t][i] = lds_tr16_b64<0>(lds0 + (uint32_t)(row * kPitchB + (cbase + i * 32 + pcol) * 2));
+          }
+        }
+        lds_tr_fence(ra, rb);
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const u32x4 wa = {ra[0][i].x, ra[0][i].y, ra[1][i].x, ra[1][i].y};
+          const u32x4 wb = {rb[0][i].x, rb[0][i].y, rb[1][i].x, rb[1][i].y};
+          fa[i] = __builtin_bit_cast(bf16x8, wa);
+          fb[i] = __builtin_bit_cast(bf16x8, wb);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) dk[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], dk[i][j], 0, 0, 0);
+      }
+      float* out = gr + a.off_k0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int f = i * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+            if (f < a.F) atomicAdd(&out[(int64_t)f * W + cbase + j * 32 + frow], dk[i][j][r] * inv_sf);
+          }
+    }
+  }
+#endif
   BNF_MARK(a, 11);
   if constexpr (H0L) {
     if (a.fbmeta) {
