@@ -1197,6 +1197,24 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 2 ? 2 : 4) void gemm_tn(const G
 // prefetched stages into load -> wait -> compute (seen in the ISA; plain ds_read_b128 loads in gemm_nt
 // do not get that wait).  The caller orders them itself: counted vmcnt + s_barrier before, lds_tr_fence after.
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+#ifndef BNF_TN_BUFDMA
+#define BNF_TN_BUFDMA 1   // LDS-DMA of the ring / skinny weight-gradient kernels as raw BUFFER loads (round 4, r04f)
+#endif
+// One 1 KiB wave load global -> LDS (16 bytes per lane) from the wave-uniform address `p` + the lane's 32-bit offset.
+// BNF_TN_BUFDMA: `buffer_load_dwordx4 v_off, s[rsrc] ... lds` -- the uniform pointer becomes the resource's base (SALU), the
+// lane offset the VGPR offset: no VALU instruction per load (the global_load_lds form took a 64-bit v_lshl_add_u64 each;
+// VALU issue slots between MFMAs are what these loops are short of, see profiles/r04_panel_ab.md r04d).
+template <int AUX>
+__device__ __forceinline__ void dma_1k(const char* p, uint32_t lane_off, char* lds_dst) {
+  typedef __attribute__((address_space(3))) void lds_void_t;
+#if BNF_TN_BUFDMA
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)lds_dst, 16, lane_off, 0, 0, AUX);
+#else
+  typedef __attribute__((address_space(1))) const void glb_void_t;
+  __builtin_amdgcn_global_load_lds((glb_void_t*)(p + lane_off), (lds_void_t*)lds_dst, 16, 0, AUX);
+#endif
+}
 template <int OFF>
 __device__ __forceinline__ u32x2_t lds_tr16_b64(uint32_t addr) {
   u32x2_t v;
@@ -1252,10 +1270,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_skinny(const GemmArgs g, const
     char* sB = sA + kSkA;
     const char* pa = pin(Ab + (int64_t)kt * kSkRows * 128);
     const char* pb = pin(Bb + (int64_t)kt * kSkRows * g.b_ld * 2);
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + src_a), (lds_void_t*)(sA + qa * 1024), 16, 0, BNF_SK_AUX);
+    dma_1k<BNF_SK_AUX>(pa, src_a, sA + qa * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + src_b[i]), (lds_void_t*)(sB + (wave * 4 + i) * 1024), 16, 0, BNF_SK_AUX);
+    for (int i = 0; i < 4; ++i) dma_1k<BNF_SK_AUX>(pb, src_b[i], sB + (wave * 4 + i) * 1024);
   };
 
   f32x16 acc[2][2];
@@ -1443,8 +1460,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gemm_tn_ring(const G
     const char* pb = pin(Bb + (int64_t)kt * kRgRows * g.b_ld * 2);
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + src_a[q]), (lds_void_t*)(sA + (wave * QN + q) * 1024), 16, 0, BNF_TN_AUX);
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + src_b[q]), (lds_void_t*)(sB + (wave * QN + q) * 1024), 16, 0, BNF_TN_AUX);
+      dma_1k<BNF_TN_AUX>(pa, src_a[q], sA + (wave * QN + q) * 1024);
+      dma_1k<BNF_TN_AUX>(pb, src_b[q], sB + (wave * QN + q) * 1024);
     }
   };
 

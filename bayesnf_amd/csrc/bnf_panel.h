@@ -4,6 +4,7 @@
 //   <8, 2, H0L, ., 2, 64>   W = 1024: 64-row panels, two 64-column slabs per wave      (C4)
 //   <4, 2, true, ., 1, FP>  W = 256: 128-row panels of two 64-row blocks, FP = 64 | 128 (C1, C5)
 //   <4, 4, false, ., 1, 64> W = 256 without the LDS feature panel: 256-row panels
+// (+ a last flag F0 on the H0L forms: layer 0 folded into its contraction, see k_panel_fwd_bwd)
 //
 // A workgroup (8 waves, one per CU: 256 registers per lane) owns a panel of BM batch rows of one
 // ensemble member and carries it through the network and back (reference models.py:212-273,
@@ -21,6 +22,16 @@
 // themselves from the dH0 tiles in registers and the feature panel in LDS (phase 9).  It replaces
 // gemm_fwd_l0 + gemm_fwd_last + gemm_dgrad + gemm_dgrad0 of the layer pipeline (and their HBM
 // round trips of H1 / dZ1 / dZ0 as contraction operands: 2.0 GB of the 8.0 GB per C2 step).
+//
+// Round 4 (profiles/r04_panel_ab.md): the phases of a panel do not overlap with one another and, inside a phase, every
+// instruction of whatever kind costs its issue time (ablation clocks add up to the cycle) -- so the kernel got faster by
+// ISSUING LESS: the weight fragments of the W x W contractions arrive by raw buffer loads (no VALU address arithmetic
+// between the MFMAs: the first wave of a SIMD finishes a contraction in 10.5k cycles instead of 17k), contractions start
+// from a zero C operand, the forward epilogues take elu + 1 as one median, the backward ones min(e, 1) of a pair by one
+// packed clamp, dZ1's column quantities come from two accumulations instead of five instructions, wave sums are DPP, panel
+// copies leave by buffer stores, and layer 0 is FOLDED (template flag F0): scale and bias inside its contraction, both of
+// its epilogues on transposed tiles with 8-byte panel stores, d bias0 from the weight-gradient kernel.  C2, same box:
+// panel kernel 1288 -> 1145 us, 131.8k -> 110k cycles per panel.
 //
 // Geometry (W = 64 WN, WN = 8 or 4): wave w = (row block rb = w / WN, column slab cs = w % WN) owns
 // rows [128 rb, +128) x columns [64 cs, +64) of every BM x W activation of the panel
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   // 10k-cycle burst per panel (a CU issues stores at ~13 B/clk).
   auto block_to_global = [&](const LaneCtx& L, bf16_t* dst, int i, int cbase) {
     if (BNF_ABL(a, 8)) return;
-    bf16_t* d = dst + (int64_t)e * a.act_batch + (int64_t)(m0 + rbase + i * 32) * W + cbase;
+    bf16_t* d = dst + (int64_t)e * a.act_batch + (int64_t)(m0 + rbase + i * 32) * W + cbase;   // uniform
     const bf16_t* sp = tile + (rbase + i * 32) * kPitchE + cbase;
     u32x4 v[4];
 #pragma unroll
@@ -547,6 +558,16 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
       const int idx = L.lane + 64 * u;
       v[u] = *reinterpret_cast<const u32x4*>(sp + (idx >> 3) * kPitchE + (idx & 7) * 8);
     }
+#if BNF_PANEL_SADDR
+    // raw buffer stores: the block's (uniform) address is the resource base, a lane's place in the block its 32-bit
+    // offset -- no 64-bit VALU address per store (aux 2 = non-temporal)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = L.lane + 64 * u;
+      __builtin_amdgcn_raw_buffer_store_b128(v[u], rs, (uint32_t)((idx >> 3) * W * 2 + (idx & 7) * 16), 0, BNF_PANEL_NT ? 2 : 0);
+    }
+#else
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = L.lane + 64 * u;
@@ -556,6 +577,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
       *reinterpret_cast<u32x4*>(d + (int64_t)(idx >> 3) * W + (idx & 7) * 8) = v[u];
 #endif
     }
+#endif
   };
 
   f32x16 accs[CH][RT][2];   // [slab][row tile][column tile]; the phases below see one slab at a time as `acc`
@@ -799,6 +821,9 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
       bf16_t* pk = park_ptr(l, hc);
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
+        int tile_off = (rbase + i * 32 + 4 * kg) * kPitchE;     // (one LDS base per 32-row tile: see the dZ1 epilogue)
+        asm volatile("" : "+v"(tile_off));
+        bf16_t* tile_i = tile + tile_off;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int lc = cbase + j * 32 + frow;
@@ -818,7 +843,8 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
               const f32x2 s = kLn2 * c.mxt + c.dl;
 #endif
               const f32x2 h = ak.c1 * c.r + (ak.alpha * s + ak.c0);
-              store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, h.x, h.y);
+              (void)lr;
+              store_pair_pk(tile_i + (8 * rg + q) * kPitchE + lc, tile_i + (8 * rg + q + 1) * kPitchE + lc, h.x, h.y);
             }
           }
           u32x4* dst = reinterpret_cast<u32x4*>(pk + ((i * 2 + j) * 2 * 64 + lane) * 8);
@@ -992,7 +1018,12 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
     const float gka[2] = {gamma1 * kvn[0] * ak.alpha, gamma1 * kvn[1] * ak.alpha};
     const float gkc[2] = {gamma1 * kvn[0] * ak.c2, gamma1 * kvn[1] * ak.c2};
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+    for (int i = 0; i < RT; ++i) {
+      // one LDS base register per 32-row tile (an opaque offset): every store of the tile then fits the 16-bit immediate --
+      // hipcc otherwise re-derives the address of each store beyond 64 KiB with a v_add_u32 (83 of them in this phase)
+      int tile_off = (rbase + i * 32 + 4 * kg) * kPitchE;
+      asm volatile("" : "+v"(tile_off));
+      bf16_t* tile_i = tile + tile_off;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int lr = rbase + i * 32 + 8 * rg + 4 * kg;
@@ -1013,7 +1044,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
             cs[j] += dv2 * s;
             sg[j] += z * tv;
             cp[j] += z;
-            store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, z.x, z.y);
+            store_pair_pk(tile_i + (8 * rg + q) * kPitchE + lc, tile_i + (8 * rg + q + 1) * kPitchE + lc, z.x, z.y);
           }
         }
         asm volatile("" : "+v"(cr[0]), "+v"(cr[1]), "+v"(sg[0]), "+v"(sg[1]), "+v"(cp[0]), "+v"(cp[1]),
@@ -1021,6 +1052,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
         if (BNF_EPI_FENCE_EVERY == 1 || (rg & 1)) __builtin_amdgcn_sched_barrier(0);
         if (rg == 1 && i > 0) block_to_global(L, a.dZ[LL], i - 1, cbase);   // (deferred: see the layer-0 forward)
       }
+    }
     block_to_global(L, a.dZ[LL], RT - 1, cbase);
     if (hc == CH - 1) ring_prefetch(wbl(LL), lane);   // the accumulators are dead: weights of dH = dZ K^T on their way
     const float crj[2] = {cr[0].x + cr[0].y, cr[1].x + cr[1].y}, csj[2] = {cs[0].x + cs[0].y, cs[1].x + cs[1].y};
@@ -1103,6 +1135,9 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
       f32x2 sa2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, sacc = {0.f, 0.f}, cs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
+        int tile_off = (rbase + i * 32 + 4 * kg) * kPitchE;
+        asm volatile("" : "+v"(tile_off));
+        bf16_t* tile_i = tile + tile_off;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int t2 = 2 * i + j;
@@ -1125,7 +1160,8 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
               sacc += raw;
               sg2 += z * tv;
               cs2[j] += z;
-              store_pair_pk(tile + (lr + q) * kPitchE + lc, tile + (lr + q + 1) * kPitchE + lc, z.x, z.y);
+              (void)lr;
+              store_pair_pk(tile_i + (8 * rg + q) * kPitchE + lc, tile_i + (8 * rg + q + 1) * kPitchE + lc, z.x, z.y);
             }
             asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(sacc), "+v"(cs2[0]), "+v"(cs2[1]));
             __builtin_amdgcn_sched_barrier(0);

@@ -288,3 +288,33 @@ def test_width_1024_panel_without_the_lds_feature_panel(monkeypatch):
   np.testing.assert_allclose(g['0'][0], g['1'][0], rtol=1e-4)
   bad = {k: v for k, v in _leaf_errs(model, g['0'][1], g['1'][1]).items() if v > 1.5e-2}
   assert not bad, bad
+
+
+@pytest.mark.parametrize('degrees,inter,want_f', [((6, 5, 5), ((0, 1), (1, 2), (0, 2)), 62),
+                                                  ((7, 5, 5), ((0, 1), (1, 2)), 63),
+                                                  ((7, 5, 5), ((0, 1), (1, 2), (0, 2)), 64)])
+def test_layer0_fold_boundary_feature_counts(degrees, inter, want_f, monkeypatch):
+  """Round 4: the H0L forms fold layer 0's scale and bias into its contraction (two ones columns behind the features,
+  bias rows in the forward-packed weights, d bias0 = the ones row of the layer-0 weight gradient, swapped operand
+  roles in both layer-0 epilogues) -- possible only while F + 2 <= Fp.  F = 62 is the last folded count at Fp = 64,
+  63 and 64 run the unfolded form; all three against the float64 oracle, and the folded form against the unfolded
+  one (`BNF_PANEL_FOLD0=0`) in the same arithmetic."""
+  n_rows, E = 700, 3
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=512, depth=2, fourier_degrees=degrees, interactions=inter)
+  assert net.F == want_f
+  theta = util.random_theta(model, E, scale=0.3)
+  loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
+  res = {}
+  for fold in ('1', '0'):
+    monkeypatch.setenv('BNF_PANEL_FOLD0', fold)
+    eng = _engine(net, X, y, members=E, compute_dtype='bf16', pipeline='panel')
+    eng.set_params(theta)
+    res[fold] = eng.debug_loss_and_grad() + (eng.debug_activation(1), eng.debug_activation(300))
+    eng.close()
+  for fold, (loss_p, g_p, H1, dZ0) in res.items():
+    np.testing.assert_allclose(loss_p, loss_o, rtol=5e-3)
+    bad = {k: v for k, v in _leaf_errs(model, g_p, g_o).items() if v > 6e-2}
+    assert not bad, (fold, 'vs oracle', bad)
+  bad = {k: v for k, v in _leaf_errs(model, res['1'][1], res['0'][1]).items() if v > 2e-2}
+  assert not bad, ('folded vs unfolded', bad)
+  assert util.rel_err(res['1'][2], res['0'][2]) < 1e-2 and util.rel_err(res['1'][3], res['0'][3]) < 3e-2

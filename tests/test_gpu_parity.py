@@ -251,6 +251,30 @@ def test_vi_step_and_training_fp32(width):
   eng.close()
 
 
+def test_vi_gradients_with_sigma_at_its_floor():
+  """k_vi_adam recovers the step's noise from the stored samples, eps = (z - mu) / sigma, instead of generating it a second
+  time.  That quotient loses ulp(z) / sigma: with sigma at its floor (rho = -12: sigma = 1e-4 + softplus(-12) = 1.06e-4) and
+  |mu| ~ 1 the recovered eps is off by ~6e-4 -- the worst case the parametrisation allows (sigma >= 1e-4).  The gradients
+  wrt mu and rho must still meet bars next to the oracle's, which uses the exact noise."""
+  n_rows, E, S = 150, 2, 3
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=2)
+  eng = _engine(net, X, y, mode='vi', members=E, vi_samples=S, kl_weight=0.2, seed=3, learning_rate=0.01, compute_dtype='fp32')
+  eng.init_params(0.0)
+  p0 = eng.get_params().astype(np.float64)
+  p0[1] = -12.0
+  p0[0] = np.where(np.abs(p0[0]) < 0.5, np.sign(p0[0] + 1e-9) * 0.5 + p0[0], p0[0])     # |mu| >= 0.5 everywhere
+  eng.set_params(p0)
+  eps0 = eng.debug_vi_eps(0)
+  loss_d, g_d = eng.debug_loss_and_grad(0, 0)
+  loss_o, gmu_o, grho_o = O.vi_loss_and_grad(model, p0[0], p0[1], eps0, X, y, n_rows, 0.2)
+  np.testing.assert_allclose(loss_d, loss_o * 0.2, rtol=5e-5)
+  bad = {k: v for k, v in util.per_leaf_rel_err(model, g_d[0], gmu_o).items() if v > 5e-4}
+  assert not bad, ('gmu', bad)
+  bad = {k: v for k, v in util.per_leaf_rel_err(model, g_d[1], grho_o).items() if v > 5e-3}
+  assert not bad, ('grho', bad)
+  eng.close()
+
+
 def test_vi_minibatch_shares_one_batch():
   n_rows, B = 200, 64
   net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=1)
