@@ -664,7 +664,8 @@ template <typename T>
 static void run_wgrad(bnf_handle* h, int nmem) {
   if constexpr (sizeof(T) == 2) {
     if (wgrad_multi_ok(h, nmem)) {
-      if (!panel_dk0_fused(h)) wgrad_after_dz<T>(h, nmem, 0);
+      const bool l0_first = getenv("BNF_WGRAD_ORDER") && !strcmp(getenv("BNF_WGRAD_ORDER"), "fwd");   // (see below)
+      if (l0_first && !panel_dk0_fused(h)) wgrad_after_dz<T>(h, nmem, 0);
       const int64_t Bp = h->Bp;
       GemmArgs g{};
       g.a_ld = h->W; g.a_batch = Bp * h->W; g.b_ld = h->W; g.b_batch = Bp * h->W;
@@ -678,10 +679,21 @@ static void run_wgrad(bnf_handle* h, int nmem) {
       ep.scale = 1.0f / sqrtf((float)h->Wt);
       ep.grad = h->gradf; ep.grad_stride = h->Pf; ep.off_out = h->nd.off_kernel[1]; ep.ld_f32 = h->W;
       launch_gemm_tn<T, 1>(h, KID_WGRAD, g, ep, h->stream, WG_RING);
+      if (!l0_first && !panel_dk0_fused(h)) wgrad_after_dz<T>(h, nmem, 0);
       return;
     }
   }
-  for (int l = (panel_dk0_fused(h) ? 1 : 0); l < h->L; ++l) wgrad_after_dz<T>(h, nmem, l);
+  // Order: the LAST layer's weight gradient first.  In the panel pipeline every dZ_l exists when this runs, and the
+  // panel kernel wrote dZ_0 last: read right away it comes back at two thirds of the HBM rate (dirty lines in the
+  // memory-side cache, profiles/r02w_wgrad_streams.md); after the W x W kernels have streamed their operands it does not.
+  // (BNF_WGRAD_ORDER=fwd: layer 0 first, the order of rounds 1 - 3.)
+  static const bool fwd_order = getenv("BNF_WGRAD_ORDER") && !strcmp(getenv("BNF_WGRAD_ORDER"), "fwd");
+  const int l_first = panel_dk0_fused(h) ? 1 : 0;
+  if (fwd_order || !h->panel) {
+    for (int l = l_first; l < h->L; ++l) wgrad_after_dz<T>(h, nmem, l);
+  } else {
+    for (int l = h->L - 1; l >= l_first; --l) wgrad_after_dz<T>(h, nmem, l);
+  }
   wgrad_join(h);
 }
 

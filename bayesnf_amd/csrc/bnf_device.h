@@ -152,9 +152,12 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
 // per lane streams at ~2x the rate of a 4-byte one (MI355X_MICROARCH.md: 8-byte accesses reach
 // 0.54 - 0.70 of the 16-byte rate).  nv < 4: the row's tail, element by element.
 typedef f32x4 __attribute__((aligned(4))) f32x4u;
+template <bool NT = false>
 __device__ __forceinline__ void load4u(const float* p, int nv, float (&o)[4]) {
   if (nv >= 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4u*>(p);
+    f32x4 v;
+    if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4u*>(p));
+    else v = *reinterpret_cast<const f32x4u*>(p);
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
   } else {
 #pragma unroll

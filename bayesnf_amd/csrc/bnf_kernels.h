@@ -670,6 +670,9 @@ __global__ void k_step_advance(StepState* st) {
 #ifndef BNF_ADAM_NT
 #define BNF_ADAM_NT 1
 #endif
+#ifndef BNF_ADAM_NTLOAD
+#define BNF_ADAM_NTLOAD 0   // the moments also READ non-temporally (touched once per step)
+#endif
 // A thread owns four consecutive parameters (16-byte accesses at any 4-byte aligned address: load4u);
 // the last thread of a member takes the P % 4 tail element by element.
 __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
@@ -683,7 +686,7 @@ __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
     const int64_t i0 = (int64_t)e * a.stride + p0;
     float th[4], g[4], m[4], v[4];
     load4u(a.theta + i0, nv, th); load4u(a.grad + i0, nv, g);
-    if (a.apply) { load4u(a.m + i0, nv, m); load4u(a.v + i0, nv, v); }
+    if (a.apply) { load4u<BNF_ADAM_NTLOAD != 0>(a.m + i0, nv, m); load4u<BNF_ADAM_NTLOAD != 0>(a.v + i0, nv, v); }
     // One hardware exp2 / log2 / rcp / sqrt each (1 ulp) instead of the libm tanhf, expf + log1pf and
     // the IEEE divide / sqrt sequences: 246 VALU instructions per element made this kernel VALU-bound
     // (profiles/r02z_mfma_valu_counters.md: VALU busy ~100 %, 4.2 TB/s); with e = exp(-|z|):

@@ -450,6 +450,10 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   constexpr int KS1 = W / 16;
   constexpr int kHalves = (RT + 1) / 2;     // row dots go through a 64-row scratch image per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifndef BNF_MARK0_AT
+#define BNF_MARK0_AT 0     // ABLATE builds: where phase clock 0 is read (0: feature staging issued, 1: kernel entry, 2: behind the staging barrier)
+#endif
+  if (BNF_MARK0_AT == 1) BNF_MARK(a, 0);
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
   constexpr int kImageB = BM * kPitchB > 8 * 64 * kRowDotPitch * 4 ? BM * kPitchB : 8 * 64 * kRowDotPitch * 4;
   float* xs = reinterpret_cast<float*>(smem + kImageB);
@@ -671,8 +675,9 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
           *reinterpret_cast<const u32x4*>(src + (int64_t)(q / kCpr) * FP + (q % kCpr) * 8);
     }
   }
-  BNF_MARK(a, 0);
+  if (BNF_MARK0_AT == 0) BNF_MARK(a, 0);
   if constexpr (H0L) lds_barrier();     // the staged feature panel is complete
+  if (BNF_MARK0_AT == 2) BNF_MARK(a, 0);
 #pragma unroll
   for (int hc = 0; hc < CH; ++hc) {
     const int cbase = slab(hc) * 64;
