@@ -135,6 +135,8 @@ struct bnf_handle {
   int32_t* leaf_off = nullptr; uint8_t* leaf_id = nullptr; int32_t n_leaves = 0;
   bool adam_clear_all = false;   // env BNF_ADAM_CLEAR_ALL (A/B of the kept gradient range)
   bool h0l = false;
+  bool fin = false;     // -DBNF_PANEL_FIN=1 builds + env BNF_PANEL_FIN=1: the H0L panel forms featurise their own rows (measured loss)
+  int32_t* fcol = nullptr; std::vector<int32_t> fcol_h;   // per padded feature column {kind | group << 8, a, b, 0}
   bool fold0 = false;   // the panel kernel's F0 forms: layer-0 scale / bias folded into its contraction (needs h0l, F + 2 <= Fp)
   void* A[BNF_MAX_LAYERS]; void* H[BNF_MAX_LAYERS]; void* Ht[BNF_MAX_LAYERS];
   void* dZ[BNF_MAX_LAYERS]; void* dZt[BNF_MAX_LAYERS];
@@ -235,6 +237,7 @@ static size_t carve(bnf_handle* h, char* base) {
   h->dbg_a = (float*)take(256);
   h->is_matrix = (uint8_t*)take((size_t)P);
   h->fbmeta = h->fbmeta_h.empty() ? nullptr : (int32_t*)take(h->fbmeta_h.size() * 4);
+  h->fcol = h->fcol_h.empty() ? nullptr : (int32_t*)take(h->fcol_h.size() * 4);
   if (h->cfg.mode == BNF_MODE_VI) {
     h->leaf_off = (int32_t*)take(260 * 4);
     h->leaf_id = (uint8_t*)take((size_t)P);
@@ -887,7 +890,7 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
                       const LossSink& sink) {
   const int64_t Bp = h->Bp;
   run_pack_fragments<bf16_t>(h, theta, nmem);     // also fills the member scalar table the next kernels read
-  {
+  if (!h->fin) {
     LaunchScope ls(h, KID_FEAT);
     dim3 grid(cdiv(h->B, kFeatRows) * (unsigned)nmem);
     const size_t lds = (size_t)kFeatRows * (h->Fp + 8) * 2;
@@ -921,6 +924,8 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   pa.loss_scale = sink.scale; pa.lik_c = c; pa.st = sink.st;
   pa.off_k0 = h->nd.off_kernel[0];
   pa.dk0_fused = panel_dk0_fused(h) ? 1 : 0;
+  pa.fin = h->fin ? 1 : 0; pa.n_in = h->nd.D; pa.n_seas = 2 * h->ft.n;
+  pa.X = h->X; pa.stab = h->stab; pa.y = h->y; pa.fcol = h->fcol; pa.H0out = (bf16_t*)h->H0; pa.rs = rs;
   // 128-row panels at W = 512 (the feature panel staged in LDS when Fp = 64), 256-row panels at W = 256,
   // 64-row panels with two 64-column slabs per wave at W = 1024
   auto with_fused_featbwd = [&]() {
@@ -1376,6 +1381,35 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   }
   h->h0l = h->panel && (((h->W == 512 || h->W == 1024) && h->Fp == 64) || (h->W == 256 && (h->Fp == 64 || h->Fp == 128))) && !getenv("BNF_PANEL_NO_H0L");
   h->fold0 = h->h0l && h->F + 2 <= h->Fp && !(getenv("BNF_PANEL_FOLD0") && atoi(getenv("BNF_PANEL_FOLD0")) == 0);
+  h->fin = BNF_PANEL_FIN != 0 && h->h0l && getenv("BNF_PANEL_FIN") && atoi(getenv("BNF_PANEL_FIN")) != 0;   // (experiment builds only)
+  if (h->fin) {
+    // what every padded feature column holds (k_featurize's group loop, one entry per column) -- models.py:218-252
+    std::vector<int32_t>& m = h->fcol_h;
+    const int Fp = h->Fp;
+    m.assign((size_t)Fp * 4, 0);
+    auto put = [&](int col, int kind, int g, int a0, int b0) {
+      m[4 * col] = kind | (g << 8); m[4 * col + 1] = a0; m[4 * col + 2] = b0;
+    };
+    for (int g = 0; g < cfg->n_groups; ++g) {
+      const int c0 = cfg->group_col0[g], nc = cfg->group_ncols[g];
+      switch (cfg->group_kind[g]) {
+        case BNF_GROUP_INPUT:
+          for (int d = 0; d < cfg->n_inputs; ++d) put(c0 + d, kFcInput, g, d, 0);
+          break;
+        case BNF_GROUP_FOURIER: {
+          const int deg = nc / 2, d = cfg->group_arg[g];
+          for (int k = 0; k < deg; ++k) { put(c0 + k, kFcCos, g, d, k); put(c0 + deg + k, kFcSin, g, d, k); }
+          break;
+        }
+        case BNF_GROUP_SEASONAL:
+          for (int j = 0; j < nc; ++j) put(c0 + j, kFcSeasonal, g, j, 0);
+          break;
+        default:
+          for (int k = 0; k < nc; ++k) put(c0 + k, kFcInter, g, cfg->interact[k][0], cfg->interact[k][1]);
+      }
+    }
+    if (h->fold0) { put(h->F, kFcOne, 0, 0, 0); put(h->F + 1, kFcOne, 0, 0, 0); }
+  }
   if (h->h0l &&
       !(getenv("BNF_PANEL_FEATBWD") && atoi(getenv("BNF_PANEL_FEATBWD")) == 0)) {
     // fused featurisation backward of the H0L panel kernel: what each feature column contributes
@@ -1491,6 +1525,8 @@ int bnf_bind(bnf_handle* h, void* params, void* opt_state, void* workspace, cons
   HIPCHK(hipMemcpyAsync(h->is_matrix, mm.data(), (size_t)h->P, hipMemcpyHostToDevice, h->stream));
   if (h->fbmeta)
     HIPCHK(hipMemcpyAsync(h->fbmeta, h->fbmeta_h.data(), h->fbmeta_h.size() * 4, hipMemcpyHostToDevice, h->stream));
+  if (h->fcol)
+    HIPCHK(hipMemcpyAsync(h->fcol, h->fcol_h.data(), h->fcol_h.size() * 4, hipMemcpyHostToDevice, h->stream));
   if (h->pad) {
     HIPCHK(hipMemcpyAsync(h->pad_src, h->pad_src_h.data(), h->pad_src_h.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->fold_src, h->fold_src_h.data(), h->fold_src_h.size() * 4, hipMemcpyHostToDevice, h->stream));

@@ -103,7 +103,18 @@ struct PanelArgs {
   // -DBNF_PANEL_DK0=1 builds (experiment, profiles/r04_panel_ab.md): layer 0's weight gradient contracted here from the
   // dZ0 and feature panels in LDS and accumulated with f32 atomics; dZ0 is then not written and gemm_tn_skinny not run
   int32_t off_k0, dk0_fused;
+  // fin (-DBNF_PANEL_FIN=1 builds + env BNF_PANEL_FIN=1; experiment, profiles/r04_panel_ab.md r04l): the H0L forms FEATURISE
+  // their own rows (models.py:218-252: what k_featurize does, value for value) straight into the LDS feature panel and write
+  // the row-major copy the layer-0 weight gradient reads; no k_featurize launch, no re-read of H0.  Measured: bit-identical
+  // features, and 45 - 85 us per C2 step SLOWER than the separate kernel (one workgroup per CU has nothing to hide the
+  // panel's serial start-up behind).  fcol: per padded feature column {kind | group << 8, a, b, 0}.
+  int32_t fin, n_in, n_seas;
+  const float* X; const float* stab; const float* y;
+  const int32_t* fcol;
+  bf16_t* H0out;
+  RowSrc rs;
 };
+constexpr int kFcZero = 0, kFcInput = 1, kFcCos = 2, kFcSin = 3, kFcSeasonal = 4, kFcInter = 5, kFcOne = 6;
 constexpr int kFbNone = 0, kFbInput = 1, kFbFourier = 2, kFbInter = 3;
 
 // ---- fragment-major weight packing -------------------------------------------------
@@ -234,6 +245,9 @@ __global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ t
 #endif
 #ifndef BNF_PANEL_CPRIO
 #define BNF_PANEL_CPRIO 1    // (r04d: -0.4 %) 1: the second-dispatched waves run the contractions at priority 1; 2: the first-dispatched ones do
+#endif
+#ifndef BNF_PANEL_FIN
+#define BNF_PANEL_FIN 0      // experiment: the H0L forms featurise their own rows; -DBNF_PANEL_FIN=1 + env BNF_PANEL_FIN=1
 #endif
 #ifndef BNF_PANEL_DK0
 #define BNF_PANEL_DK0 0      // experiment: dK_0 = H0^T dZ0 inside the panel kernel (f32 atomics), env BNF_PANEL_DK0=1 at run time
@@ -506,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   const float e_lns = expf(lns), sigma = 0.01f + e_lns, inv_sigma = 1.0f / sigma;
   const float ll_const = -logf(sigma) - 0.918938533204672742f;
   // the row phase's target value, fetched now (one thread per row; rows >= B read nothing)
-  const float y_row = (tid < BM && m0 + tid < a.B) ? a.ybat[(int64_t)e * a.row_batch + m0 + tid] : 0.f;
+  const float y_pre = (!(BNF_PANEL_FIN && H0L && a.fin) && tid < BM && m0 + tid < a.B) ? a.ybat[(int64_t)e * a.row_batch + m0 + tid] : 0.f;
 
   float* s_grp = s_sc + 64;                 // [BNF_MAX_GROUPS + BNF_MAX_INPUTS] sums of the fused featurisation backward
   float* s_gfac = s_sc + 88;                // [BNF_MAX_GROUPS] sigmoid(scale_g) / softplus(scale_g) ...
@@ -665,7 +679,77 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
     for (int j = 0; j < 2; ++j) gb_pre[j] = th[a.off_bias[0] + slab(0) * 64 + j * 32 + Lpre.frow];
     l0_weights(Lpre);
   }
-  if constexpr (H0L) {   // feature panel -> LDS (row-major source, 16-byte chunks, 8 per row)
+  if constexpr (H0L) {
+   if (BNF_PANEL_FIN && a.fin) {
+    // ---- featurise this panel's rows into LDS (what k_featurize<bf16_t> computes, value for value) -----------------
+    // A lane owns a ROW, a wave a block of CPT consecutive columns of 64 rows: which column holds what is then uniform
+    // across the wave -- metadata and group scales by scalar loads, no divergence (a first version with four lanes per
+    // row and 16 columns each diverged four ways per column and cost 105 us per launch against the 37 us of the kernel
+    // it replaced: profiles/r04_panel_ab.md r04l).  Inputs u_d = x_d / (input scale e^lsa_d) (the member's scalar table),
+    // Fourier columns cos / sin(2 pi 2^k u_d) / (k + 1) by the hardware v_cos / v_sin on the fractional part, seasonal
+    // columns from the data-constant table, interactions u_p u_q, every group times softplus(scale_g); the ones columns
+    // of the folded layer 0; zero padding.  The row's target goes to s_dv (read by the row phase).
+    constexpr int RG = BM / 64, PARTS = 8 / RG, CPT = FP / PARTS;    // row groups of 64, waves per row group, columns per wave
+    static_assert(BM % 64 == 0 && CPT % 8 == 0 && CPT * PARTS == FP, "feature panel geometry");
+    const int part = wave % PARTS;                                   // uniform
+    const int r = (wave / PARTS) * 64 + (tid & 63);
+    const int m = m0 + r;
+    float vals[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) vals[k] = 0.f;
+    float y_here = 0.f;
+    {
+      const bool live = m < a.B;
+      const int64_t row = live ? row_of(a.rs, e, m) : 0;            // (dead rows compute on row 0 and store zeros)
+      const float* x = a.X + row * a.n_in;
+      float u[BNF_MAX_INPUTS];
+#pragma unroll
+      for (int d = 0; d < BNF_MAX_INPUTS; ++d) u[d] = (d < a.n_in) ? x[d] : 0.f;     // all in flight (uniform bound)
+      if (a.y && part == 0) y_here = live ? a.y[row] : 0.f;
+#pragma unroll
+      for (int d = 0; d < BNF_MAX_INPUTS; ++d)
+        if (d < a.n_in) u[d] = u[d] / sc[kScalInput + d];
+      static_assert(BNF_MAX_INPUTS == 8, "pick");
+      auto pick = [&](int idx) {     // idx is wave-uniform: one scalar branch, one move (a select chain costs 8 VALU slots)
+        switch (__builtin_amdgcn_readfirstlane(idx)) {
+          case 0: return u[0]; case 1: return u[1]; case 2: return u[2]; case 3: return u[3];
+          case 4: return u[4]; case 5: return u[5]; case 6: return u[6]; default: return u[7];
+        }
+      };
+      const float* srow = a.stab + row * a.n_seas;
+      const int4* fc = reinterpret_cast<const int4*>(a.fcol) + part * CPT;   // uniform
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) {
+        const int4 md = fc[k];
+        const int kind = md.x & 0xff;
+        const float sp = sc[kScalGroup + ((md.x >> 8) & 0xff)];
+        float v = 0.f;
+        if (kind == kFcInput) {
+          v = pick(md.y) * sp;
+        } else if (kind == kFcCos || kind == kFcSin) {
+          const float xk = pick(md.y) * (float)(1u << md.z);
+          const float fx = xk - floorf(xk);
+          const float q = __builtin_amdgcn_rcpf((float)(md.z + 1)) * sp;
+          v = (kind == kFcCos ? __builtin_amdgcn_cosf(fx) : __builtin_amdgcn_sinf(fx)) * q;
+        } else if (kind == kFcSeasonal) {
+          v = srow[md.y] * sp;
+        } else if (kind == kFcInter) {
+          v = (pick(md.y) * pick(md.z)) * sp;
+        } else if (kind == kFcOne) {
+          v = 1.f;
+        }
+        vals[k] = live ? v : 0.f;
+      }
+    }
+    if (part == 0) s_dv[r] = y_here;
+#pragma unroll
+    for (int ch = 0; ch < CPT / 8; ++ch) {
+      const u32x4 w = {pack_bf16x2(vals[8 * ch], vals[8 * ch + 1]), pack_bf16x2(vals[8 * ch + 2], vals[8 * ch + 3]),
+                       pack_bf16x2(vals[8 * ch + 4], vals[8 * ch + 5]), pack_bf16x2(vals[8 * ch + 6], vals[8 * ch + 7])};
+      *reinterpret_cast<u32x4*>(const_cast<char*>(h0s) + r * kH0Pitch + (part * CPT + 8 * ch) * 2) = w;
+    }
+   } else {
+    // feature panel -> LDS (row-major source written by k_featurize, 16-byte chunks, 8 per row)
     const bf16_t* src = a.H0rm + (int64_t)e * a.h0_batch + (int64_t)m0 * FP;
     constexpr int kCpr = FP / 8;              // 16-byte chunks per feature row
 #pragma unroll
@@ -674,10 +758,23 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
       *reinterpret_cast<u32x4*>(const_cast<char*>(h0s) + (q / kCpr) * kH0Pitch + (q % kCpr) * 16) =
           *reinterpret_cast<const u32x4*>(src + (int64_t)(q / kCpr) * FP + (q % kCpr) * 8);
     }
+   }
   }
   if (BNF_MARK0_AT == 0) BNF_MARK(a, 0);
   if constexpr (H0L) lds_barrier();     // the staged feature panel is complete
   if (BNF_MARK0_AT == 2) BNF_MARK(a, 0);
+  if constexpr (H0L) {
+    if (BNF_PANEL_FIN && a.fin) {   // the row-major (Bp, Fp) copy the layer-0 weight gradient reads: whole 16-byte chunks, rows >= B are zero
+      constexpr int kCpr = FP / 8;
+      bf16_t* dst = a.H0out + (int64_t)e * a.h0_batch + (int64_t)m0 * FP;
+#pragma unroll
+      for (int c = 0; c < (BM * kCpr) / 512; ++c) {
+        const int q = tid + c * 512;
+        *reinterpret_cast<u32x4*>(dst + (int64_t)(q / kCpr) * FP + (q % kCpr) * 8) =
+            *reinterpret_cast<const u32x4*>(h0s + (q / kCpr) * kH0Pitch + (q % kCpr) * 16);
+      }
+    }
+  }
 #pragma unroll
   for (int hc = 0; hc < CH; ++hc) {
     const int cbase = slab(hc) * 64;
@@ -965,6 +1062,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
     float ll = 0.f, s_doutv = 0.f, s_dvsum = 0.f, s_par = 0.f, s_infl = 0.f;
     if (tid < BM) {
       const int m = m0 + tid;
+      const float y_row = (BNF_PANEL_FIN && H0L && a.fin) ? s_dv[tid] : y_pre;   // (fin: the featurisation left the row's target here)
       float vsum = 0.f;
 #pragma unroll
       for (int c = 0; c < kSlabs; ++c) vsum += s_part[tid * kSlabs + c];

@@ -318,3 +318,36 @@ def test_layer0_fold_boundary_feature_counts(degrees, inter, want_f, monkeypatch
   bad = {k: v for k, v in _leaf_errs(model, res['1'][1], res['0'][1]).items() if v > 2e-2}
   assert not bad, ('folded vs unfolded', bad)
   assert util.rel_err(res['1'][2], res['0'][2]) < 1e-2 and util.rel_err(res['1'][3], res['0'][3]) < 3e-2
+
+
+@pytest.mark.parametrize('width,degrees,mode,batch', [(512, (5, 3, 2), 'map', None), (512, (5, 3, 2), 'map', 300),
+                                                      (256, (5, 3, 2), 'map', 256), (1024, (5, 3, 2), 'map', None),
+                                                      (256, (12, 9, 9), 'map', None), (512, (5, 3, 2), 'vi', 200)])
+def test_panel_featurises_its_own_rows_like_k_featurize(width, degrees, mode, batch, monkeypatch):
+  """Round 4 experiment (`-DBNF_PANEL_FIN=1` builds, `scripts/build_variant.sh fin -DBNF_PANEL_FIN=1`, run
+  with `BNF_LIB=ab/libbnf_fin.so`): the H0L forms of the panel kernel featurise their rows themselves (no k_featurize launch,
+  no re-read of H0) and write the row-major copy the layer-0 weight gradient reads.  `BNF_PANEL_FIN=0` runs the separate
+  kernel: the features (`debug_activation(0)`), the loss and every gradient leaf must come out the same -- full batch, the
+  engine's shuffled minibatches (row source modes 1 / 2), 64 and 128 padded features, all three widths, MAP and VI.  Green on
+  the experiment build (profiles/r04_panel_ab.md r04l); it measured SLOWER than the separate kernel, so the default build
+  compiles the path out and this test then compares the default path with itself."""
+  n_rows, E = 700, 3
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=2, fourier_degrees=degrees)
+  out = {}
+  for fin in ('1', '0'):
+    monkeypatch.setenv('BNF_PANEL_FIN', fin)
+    kw = dict(mode='vi', vi_samples=2, kl_weight=0.2) if mode == 'vi' else {}
+    eng = _engine(net, X, y, members=E, compute_dtype='bf16', pipeline='panel', batch=batch, seed=11, **kw)
+    eng.init_params(0.2)
+    loss, g = eng.debug_loss_and_grad(0, 1 if batch else 0)
+    H0 = eng.debug_activation(0)
+    losses = eng.train(0, 2).cpu().numpy()
+    out[fin] = (loss, g, H0, losses, eng.get_params())
+    eng.close()
+  a, b = out['1'], out['0']
+  np.testing.assert_array_equal(a[2], b[2])                       # the same features, bit for bit
+  np.testing.assert_allclose(a[0], b[0], rtol=1e-5)
+  ga, gb = np.asarray(a[1]), np.asarray(b[1])
+  assert np.max(np.abs(ga - gb)) <= 1e-5 * max(1.0, np.max(np.abs(gb)))    # (f32 atomics order only)
+  np.testing.assert_allclose(a[3], b[3], rtol=1e-5)
+  assert np.max(np.abs(a[4] - b[4])) < 1e-4
