@@ -2082,10 +2082,24 @@ struct RcclApi {
 RcclApi g_rccl;
 int rccl_load() {
   if (g_rccl.lib) return BNF_OK;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  // Prefer the RCCL the process has ALREADY mapped (a torch host brings its own copy under torch/lib): a second instance
+  // next to it would keep its own bootstrap threads and device state.  /proc/self/maps names it; else the loader's search.
   void* lib = nullptr;
-  for (const char* n : names)
-    if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (FILE* mp = fopen("/proc/self/maps", "r")) {
+    char line[1024];
+    while (!lib && fgets(line, sizeof(line), mp)) {
+      char* pth = strchr(line, '/');
+      if (!pth || !strstr(pth, "librccl.so")) continue;
+      pth[strcspn(pth, "\n")] = 0;
+      lib = dlopen(pth, RTLD_NOW | RTLD_GLOBAL);
+    }
+    fclose(mp);
+  }
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    if (lib) break;
+    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  }
   if (!lib) return fail(BNF_ERR_STATE, "cannot dlopen librccl.so: %s", dlerror());
   g_rccl.GetUniqueId = (int (*)(RcclId*))dlsym(lib, "ncclGetUniqueId");
   g_rccl.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(lib, "ncclCommInitRank");

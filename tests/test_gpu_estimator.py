@@ -179,6 +179,31 @@ def test_posterior_gather_through_the_c_abi_single_rank():
   assert torch.equal(recv[0], send2)
 
 
+def test_local_communicator_set_and_grouped_gather_single_device():
+  """bnf_comm_create_local / bnf_allgather_group (include/bnf.h): what ONE process driving several GPUs gathers its shards
+  with (`distributed.gather_shards`) -- here the set of one device a test box has: ncclCommInitAll, one grouped
+  ncclAllGather, the set cached per device list; a device named twice is refused (and the callers fall back to peer
+  copies).  Also: the library binds the RCCL the process has already mapped (torch's), not a second copy."""
+  import torch
+  from bayesnf_amd import _native, distributed
+  dev = torch.device('cuda:0')
+  send = torch.arange(2 * 500, dtype=torch.float32, device=dev).reshape(2, 500)
+  recv = torch.zeros((1, 2, 500), dtype=torch.float32, device=dev)
+  _native.allgather_local([send], [recv])
+  torch.cuda.synchronize(dev)
+  assert torch.equal(recv[0], send)
+  _native.allgather_local([send * 3], [recv])           # cached communicator set
+  torch.cuda.synchronize(dev)
+  assert torch.equal(recv[0], send * 3)
+  with pytest.raises(RuntimeError, match='listed twice'):
+    _native.allgather_local([send, send], [recv, recv])
+  parts = [send, send + 1]                               # the same device twice: gather_shards falls back to peer copies
+  out = distributed.gather_shards(parts)
+  assert out.shape == (2, 2, 500) and torch.equal(out[1], send + 1) and distributed.last_gather()['impl'] == 'peer-copies'
+  mapped = [l.split()[-1] for l in open('/proc/self/maps') if 'librccl' in l]
+  assert len(set(mapped)) == 1, set(mapped)              # one RCCL in the process
+
+
 @pytest.mark.parametrize('obs', ['NORMAL', 'NB', 'ZINB'])
 def test_likelihood_model_against_the_oracle(golden_dir, obs):
   """N3: the object `likelihood_model(table)` returns (reference spatiotemporal.py:433-468 returns
