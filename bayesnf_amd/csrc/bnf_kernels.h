@@ -226,6 +226,66 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
 }
 
 // ---------------------------------------------------------------------------
+// The same features with a lane per ROW and a wave per block of consecutive COLUMNS (round 4): which column holds what is
+// uniform across the wave -- column descriptors and group scales by scalar loads, scalar branches, no divergence -- where
+// k_featurize's thread walks all F columns of its row through per-group loops.  Value for value what k_featurize<bf16_t>
+// computes (bit-identical on the GPU: profiles/r04_panel_ab.md r04l / r04m).  Used by the panel kernel's in-kernel
+// featurisation experiment (-DBNF_PANEL_FIN=1) only: as a standalone kernel (64-row workgroups, eight per CU) it measured
+// SLOWER than k_featurize -- 58 against 37 us at C2, 921 against 436 us at C5/8: a scalar load + branch per column costs
+// more than the row walk's per-group loops with their batched loads -- and was removed again.
+//   fcol: per padded feature column {kind | group << 8, a, b, 0} (bnf_api.hip builds it from the config's groups):
+//         input a; Fourier cos / sin of input a, degree index b; seasonal table column a; interaction a x b; one; zero
+// ---------------------------------------------------------------------------
+constexpr int kFcZero = 0, kFcInput = 1, kFcCos = 2, kFcSin = 3, kFcSeasonal = 4, kFcInter = 5, kFcOne = 6;
+struct FeatIn {
+  const float* X; const float* stab; const float* sc;   // inputs (N, D); seasonal table (N, n_seas); the member's scalar table
+  const int32_t* fcol;
+  int32_t n_in, n_seas;
+};
+// columns [col0, col0 + CPT) of data row `row` for this lane; live = false: zeros
+template <int CPT>
+__device__ __forceinline__ void featurize_cols(const FeatIn& f, int64_t row, bool live, int col0, float (&vals)[CPT]) {
+  const float* x = f.X + row * f.n_in;
+  float u[BNF_MAX_INPUTS];
+#pragma unroll
+  for (int d = 0; d < BNF_MAX_INPUTS; ++d) u[d] = (d < f.n_in) ? x[d] : 0.f;     // all in flight (uniform bound)
+#pragma unroll
+  for (int d = 0; d < BNF_MAX_INPUTS; ++d)
+    if (d < f.n_in) u[d] = u[d] / f.sc[kScalInput + d];
+  static_assert(BNF_MAX_INPUTS == 8, "pick");
+  auto pick = [&](int idx) {     // idx is wave-uniform: one scalar branch, one move (a select chain costs 8 VALU slots)
+    switch (__builtin_amdgcn_readfirstlane(idx)) {
+      case 0: return u[0]; case 1: return u[1]; case 2: return u[2]; case 3: return u[3];
+      case 4: return u[4]; case 5: return u[5]; case 6: return u[6]; default: return u[7];
+    }
+  };
+  const float* srow = f.stab + row * f.n_seas;
+  const int4* fc = reinterpret_cast<const int4*>(f.fcol) + col0;   // uniform
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int4 md = fc[k];
+    const int kind = md.x & 0xff;
+    const float sp = f.sc[kScalGroup + ((md.x >> 8) & 0xff)];
+    float v = 0.f;
+    if (kind == kFcInput) {
+      v = pick(md.y) * sp;
+    } else if (kind == kFcCos || kind == kFcSin) {
+      const float xk = pick(md.y) * (float)(1u << md.z);
+      const float fx = xk - floorf(xk);
+      const float q = __builtin_amdgcn_rcpf((float)(md.z + 1)) * sp;
+      v = (kind == kFcCos ? __builtin_amdgcn_cosf(fx) : __builtin_amdgcn_sinf(fx)) * q;
+    } else if (kind == kFcSeasonal) {
+      v = srow[md.y] * sp;
+    } else if (kind == kFcInter) {
+      v = (pick(md.y) * pick(md.z)) * sp;
+    } else if (kind == kFcOne) {
+      v = 1.f;
+    }
+    vals[k] = live ? v : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // featurise backward: d feature scales, d log_scale_adjustment.
 // dH0^T (Fp, ldt) f32 comes from the layer-0 dgrad contraction (transposed so
 // that a thread-per-row read is coalesced).

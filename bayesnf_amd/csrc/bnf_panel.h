@@ -114,7 +114,6 @@ struct PanelArgs {
   bf16_t* H0out;
   RowSrc rs;
 };
-constexpr int kFcZero = 0, kFcInput = 1, kFcCos = 2, kFcSin = 3, kFcSeasonal = 4, kFcInter = 5, kFcOne = 6;
 constexpr int kFbNone = 0, kFbInput = 1, kFbFourier = 2, kFbInter = 3;
 
 // ---- fragment-major weight packing -------------------------------------------------
@@ -695,52 +694,12 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
     const int r = (wave / PARTS) * 64 + (tid & 63);
     const int m = m0 + r;
     float vals[CPT];
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) vals[k] = 0.f;
-    float y_here = 0.f;
-    {
-      const bool live = m < a.B;
-      const int64_t row = live ? row_of(a.rs, e, m) : 0;            // (dead rows compute on row 0 and store zeros)
-      const float* x = a.X + row * a.n_in;
-      float u[BNF_MAX_INPUTS];
-#pragma unroll
-      for (int d = 0; d < BNF_MAX_INPUTS; ++d) u[d] = (d < a.n_in) ? x[d] : 0.f;     // all in flight (uniform bound)
-      if (a.y && part == 0) y_here = live ? a.y[row] : 0.f;
-#pragma unroll
-      for (int d = 0; d < BNF_MAX_INPUTS; ++d)
-        if (d < a.n_in) u[d] = u[d] / sc[kScalInput + d];
-      static_assert(BNF_MAX_INPUTS == 8, "pick");
-      auto pick = [&](int idx) {     // idx is wave-uniform: one scalar branch, one move (a select chain costs 8 VALU slots)
-        switch (__builtin_amdgcn_readfirstlane(idx)) {
-          case 0: return u[0]; case 1: return u[1]; case 2: return u[2]; case 3: return u[3];
-          case 4: return u[4]; case 5: return u[5]; case 6: return u[6]; default: return u[7];
-        }
-      };
-      const float* srow = a.stab + row * a.n_seas;
-      const int4* fc = reinterpret_cast<const int4*>(a.fcol) + part * CPT;   // uniform
-#pragma unroll
-      for (int k = 0; k < CPT; ++k) {
-        const int4 md = fc[k];
-        const int kind = md.x & 0xff;
-        const float sp = sc[kScalGroup + ((md.x >> 8) & 0xff)];
-        float v = 0.f;
-        if (kind == kFcInput) {
-          v = pick(md.y) * sp;
-        } else if (kind == kFcCos || kind == kFcSin) {
-          const float xk = pick(md.y) * (float)(1u << md.z);
-          const float fx = xk - floorf(xk);
-          const float q = __builtin_amdgcn_rcpf((float)(md.z + 1)) * sp;
-          v = (kind == kFcCos ? __builtin_amdgcn_cosf(fx) : __builtin_amdgcn_sinf(fx)) * q;
-        } else if (kind == kFcSeasonal) {
-          v = srow[md.y] * sp;
-        } else if (kind == kFcInter) {
-          v = (pick(md.y) * pick(md.z)) * sp;
-        } else if (kind == kFcOne) {
-          v = 1.f;
-        }
-        vals[k] = live ? v : 0.f;
-      }
-    }
+    const bool live = m < a.B;
+    const int64_t row = live ? row_of(a.rs, e, m) : 0;            // (dead rows compute on row 0 and store zeros)
+    const float y_here = (a.y && part == 0 && live) ? a.y[row] : 0.f;
+    FeatIn fi;
+    fi.X = a.X; fi.stab = a.stab; fi.sc = sc; fi.fcol = a.fcol; fi.n_in = a.n_in; fi.n_seas = a.n_seas;
+    featurize_cols<CPT>(fi, row, live, part * CPT, vals);
     if (part == 0) s_dv[r] = y_here;
 #pragma unroll
     for (int ch = 0; ch < CPT / 8; ++ch) {
