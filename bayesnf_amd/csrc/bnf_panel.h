@@ -547,6 +547,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   struct LaneCtx {
     int lane, frow, kg;
     const char *h0row, *w00, *w01, *prow;
+    uint32_t w0off;        // byte offset of slab hc's first layer-0 weight fragment in wf0 (uniform)
   };
   auto lane_ctx = [&](int hc = 0) {
     LaneCtx c;
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
     c.h0row = h0p + c.lane * 16;
     c.w00 = wf0 + (size_t)(2 * slab(hc)) * KS0 * 1024 + c.lane * 16;      // layer-0 fragment streams of slab hc
     c.w01 = c.w00 + (size_t)KS0 * 1024;
+    c.w0off = (uint32_t)(2 * slab(hc)) * (uint32_t)KS0 * 1024u;
     c.prow = smem + (rbase + c.frow) * kPitchB + c.kg * 16;   // A fragments of this lane
     return c;
   };
@@ -620,10 +622,12 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
   bf16x8 bres[H0L ? 2 : 1][H0L ? KS0c : 4];     // H0L: this wave's layer-0 weight fragments [column half][k step]
   auto l0_weights = [&](const LaneCtx& L) {
     if constexpr (H0L) {
+      const PanelW w0w = panel_wbase(wf0);
+      const uint32_t o0 = L.w0off;
 #pragma unroll
       for (int u = 0; u < KS0c; ++u) {
-        bres[0][u] = *reinterpret_cast<const bf16x8*>(L.w00 + (size_t)u * 1024);
-        bres[1][u] = *reinterpret_cast<const bf16x8*>(L.w01 + (size_t)u * 1024);
+        bres[0][u] = panel_wload(w0w, o0 + (uint32_t)u * 1024u, (uint32_t)L.lane * 16u);
+        bres[1][u] = panel_wload(w0w, o0 + (uint32_t)(KS0 + u) * 1024u, (uint32_t)L.lane * 16u);
       }
     } else {
       l0_load(blk, L.h0row, L.w00, 0);
@@ -1399,10 +1403,11 @@ __global__ __launch_bounds__(512, 2) void k_panel_fwd_bwd(const PanelArgs a) {
     float* dh0 = a.dH0t + (int64_t)e * a.dh0_batch;
     constexpr int KC = KS1 < 32 ? KS1 : 32;       // weight fragments in registers at a time (128 registers)
     bf16x8 fb[KC];
+    const PanelW wb0w = panel_wbase(wb0);       // (raw buffer loads: no 64-bit VALU address per fragment)
     auto load_b = [&](int t, int k0) {
-      const char* bp = wb0 + ((size_t)(t % ct) * KS1 + k0) * 1024 + lane * 16;
+      const uint32_t o = (uint32_t)((t % ct) * KS1 + k0) * 1024u;   // uniform
 #pragma unroll
-      for (int u = 0; u < KC; ++u) fb[u] = *reinterpret_cast<const bf16x8*>(bp + (size_t)u * 1024);
+      for (int u = 0; u < KC; ++u) fb[u] = panel_wload(wb0w, o + (uint32_t)u * 1024u, (uint32_t)lane * 16u);
     };
     load_b(wave, 0);   // (unconditional: a wave without a first tile -- 64-row panels -- loads a tile it never uses)
     // fused featurisation backward: the column table entries of this wave's first tile and of the final
