@@ -144,6 +144,10 @@ struct bnf_handle {
   int64_t pack_batch[BNF_MAX_LAYERS];
   float* dH0 = nullptr; float* out = nullptr; float* ybat = nullptr; float* loss_raw = nullptr;
   float* vacc = nullptr; float* dv = nullptr;   // output-layer dot accumulator, d loss / d v
+  // read at bnf_create: BNF_VI_SAMPLE_PACK=0 -> k_vi_sample + k_pack_layers instead of the fused sampler;
+  // BNF_VI_KEEP_Z=1 -> every sample is written to theta_c and k_vi_adam recovers the noise from it (round-3 data flow)
+  bool vi_sample_pack = true, vi_keep_z = false;
+  bool fragments_current = false;   // VI: k_vi_sample_pack already wrote this step's weight fragments + scalar table
   bool panel = false;         // row-panel forward + backward kernel (bnf_panel.h): bf16, depth 2, W = 256 / 512
   void* Wf[BNF_MAX_LAYERS]; void* Wb[BNF_MAX_LAYERS];   // fragment-major packed weights
   void* park[BNF_MAX_LAYERS];                            // row-panel pipeline, depth > 2: parked pre-activations of the middle layers
@@ -841,7 +845,7 @@ static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
   LaunchScope ls(h, KID_PACK);
   int tiles = 0;
   const PackJobs jb = pack_jobs(h, &tiles);
-  hipLaunchKernelGGL((k_pack_layers<T>), dim3((unsigned)tiles, (unsigned)nmem), dim3(256), 0, h->stream,
+  hipLaunchKernelGGL((k_pack_layers<T>), dim3((unsigned)tiles * (unsigned)nmem), dim3(256), 0, h->stream,
                      theta, (int64_t)h->Pf, jb, h->nd, h->scal);
 }
 
@@ -889,7 +893,8 @@ static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
 static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs, float c,
                       const LossSink& sink) {
   const int64_t Bp = h->Bp;
-  run_pack_fragments<bf16_t>(h, theta, nmem);     // also fills the member scalar table the next kernels read
+  if (h->fragments_current) h->fragments_current = false;     // the VI sampler packed while it sampled
+  else run_pack_fragments<bf16_t>(h, theta, nmem);            // also fills the member scalar table the next kernels read
   if (!h->fin) {
     LaunchScope ls(h, KID_FEAT);
     dim3 grid(cdiv(h->B, kFeatRows) * (unsigned)nmem);
@@ -1143,6 +1148,37 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
   return BNF_OK;
 }
 
+// ---- VI sampler launch shapes -------------------------------------------------------------------------------
+static ViSegs vi_segments_all(const bnf_handle* h) {
+  ViSegs sg{};
+  sg.n = 1; sg.lo[0] = 0; sg.hi[0] = h->P;
+  return sg;
+}
+// what lies before, between and after the hidden Dense kernels (biases, scalars, the output layer)
+static ViSegs vi_segments_between_kernels(const bnf_handle* h) {
+  ViSegs sg{};
+  int32_t at = 0;
+  for (int l = 0; l < h->L; ++l) {
+    sg.lo[sg.n] = at; sg.hi[sg.n] = h->nd.off_kernel[l]; ++sg.n;
+    at = h->nd.off_kernel[l] + ((l == 0) ? h->F : h->W) * h->W;
+  }
+  sg.lo[sg.n] = at; sg.hi[sg.n] = h->P; ++sg.n;
+  return sg;
+}
+static dim3 vi_sample_grid(const ViSegs& sg, int members) {
+  int32_t longest = 1;
+  for (int i = 0; i < sg.n; ++i) longest = std::max(longest, sg.hi[i] - sg.lo[i]);
+  return dim3(cdiv(cdiv(longest, 4) + 1, 256), (unsigned)members, (unsigned)sg.n);   // + 1: a range may start mid-quad
+}
+// k_vi_sample_pack: row-panel pipeline on the parameter layout itself (no padded copy), every hidden kernel starting on
+// a quad boundary of the noise stream (always, with spec.py's layout), BNF_VI_SAMPLE_PACK=0 restores the two kernels
+static bool vi_sample_pack_ok(const bnf_handle* h) {
+  if (!h->vi_sample_pack || !h->panel || h->pad || h->W % 64 != 0) return false;
+  for (int l = 0; l < h->L; ++l)
+    if ((h->nd.off_kernel[l] + kEpsQuadPhase) % 4 != 0) return false;
+  return true;
+}
+
 static JaxNoise jax_noise_for_step(const bnf_handle* h) {
   JaxNoise jn{};
   if (!h->vi_keys) return jn;
@@ -1163,12 +1199,27 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   if (jn.keys && (jn.row < 0 || jn.row >= h->vi_key_rows))
     return fail(BNF_ERR_STATE, "VI step %lld is outside the noise-key table (%lld rows from step %lld)",
                 (long long)h->adam_t, (long long)h->vi_key_rows, (long long)h->vi_key_t0);
+  // The hidden Dense kernels are sampled by the kernel that also packs them (k_vi_sample_pack) when the step draws the
+  // device generator's noise and runs the row-panel pipeline on the parameter layout itself; k_vi_sample takes the rest
+  // (or, otherwise, everything: k_pack_layers then packs from theta_c as in MAP).
+  const bool fused = vi_sample_pack_ok(h) && !h->ext_eps && !jn.keys;
   {
     LaunchScope ls(h, KID_VISAMPLE);
-    dim3 grid(cdiv(cdiv(h->P, 4), 256), (unsigned)E, (unsigned)((S + 3) / 4));
-    hipLaunchKernelGGL(k_vi_sample, grid, dim3(256), 0, h->stream, mu, rho, h->P, S, h->cfg.seed,
+    const ViSegs segs = fused ? vi_segments_between_kernels(h) : vi_segments_all(h);
+    hipLaunchKernelGGL(k_vi_sample, vi_sample_grid(segs, E), dim3(256), 0, h->stream, mu, rho, h->P, S, h->cfg.seed,
                        h->cfg.member_offset, (uint64_t)step, (uint32_t)STREAM_VI_EPS, h->theta_c,
-                       (int64_t)S * h->P, (int64_t)h->P, h->ext_eps, jn);
+                       (int64_t)S * h->P, (int64_t)h->P, segs, h->ext_eps, jn);
+    if (fused) {
+      int tiles = 0;
+      const PackJobs jb = pack_jobs(h, &tiles);
+      ViSampleArgs sa{};
+      sa.mu = mu; sa.rho = rho; sa.P = h->P; sa.S = S; sa.seed = h->cfg.seed; sa.member_offset = h->cfg.member_offset;
+      sa.step = (uint64_t)step; sa.z = h->theta_c; sa.write_z = h->vi_keep_z ? 1 : 0;
+      hipLaunchKernelGGL((k_vi_sample_pack<bf16_t, BNF_VI_SP_THREADS>), dim3((unsigned)tiles * (unsigned)E),
+                         dim3(BNF_VI_SP_THREADS), 0, h->stream, sa, jb,
+                         h->nd, h->scal);
+      h->fragments_current = true;     // run_panel: this step's fragments and scalar table are already in place
+    }
   }
   const float kl = h->cfg.kl_weight;
   const float c = (float)((double)h->N / (double)h->B / (double)kl);
@@ -1193,7 +1244,10 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   a.bc1 = (float)(1.0 - std::pow(0.9, (double)t));
   a.bc2 = (float)(1.0 - std::pow(0.999, (double)t));
   a.kl_weight = kl; a.loss = loss; a.loss_stride = loss_stride; a.apply = apply ? 1 : 0;
-  a.gmu_out = gmu_out; a.grho_out = grho_out; a.ext_eps = h->ext_eps; a.jn = jn; a.z = h->theta_c;
+  a.gmu_out = gmu_out; a.grho_out = grho_out; a.ext_eps = h->ext_eps; a.jn = jn;
+  // the device generator's noise is made again in k_vi_adam (one Philox call per sample and quad); the caller's or the
+  // reference's stream is recovered from the samples in theta_c
+  a.z = (!h->ext_eps && !jn.keys && !h->vi_keep_z) ? nullptr : h->theta_c;
   // the Dense kernels whose gradient the next step's weight-gradient kernel stores (split-K = 1) need no clearing
   a.n_keep = 0;
   if (!h->pad && !h->adam_clear_all && h->ablate == 0)
@@ -1205,8 +1259,9 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
       }
   {
     LaunchScope ls(h, KID_VIADAM);
-    dim3 grid(cdiv(cdiv(h->P, 4), 256), (unsigned)E);
-    hipLaunchKernelGGL(k_vi_adam, grid, dim3(256), 0, h->stream, a);
+    dim3 grid(cdiv(cdiv(h->P + kEpsQuadPhase, 4), 256), (unsigned)E);
+    if (a.z) hipLaunchKernelGGL(k_vi_adam<false>, grid, dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(k_vi_adam<true>, grid, dim3(256), 0, h->stream, a);
   }
   if (apply) h->adam_t = t;
   return BNF_OK;
@@ -1355,6 +1410,8 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   if (const char* rg = getenv("BNF_TN_RING")) h->tn_ring = atoi(rg);
   if (const char* gm = getenv("BNF_GRAPH")) h->graph_mode = atoi(gm);
   h->adam_clear_all = getenv("BNF_ADAM_CLEAR_ALL") != nullptr;
+  if (const char* v = getenv("BNF_VI_SAMPLE_PACK")) h->vi_sample_pack = atoi(v) != 0;
+  if (const char* v = getenv("BNF_VI_KEEP_Z")) h->vi_keep_z = atoi(v) != 0;
   {
     int want = cfg->pipeline;  // 0 auto, 1 layer kernels with every activation materialised, 3 row-panel kernel
     if (const char* pf = getenv("BNF_PIPELINE")) want = atoi(pf);
@@ -1684,7 +1741,6 @@ int bnf_vi_posterior_draws(bnf_handle* h, int32_t n_draws, float* out) {
   if (n_draws < 1 || n_draws > 65535 || !out) return fail(BNF_ERR_INVALID, "n_draws/out");
   HIPCHK(hipSetDevice(h->cfg.device));
   const int E = h->cfg.members;
-  dim3 grid(cdiv(cdiv(h->P, 4), 256), (unsigned)E, (unsigned)((n_draws + 3) / 4));
   JaxNoise jn{};
   if (h->vi_draw_keys) {
     if (n_draws > h->vi_draw_rows) return fail(BNF_ERR_INVALID, "n_draws exceeds the draw-key table");
@@ -1692,10 +1748,11 @@ int bnf_vi_posterior_draws(bnf_handle* h, int32_t n_draws, float* out) {
     jn.n_leaves = h->n_leaves; jn.S = n_draws; jn.members = E; jn.row = 0;
   }
   // out[d][e][p]: member stride P, sample stride E*P
-  hipLaunchKernelGGL(k_vi_sample, grid, dim3(256), 0, h->stream, h->params,
+  const ViSegs segs = vi_segments_all(h);
+  hipLaunchKernelGGL(k_vi_sample, vi_sample_grid(segs, E), dim3(256), 0, h->stream, h->params,
                      h->params + (int64_t)E * h->P, h->P, n_draws, h->cfg.seed,
                      h->cfg.member_offset, (uint64_t)0, (uint32_t)STREAM_VI_DRAW, out, (int64_t)h->P,
-                     (int64_t)E * h->P, (const float*)nullptr, jn);
+                     (int64_t)E * h->P, segs, (const float*)nullptr, jn);
   HIPCHK(hipGetLastError());
   return BNF_OK;
 }

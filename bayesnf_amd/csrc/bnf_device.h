@@ -177,6 +177,21 @@ __device__ __forceinline__ void store4u(float* p, int nv, const float (&v)[4]) {
   }
 }
 
+// the same with a window: elements [klo, khi) of the four are inside the array (a quad that straddles its start or end)
+template <bool NT = false>
+__device__ __forceinline__ void load4w(const float* p, int klo, int khi, float (&o)[4]) {
+  if (klo <= 0) { load4u<NT>(p, khi, o); return; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (k >= klo && k < khi) ? p[k] : 0.f;
+}
+template <bool NT = false>
+__device__ __forceinline__ void store4w(float* p, int klo, int khi, const float (&v)[4]) {
+  if (klo <= 0) { store4u<NT>(p, khi, v); return; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k >= klo && k < khi) p[k] = v[k];
+}
+
 // raw (undecoded) vectors: issue the load early, decode at the point of use so
 // the compiler does not have to wait for the data right after the load
 struct RawF4 { f32x4 v; };
@@ -548,6 +563,9 @@ __device__ __forceinline__ float wave_min(float v) {
 // of any stream is computable independently -> results do not depend on how
 // members are sharded over GPUs.
 // ---------------------------------------------------------------------------
+#ifndef BNF_PHILOX_ROUNDS
+#define BNF_PHILOX_ROUNDS 10   // the standard count; other values only to price the generator (profiles/r04_panel_ab.md r04p)
+#endif
 struct Philox {
   uint32_t v[4];
 };
@@ -555,7 +573,7 @@ __host__ __device__ __forceinline__ Philox philox4x32(uint32_t c0, uint32_t c1, 
                                                       uint32_t c3, uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < BNF_PHILOX_ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
     const uint32_t n1 = (uint32_t)p1;
@@ -596,9 +614,15 @@ __device__ __forceinline__ float std_normal(uint32_t a, uint32_t b) {
   return sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
 }
 
-// reparameterisation noise eps[member_global][sample][p] of VI step `step`.  One Philox call
-// yields the four normals of samples 4g .. 4g+3 (two Box-Muller pairs, both branches); the
-// hardware log2 / sqrt / sin / cos are plenty for noise (the tests read eps back from the device).
+// reparameterisation noise eps[member_global][sample][p] of VI step `step`.  One Philox call yields the four normals
+// of ONE sample at four consecutive parameters (two Box-Muller pairs, both branches): S calls per four parameters,
+// whatever S is (calls keyed by groups of four SAMPLES spent 8 per four parameters at S = 5, and Philox's 40 quarter-rate
+// integer multiplies were what k_vi_sample was bound by).  Quads are cut at p = 3 (mod 4) -- quad = (p + 1) / 4 --
+// because that is where every hidden Dense kernel starts in the parameter layout (three leading scalars, then leaves
+// whose sizes are multiples of the width: spec.py), so a 64 x 64 tile of a kernel is made of whole quads
+// (k_vi_sample_pack).  The hardware log2 / sqrt / sin / cos are plenty for noise (the tests read eps back from the
+// device: bnf_debug_vi_eps).
+constexpr int kEpsQuadPhase = 1;
 struct Normal4 {
   float v[4];
 };
@@ -608,15 +632,12 @@ __device__ __forceinline__ void box_muller_pair(uint32_t a, uint32_t b, float* n
   *n0 = rad * __builtin_amdgcn_cosf(u2);    // v_cos / v_sin take revolutions
   *n1 = rad * __builtin_amdgcn_sinf(u2);
 }
-__device__ __forceinline__ Philox vi_eps_words(uint64_t seed, uint32_t member_global, uint32_t group,
-                                               uint32_t p, uint64_t step, uint32_t stream) {
-  return philox4x32(p, member_global, (uint32_t)step,
-                    (stream & 0xffu) | (group << 8) | ((uint32_t)(step >> 32) << 20), (uint32_t)seed,
-                    (uint32_t)(seed >> 32));
-}
-__device__ __forceinline__ Normal4 vi_eps4(uint64_t seed, uint32_t member_global, uint32_t group,
-                                           uint32_t p, uint64_t step, uint32_t stream) {
-  const Philox r = vi_eps_words(seed, member_global, group, p, step, stream);
+// the normals of parameters 4 quad - 1 .. 4 quad + 2 (sample < 4096: bits 8..19 of counter word 3)
+__device__ __forceinline__ Normal4 vi_eps_quad(uint64_t seed, uint32_t member_global, uint32_t sample,
+                                               uint32_t quad, uint64_t step, uint32_t stream) {
+  const Philox r = philox4x32(quad, member_global, (uint32_t)step,
+                              (stream & 0xffu) | (sample << 8) | ((uint32_t)(step >> 32) << 20), (uint32_t)seed,
+                              (uint32_t)(seed >> 32));
   Normal4 n;
   box_muller_pair(r.v[0], r.v[1], &n.v[0], &n.v[1]);
   box_muller_pair(r.v[2], r.v[3], &n.v[2], &n.v[3]);
@@ -624,11 +645,9 @@ __device__ __forceinline__ Normal4 vi_eps4(uint64_t seed, uint32_t member_global
 }
 __device__ __forceinline__ float vi_eps(uint64_t seed, uint32_t member_global, uint32_t sample,
                                         uint32_t p, uint64_t step, uint32_t stream) {
-  const Philox r = vi_eps_words(seed, member_global, sample >> 2, p, step, stream);
-  float n0, n1;
-  if (sample & 2u) box_muller_pair(r.v[2], r.v[3], &n0, &n1);
-  else box_muller_pair(r.v[0], r.v[1], &n0, &n1);
-  return (sample & 1u) ? n1 : n0;
+  const uint32_t u = p + (uint32_t)kEpsQuadPhase;
+  const Normal4 n = vi_eps_quad(seed, member_global, sample, u >> 2, step, stream);
+  return n.v[u & 3u];
 }
 
 // ---------------------------------------------------------------------------

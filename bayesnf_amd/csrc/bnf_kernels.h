@@ -803,52 +803,50 @@ __device__ __forceinline__ float hw_sigmoid(float x) {
 }
 __device__ __forceinline__ float vi_sigma(float rho) { return 1e-4f + hw_softplus(rho); }
 
+// parameter ranges [lo, hi) a launch of k_vi_sample covers (one range = everything; the step's sampler leaves the
+// hidden Dense kernels to k_vi_sample_pack and covers what lies between them)
+struct ViSegs {
+  int32_t n;
+  int32_t lo[BNF_MAX_LAYERS + 2], hi[BNF_MAX_LAYERS + 2];
+};
 __global__ __launch_bounds__(256) void k_vi_sample(const float* __restrict__ mu,
                                                    const float* __restrict__ rho, int32_t P,
                                                    int32_t S, uint64_t seed, int64_t member_offset,
                                                    uint64_t step, uint32_t stream,
                                                    float* __restrict__ z, int64_t z_member_stride,
-                                                   int64_t z_sample_stride, const float* __restrict__ ext_eps = nullptr,
+                                                   int64_t z_sample_stride, ViSegs segs,
+                                                   const float* __restrict__ ext_eps = nullptr,
                                                    JaxNoise jn = JaxNoise{}) {
-  // grid: (ceil(ceil(P/4)/256), members, ceil(S/4)): a thread serves four consecutive parameters (16-byte
-  // accesses: load4u / store4u) x the four samples of a group -- one Philox call per parameter and group
-  const int e = blockIdx.y, s0 = blockIdx.z * 4;
-  const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (p0 >= P) return;
-  const int nv = min(4, P - p0);
+  // grid: (blocks over the quads of the longest range, members, ranges): a thread serves one quad of parameters
+  // (vi_eps_quad: p0 = 4 quad - 1 .. + 3; 16-byte accesses, load4w / store4w) for every sample -- one Philox call per
+  // sample
+  const int e = blockIdx.y;
+  const int lo = segs.lo[blockIdx.z], hi = segs.hi[blockIdx.z];
+  const int u0 = ((lo + kEpsQuadPhase) & ~3) + (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int p0 = u0 - kEpsQuadPhase;
+  const int klo = max(0, lo - p0), khi = min(4, hi - p0);
+  if (khi <= klo) return;
   const int64_t i = (int64_t)e * P + p0;
   float m[4], sg[4];
-  load4u(mu + i, nv, m);
-  load4u(rho + i, nv, sg);
-  Normal4 n4[4];
+  load4w(mu + i, klo, khi, m);
+  load4w(rho + i, klo, khi, sg);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    sg[k] = vi_sigma(sg[k]);
-    n4[k] = vi_eps4(seed, (uint32_t)(member_offset + e), (uint32_t)blockIdx.z, (uint32_t)(p0 + k), step, stream);
-  }
-  if (ext_eps) {   // bnf_debug_vi_noise: the caller's standard normals, (members, S, P)
+  for (int k = 0; k < 4; ++k) sg[k] = vi_sigma(sg[k]);
+  for (int s = 0; s < S; ++s) {
+    Normal4 n;
+    if (ext_eps) {          // bnf_debug_vi_noise: the caller's standard normals, (members, S, P)
+      load4w(ext_eps + ((int64_t)e * S + s) * P + p0, klo, khi, n.v);
+    } else if (jn.keys) {   // the reference's stream (jaxseed.vi_noise_keys)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      float ev[4];
-      load4u(ext_eps + ((int64_t)e * S + min(s0 + ks, S - 1)) * P + p0, nv, ev);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) n4[k].v[ks] = ev[k];
+      for (int k = 0; k < 4; ++k) n.v[k] = (k >= klo && k < khi) ? jax_normal(jn, e, s, p0 + k) : 0.f;
+    } else {
+      n = vi_eps_quad(seed, (uint32_t)(member_offset + e), (uint32_t)s, (uint32_t)(u0 >> 2), step, stream);
     }
-  } else if (jn.keys) {   // the reference's stream (jaxseed.vi_noise_keys)
+    float zv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        if (k < nv && s0 + ks < S) n4[k].v[ks] = jax_normal(jn, e, s0 + ks, p0 + k);
+    for (int k = 0; k < 4; ++k) zv[k] = m[k] + sg[k] * n.v[k];
+    store4w(z + (int64_t)e * z_member_stride + (int64_t)s * z_sample_stride + p0, klo, khi, zv);
   }
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-    if (s0 + ks < S) {
-      float zv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) zv[k] = m[k] + sg[k] * n4[k].v[ks];
-      store4u(z + (int64_t)e * z_member_stride + (int64_t)(s0 + ks) * z_sample_stride + p0, nv, zv);
-    }
 }
 
 struct ViAdamArgs {
@@ -862,31 +860,43 @@ struct ViAdamArgs {
   float* gmu_out; float* grho_out;  // debug: (members, P) each
   const float* ext_eps;             // bnf_debug_vi_noise: (members, S, P) standard normals instead of the generator's
   JaxNoise jn;                      // the reference's stream when jn.keys != null
-  const float* z;                   // (members*S, P) the samples k_vi_sample wrote for this step (theta_c): the noise is
-                                    // recovered from them as (z - mu) / sigma instead of being generated a second time
+  const float* z;                   // null: the device generator's noise, made again here.  Else (members*S, P), the samples
+                                    // k_vi_sample wrote for this step (theta_c): the noise is recovered as (z - mu) / sigma
   int32_t n_keep;                   // parameter ranges whose sample gradients the next step STORES (weight-gradient
   int32_t keep_lo[BNF_MAX_LAYERS], keep_hi[BNF_MAX_LAYERS];   // kernels without split-K): not cleared here
 };
 
-__global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
-  // grid: (ceil(ceil(P/4)/256), members): a thread owns four consecutive parameters -- every access is 16 bytes
-  // per lane (load4u), which is what this kernel is bound by: at C3/8 it reads 2 x 267 MB of sample gradients and
-  // samples and reads + writes 6 x 53 MB of optimiser state (3.2 TB/s with 4-byte accesses)
+#ifndef BNF_VIADAM_INFLIGHT
+#define BNF_VIADAM_INFLIGHT 1   // samples whose gradient loads are in flight together: 1 -> 78 registers, 6 waves per SIMD (C3/8: 179 us; 4 -> 90 registers, 208 us)
+#endif
+#ifndef BNF_VIADAM_OCC
+#define BNF_VIADAM_OCC 4
+#endif
+template <bool REGEN>
+__global__ __launch_bounds__(256, BNF_VIADAM_OCC) void k_vi_adam(ViAdamArgs a) {
+  constexpr int NF = BNF_VIADAM_INFLIGHT;
+  // grid: (ceil(ceil((P + 1)/4)/256), members): a thread owns one quad of the noise stream -- parameters 4 t - 1 .. 4 t + 2
+  // (vi_eps_quad); every access is 16 bytes per lane (load4w), which is what this kernel is bound by: at C3/8 it reads
+  // 267 MB of sample gradients and reads + writes 6 x 53 MB of optimiser state
   __shared__ float red[4];
   const int e = blockIdx.y;
-  const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int u0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int p0 = u0 - kEpsQuadPhase;
+  const int klo = max(0, -p0), khi = min(4, a.P - p0);
   float lterm = 0.f;
-  if (p0 < a.P) {
-    const int nv = min(4, a.P - p0);
+  if (khi > klo) {
     const int64_t i = (int64_t)e * a.P + p0;
     float mu[4], rho[4], sig[4], inv_sig[4], loc[4];
     float gmu[4] = {0.f, 0.f, 0.f, 0.f}, grho[4] = {0.f, 0.f, 0.f, 0.f}, e2[4] = {0.f, 0.f, 0.f, 0.f}, lpr[4] = {0.f, 0.f, 0.f, 0.f};
-    load4u(a.mu + i, nv, mu);
-    load4u(a.rho + i, nv, rho);
-    // The step's noise is NOT generated a second time (Philox + Box-Muller, or threefry + erfinv for the
-    // reference's stream: that was most of this kernel's 0.40 ms at C3/8, VALU-bound): k_vi_sample left
-    // z_s = mu + sigma eps_s in theta_c and nothing has written it since, so eps_s = (z_s - mu) / sigma --
-    // exact up to the rounding of z_s (|z| 6e-8 / sigma absolute on a unit normal).
+    load4w(a.mu + i, klo, khi, mu);
+    load4w(a.rho + i, klo, khi, rho);
+    // The step's noise: with the device generator (a.z == null) the quad's S Philox calls are simply made again -- one
+    // call per sample and four parameters hides under this kernel's memory time, and the S x P samples need not exist
+    // in memory at all for the Dense kernels (k_vi_sample_pack writes only their bf16 fragments).  With the caller's
+    // noise or the reference's stream (threefry + erfinv: too dear to run twice) k_vi_sample left z_s = mu + sigma eps_s
+    // in theta_c and nothing has written it since, so eps_s = (z_s - mu) / sigma -- exact up to the rounding of z_s
+    // (|z| 6e-8 / sigma absolute on a unit normal).
+    constexpr bool regen = REGEN;     // (a.z == null)
     bool clear[4], all_clear = true, any_clear = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -899,22 +909,24 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
       any_clear = any_clear || clear[k];
     }
     const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < a.S; s0 += 4) {
-      float gl[4][4], zs[4][4];   // the likelihood gradients and samples of four samples in flight together
+    for (int s0 = 0; s0 < a.S; s0 += NF) {
+      float gl[NF][4], zs[NF][4];   // the likelihood gradients and samples of NF samples in flight together
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < NF; ++ks) {
         const int64_t gi = ((int64_t)e * a.S + min(s0 + ks, a.S - 1)) * a.P + p0;
-        load4u(a.grad + gi, nv, gl[ks]);
-        load4u(a.z + gi, nv, zs[ks]);
+        load4w(a.grad + gi, klo, khi, gl[ks]);
+        if constexpr (!regen) load4w(a.z + gi, klo, khi, zs[ks]);
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < NF; ++ks) {
         const int s = s0 + ks;
         if (s >= a.S) break;
+        Normal4 n;
+        if constexpr (regen) n = vi_eps_quad(a.seed, (uint32_t)(a.member_offset + e), (uint32_t)s, (uint32_t)(u0 >> 2), a.step, STREAM_VI_EPS);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float eps = (zs[ks][k] - mu[k]) * inv_sig[k];
-          const float z = zs[ks][k] - loc[k];
+          const float eps = regen ? n.v[k] : (zs[ks][k] - mu[k]) * inv_sig[k];
+          const float z = (regen ? mu[k] + sig[k] * eps : zs[ks][k]) - loc[k];
           // Logistic(loc, 1) prior: d(-log p)/dz = tanh(z/2), log p = -z - 2 softplus(-z);
           // both from u = exp(-|z|)
           const float u = hw_exp_neg_abs(z);
@@ -927,11 +939,11 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
         if (any_clear) {
           float* gp = a.grad + ((int64_t)e * a.S + s) * a.P + p0;
           if (all_clear) {
-            store4u(gp, nv, zero4);
+            store4w(gp, klo, khi, zero4);
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              if (k < nv && clear[k]) gp[k] = 0.f;
+              if (k >= klo && k < khi && clear[k]) gp[k] = 0.f;
           }
         }
       }
@@ -939,8 +951,8 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
     const float invS = 1.f / (float)a.S;
     float m1[4], v1[4], m2[4], v2[4];
     if (a.apply) {
-      load4u(a.m_mu + i, nv, m1); load4u(a.v_mu + i, nv, v1);
-      load4u(a.m_rho + i, nv, m2); load4u(a.v_rho + i, nv, v2);
+      load4w(a.m_mu + i, klo, khi, m1); load4w(a.v_mu + i, klo, khi, v1);
+      load4w(a.m_rho + i, klo, khi, m2); load4w(a.v_rho + i, klo, khi, v2);
     }
     const float ibc1 = 1.0f / a.bc1, ibc2 = 1.0f / a.bc2;
 #pragma unroll
@@ -948,7 +960,7 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
       gmu[k] *= invS;
       grho[k] = hw_sigmoid(rho[k]) * (grho[k] * invS - __builtin_amdgcn_rcpf(sig[k]));
       // mean_s [ log q(z_s) - log p(z_s) ] for this coordinate
-      if (k < nv)
+      if (k >= klo && k < khi)
         lterm += (-0.5f * e2[k] * invS - 0.69314718055994530942f * __builtin_amdgcn_logf(sig[k]) - 0.918938533204672742f) - lpr[k] * invS;
       if (a.apply) {
         m1[k] = 0.9f * m1[k] + 0.1f * gmu[k]; v1[k] = 0.999f * v1[k] + 0.001f * gmu[k] * gmu[k];
@@ -958,13 +970,13 @@ __global__ __launch_bounds__(256) void k_vi_adam(ViAdamArgs a) {
       }
     }
     if (a.apply) {
-      store4u(a.mu + i, nv, mu);
-      store4u(a.rho + i, nv, rho);
-      store4u<true>(a.m_mu + i, nv, m1); store4u<true>(a.v_mu + i, nv, v1);     // touched once per step: written through
-      store4u<true>(a.m_rho + i, nv, m2); store4u<true>(a.v_rho + i, nv, v2);
+      store4w(a.mu + i, klo, khi, mu);
+      store4w(a.rho + i, klo, khi, rho);
+      store4w<true>(a.m_mu + i, klo, khi, m1); store4w<true>(a.v_mu + i, klo, khi, v1);     // touched once per step: written through
+      store4w<true>(a.m_rho + i, klo, khi, m2); store4w<true>(a.v_rho + i, klo, khi, v2);
     } else {
-      store4u(a.gmu_out + i, nv, gmu);
-      store4u(a.grho_out + i, nv, grho);
+      store4w(a.gmu_out + i, klo, khi, gmu);
+      store4w(a.grho_out + i, klo, khi, grho);
     }
   }
   const float s = wave_sum(lterm);

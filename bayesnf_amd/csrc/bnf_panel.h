@@ -137,7 +137,7 @@ struct PackJobs {
 // Workgroup 0 of a member also fills the member's row of the transformed-scalar table
 // (k_member_scalars folded in: one launch and one dependent-launch gap less per step).
 // the 8 forward and 8 backward fragments of the 64 x 64 tile of layer l's kernel staged in `tile` (origin k0, n0)
-template <typename T>
+template <typename T, int NT = 256>
 __device__ __forceinline__ void pack_tile_fragments(const float (&tile)[64][65], const PackJobs& jb, int l, int64_t e,
                                                     int k0, int n0, int tid, const float* th) {
   const int W = jb.W;
@@ -152,8 +152,8 @@ __device__ __forceinline__ void pack_tile_fragments(const float (&tile)[64][65],
   T* wb = (T*)jb.wb[l] + e * jb.batch[l];
   const int KSf = jb.n_pad[l] / 16, KSb = W / 16;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int q = tid + 256 * h;            // 512 lane vectors per layout
+  for (int h = 0; h < 512 / NT; ++h) {
+    const int q = tid + NT * h;             // 512 lane vectors per layout
     const int frag = q >> 6, fl = q & 63;
     float v[8];
     {  // forward: Bt[n][k] = K[k][n]; fragment (n/32, k/16), lane = n%32 + 32*((k%16)/8)
@@ -181,23 +181,33 @@ __device__ __forceinline__ void pack_tile_fragments(const float (&tile)[64][65],
     }
   }
 }
-__device__ __forceinline__ void pack_tile_of(const PackJobs& jb, int bx, int* l_out, int* k0, int* n0) {
+// grid of the two packing kernels: members x tiles in one dimension, XCD-aware -- the tiles next to each other along a
+// kernel row run on the SAME XCD back to back, so the 128-byte lines two tiles share (a tile row is 256 bytes starting
+// 12 bytes into a line: kernels start at p = 3 mod 4) meet in one L2 instead of being fetched by, or leaving, two XCDs
+// as partial lines (C3/8: sample + pack 194 -> 152 us, pack alone 116 -> 110 us)
+struct PackItem { int e, l, k0, n0; bool first; };
+__device__ __forceinline__ PackItem pack_item_of(const PackJobs& jb) {
+  const int n_tiles = jb.tile0[jb.n_layers];
+  const uint32_t w = xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = (int)(w % (uint32_t)n_tiles);
+  PackItem it;
+  it.e = (int)(w / (uint32_t)n_tiles);
   int l = 0;
   while (l + 1 < jb.n_layers && bx >= jb.tile0[l + 1]) ++l;
   const int t = bx - jb.tile0[l], tn = jb.W / 64;
-  *l_out = l; *k0 = (t / tn) * 64; *n0 = (t % tn) * 64;      // tile origin: K rows (fan-in), K columns
+  it.l = l; it.k0 = (t / tn) * 64; it.n0 = (t % tn) * 64;      // tile origin: K rows (fan-in), K columns
+  it.first = bx == 0 && threadIdx.x == 0;
+  return it;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ theta, int64_t theta_stride,
                                                      PackJobs jb, NetDev nd, float* __restrict__ scal) {
   __shared__ float tile[64][65];
-  const int e = blockIdx.y;
-  if (scal && blockIdx.x == 0 && threadIdx.x == 0) member_scalars_row(nd, theta + (int64_t)e * theta_stride, scal + (int64_t)e * kScalStride);
-  int l, k0, n0;
-  pack_tile_of(jb, (int)blockIdx.x, &l, &k0, &n0);
-  const int W = jb.W;
-  const float* K = theta + (int64_t)e * theta_stride + jb.off_kernel[l];
+  const PackItem it = pack_item_of(jb);
+  const float* th = theta + (int64_t)it.e * theta_stride;
+  if (scal && it.first) member_scalars_row(nd, th, scal + (int64_t)it.e * kScalStride);
+  const float* K = th + jb.off_kernel[it.l];
   const int tid = threadIdx.x;
   // 16 bytes per lane (K starts at an arbitrary 4-byte aligned offset of the member's parameters: load4u);
   // sixteen lanes cover a 256-byte row of the tile, a wave four rows per access
@@ -205,16 +215,84 @@ __global__ __launch_bounds__(256) void k_pack_layers(const float* __restrict__ t
   for (int i = 0; i < 4; ++i) {
     const int r = (tid >> 4) + 16 * i, c = (tid & 15) * 4;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (k0 + r < jb.n_in[l]) load4u(K + (int64_t)(k0 + r) * W + n0 + c, 4, v);
+    if (it.k0 + r < jb.n_in[it.l]) load4u(K + (int64_t)(it.k0 + r) * jb.W + it.n0 + c, 4, v);
 #pragma unroll
     for (int j = 0; j < 4; ++j) tile[r][c + j] = v[j];
   }
   __syncthreads();
-  pack_tile_fragments<T>(tile, jb, l, e, k0, n0, tid, theta + (int64_t)e * theta_stride);
+  pack_tile_fragments<T>(tile, jb, it.l, it.e, it.k0, it.n0, tid, th);
+}
+
+// VI: sample AND pack in one pass over (mu, rho) of the hidden Dense kernels (inference.py:687-720 draws
+// z = mu + sigma eps leaf by leaf; the forward contraction then wants bf16 fragments of it).  A workgroup owns a
+// 64 x 64 tile of one member's kernel for ALL S samples: mu and sigma stay in registers (16 + 16 per lane), every
+// sample costs one Philox call per quad (vi_eps_quad; the tile's quads are whole: kEpsQuadPhase), goes out as f32
+// (theta_c: k_vi_adam recovers eps from it) and through an LDS tile (two in turn: one barrier per sample) into the
+// 8 + 8 fragments of network e S + s.  Against k_vi_sample + k_pack_layers this never re-reads the S x P samples
+// (C3/8: 260 MB of 880 MB) and is one launch less.  Everything else of the parameter vector (biases, scalars, the
+// output layer) is k_vi_sample's, launched BEFORE this kernel: the layer-0 fold and the member-scalar table read those
+// samples here.  Measured at C3/8 (profiles/r04_panel_ab.md r04p): 152 us against 82 + 110; neither the generator
+// (7 Philox rounds: same time) nor HBM (4.1 TB/s) nor the barriers (a barrier-free form on wave-private 32 x 32
+// sub-tiles: 157 us) bounds it; more waves per SIMD spill (104 registers).
+#ifndef BNF_VI_Z_NT
+#define BNF_VI_Z_NT 0   // 1: the f32 samples leave non-temporally (measured: 190 vs 152 us at C3/8 -- partial lines)
+#endif
+struct ViSampleArgs {
+  const float* mu; const float* rho;
+  int32_t P, S;
+  uint64_t seed; int64_t member_offset; uint64_t step;
+  float* z;                 // (members * S, P): the samples of the other leaves (k_vi_sample's); this kernel's own go there
+  int32_t write_z;          // only when something reads them back (k_vi_adam does not with the device generator)
+};
+#ifndef BNF_VI_SP_THREADS
+#define BNF_VI_SP_THREADS 512   // 512: two quads per lane, 62 registers (256: four, 104; C3/8 115 vs 108 us)
+#endif
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void k_vi_sample_pack(ViSampleArgs a, PackJobs jb, NetDev nd, float* __restrict__ scal) {
+  constexpr int NI = 1024 / NT;   // quads per lane
+  __shared__ float tile[2][64][65];
+  const PackItem it = pack_item_of(jb);
+  const int e = it.e, l = it.l, tid = threadIdx.x;
+  const int c = (tid & 15) * 4;
+  float m[NI][4], sg[NI][4];
+  int32_t pq[NI];            // parameter index of this lane's quad in row i (-1: a pad row of layer 0)
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int r = (tid >> 4) + (NT / 16) * i;
+    pq[i] = (it.k0 + r < jb.n_in[l]) ? jb.off_kernel[l] + (it.k0 + r) * jb.W + it.n0 + c : -1;
+    if (pq[i] >= 0) {
+      load4u(a.mu + (int64_t)e * a.P + pq[i], 4, m[i]);
+      load4u(a.rho + (int64_t)e * a.P + pq[i], 4, sg[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sg[i][j] = vi_sigma(sg[i][j]);
+    }
+  }
+  for (int s = 0; s < a.S; ++s) {
+    const int64_t en = (int64_t)e * a.S + s;
+    float* zn = a.z + en * a.P;
+    float (&tl)[64][65] = tile[s & 1];
+    if (scal && it.first) member_scalars_row(nd, zn, scal + en * kScalStride);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = (tid >> 4) + (NT / 16) * i;
+      float zv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (pq[i] >= 0) {
+        const Normal4 n = vi_eps_quad(a.seed, (uint32_t)(a.member_offset + e), (uint32_t)s,
+                                      (uint32_t)(pq[i] + kEpsQuadPhase) >> 2, a.step, STREAM_VI_EPS);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zv[j] = m[i][j] + sg[i][j] * n.v[j];
+        if (a.write_z) store4u<BNF_VI_Z_NT != 0>(zn + pq[i], 4, zv);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tl[r][c + j] = zv[j];
+    }
+    __syncthreads();
+    pack_tile_fragments<T, NT>(tl, jb, l, en, it.k0, it.n0, tid, zn);
+  }
 }
 
 #ifndef BNF_EPI_FENCE_EVERY
-#define BNF_EPI_FENCE_EVERY 1   // scheduling fence after every 4-row group of an epilogue (2: after every second one)
+#define BNF_EPI_FENCE_EVERY 1  // scheduling fence after every 4-row group of an epilogue (2: after every second one)
 #endif
 #ifndef BNF_PANEL_PRIO
 #define BNF_PANEL_PRIO 0

@@ -351,3 +351,42 @@ def test_panel_featurises_its_own_rows_like_k_featurize(width, degrees, mode, ba
   assert np.max(np.abs(ga - gb)) <= 1e-5 * max(1.0, np.max(np.abs(gb)))    # (f32 atomics order only)
   np.testing.assert_allclose(a[3], b[3], rtol=1e-5)
   assert np.max(np.abs(a[4] - b[4])) < 1e-4
+
+
+def test_vi_sampler_data_flows_agree(monkeypatch):
+  """Round 4: with the device generator the VI step samples the Dense kernels in the kernel that packs them
+  (k_vi_sample_pack: the f32 samples of the kernels never reach memory) and k_vi_adam makes the noise again from the
+  counter-based stream.  Against the two-kernel flow (BNF_VI_SAMPLE_PACK=0: k_vi_sample writes every sample, k_pack_layers
+  packs them) the fused one is the SAME arithmetic on the same normals -- identical losses and parameters; against the
+  round-3 flow (BNF_VI_KEEP_Z=1: noise recovered as (z - mu) / sigma from the stored samples) it differs by the rounding
+  of z only.  The noise the tests read back (bnf_debug_vi_eps) is the noise both flows draw: one step's d mu equals the
+  mean over samples of the likelihood + prior gradient only if eps is the stream's."""
+  n_rows, E, S, B = 700, 3, 5, 300
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=512, depth=3)
+  res = {}
+  for name, env in (('fused', {}), ('two_kernels', {'BNF_VI_SAMPLE_PACK': '0'}), ('keep_z', {'BNF_VI_KEEP_Z': '1'}),
+                    ('round3', {'BNF_VI_SAMPLE_PACK': '0', 'BNF_VI_KEEP_Z': '1'})):
+    for k in ('BNF_VI_SAMPLE_PACK', 'BNF_VI_KEEP_Z'):
+      monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)
+    eng = _engine(net, X, y, mode='vi', members=E, vi_samples=S, kl_weight=0.2, seed=11, learning_rate=0.01,
+                  batch=B, compute_dtype='bf16', pipeline='panel')
+    eng.init_params(0.0)
+    eps = eng.debug_vi_eps(0)
+    step = eng.debug_loss_and_grad(0, 0)
+    losses = eng.train(0, 5)
+    torch.cuda.synchronize()
+    res[name] = (eps, step, losses.cpu().numpy(), eng.get_params())
+    eng.close()
+  f = res['fused']
+  assert f[0].shape == (E, S, model.P) and abs(float(f[0].std()) - 1.0) < 5e-3 and abs(float(f[0].mean())) < 5e-3
+  for other in ('two_kernels', 'keep_z', 'round3'):
+    o = res[other]
+    np.testing.assert_array_equal(f[0], o[0])                      # one stream
+    same = other == 'two_kernels'      # same arithmetic; only the order of the gradient atomics differs from run to run
+    np.testing.assert_allclose(f[1][0], o[1][0], rtol=1e-6 if same else 1e-5)
+    for k in (0, 1):                                               # d mu, d rho of the first step
+      np.testing.assert_allclose(f[1][1][k], o[1][1][k], rtol=0, atol=(2e-5 if same else 5e-4) * np.abs(o[1][1][k]).max())
+    np.testing.assert_allclose(f[2], o[2], rtol=1e-5 if same else 1e-4)
+    assert np.abs(f[3] - o[3]).max() <= (1e-3 if same else 5e-3)      # five Adam steps of 0.01 on top of that
