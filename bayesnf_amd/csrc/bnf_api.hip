@@ -853,6 +853,9 @@ static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
 // row-panel pipeline (bf16, depth 2): pack fragments -> featurise -> k_panel_fwd_bwd ->
 // featurise backward -> gemm_tn weight gradients
 // ---------------------------------------------------------------------------
+#ifndef BNF_PANEL_BM64
+#define BNF_PANEL_BM64 0
+#endif
 template <int WN, int RT, bool H0L, bool DEEP, int CH, int FP, bool F0>
 static void launch_panel_f(bnf_handle* h, const PanelArgs& pa) {
   constexpr int kLds = panel_lds_bytes(WN, RT, H0L, CH, FP);
@@ -946,6 +949,10 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
     } else {
       launch_panel<8, 2, false, 2>(h, pa);
     }
+  } else if (h->W == 512 && BNF_PANEL_BM64 != 0 && getenv("BNF_PANEL_BM64") && !h->h0l) {
+    // experiment (profiles/r04_panel_ab.md r04s): 64-row panels, two workgroups per CU (4 waves per SIMD, 128 registers)
+    pa.panels = (int32_t)(Bp / panel_rows(8, 2));
+    launch_panel<8, 2, false>(h, pa);
   } else if (h->W == 512) {
     pa.panels = (int32_t)(Bp / panel_rows(8, 4));
     if (h->h0l) {
