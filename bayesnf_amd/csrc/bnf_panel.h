@@ -532,7 +532,7 @@ __device__ __forceinline__ void l0_mma(f32x16& a0, const L0Blk& bk) {
 // roles SWAPPED (weights as A, panel rows as B): a lane then owns ONE row and four consecutive hidden units per
 // register group, and the bf16 panel store is one ds_write_b64 per four elements instead of four ds_write_b16.
 template <int WN, int RT, bool H0L, bool DEEP = false, int CH = 1, int FP = 64, bool F0 = false>
-__global__ __launch_bounds__(512, (RT * CH == 2) ? 4 : 2) void k_panel_fwd_bwd(const PanelArgs a) {
+__global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_panel_fwd_bwd(const PanelArgs a) {   // (4: the r04s experiment form only)
   static_assert(!F0 || H0L, "the folded layer 0 needs the LDS feature panel");
   constexpr int W = 64 * WN * CH, RB = 8 / WN, WR = 32 * RT, BM = WR * RB;   // WR = rows per wave
   constexpr int kSlabs = WN * CH;           // 64-column slabs of the layer
