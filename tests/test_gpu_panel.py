@@ -90,6 +90,30 @@ def test_panel_vi_step():
     assert not bad, (k, bad)
 
 
+@pytest.mark.parametrize('width,depth,S,n_rows', [(256, 2, 1, 300), (512, 2, 7, 260), (1024, 3, 2, 200)])
+def test_panel_vi_step_vs_oracle(width, depth, S, n_rows):
+  """The VI step of the row-panel pipeline against the float64 oracle on the noise the device drew (bnf_debug_vi_eps): the
+  Dense kernels' samples exist only as the bf16 fragments k_vi_sample_pack wrote, k_vi_adam makes the noise again -- loss and
+  d mu / d rho at the panel kernel's bf16 bars, for one sample, for a count that is no multiple of four, and for the
+  width-1024 form."""
+  E = 2
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth)
+  eng = _engine(net, X, y, mode='vi', members=E, vi_samples=S, kl_weight=0.2, seed=5, learning_rate=0.01,
+                compute_dtype='bf16', pipeline='panel')
+  eng.init_params(0.0)
+  p0 = eng.get_params().astype(np.float64)
+  eps0 = eng.debug_vi_eps(0)
+  assert eps0.shape == (E, S, model.P)
+  loss_d, g_d = eng.debug_loss_and_grad(0, 0)
+  eng.close()
+  loss_o, gmu_o, grho_o = O.vi_loss_and_grad(model, p0[0], p0[1], eps0, X, y, n_rows, 0.2)
+  np.testing.assert_allclose(loss_d, loss_o * 0.2, rtol=5e-3)
+  bad = {k: v for k, v in _leaf_errs(model, g_d[0], gmu_o).items() if v > 6e-2}
+  assert not bad, ('gmu', bad)
+  bad = {k: v for k, v in _leaf_errs(model, g_d[1], grho_o).items() if v > 6e-2}
+  assert not bad, ('grho', bad)
+
+
 def test_panel_repeated_step_is_reproducible():
   net, model, X, y = util.make_problem(n_rows=2000, width=512, depth=2)
   eng = _engine(net, X, y, members=4, seed=1, compute_dtype='bf16', pipeline='panel')

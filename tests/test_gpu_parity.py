@@ -251,11 +251,15 @@ def test_vi_step_and_training_fp32(width):
   eng.close()
 
 
-def test_vi_gradients_with_sigma_at_its_floor():
-  """k_vi_adam recovers the step's noise from the stored samples, eps = (z - mu) / sigma, instead of generating it a second
-  time.  That quotient loses ulp(z) / sigma: with sigma at its floor (rho = -12: sigma = 1e-4 + softplus(-12) = 1.06e-4) and
-  |mu| ~ 1 the recovered eps is off by ~6e-4 -- the worst case the parametrisation allows (sigma >= 1e-4).  The gradients
-  wrt mu and rho must still meet bars next to the oracle's, which uses the exact noise."""
+@pytest.mark.parametrize('keep_z', ['1', '0'])
+def test_vi_gradients_with_sigma_at_its_floor(keep_z, monkeypatch):
+  """keep_z = 1 (BNF_VI_KEEP_Z=1; always the flow of the caller's / the reference's noise): k_vi_adam recovers the step's
+  noise from the stored samples, eps = (z - mu) / sigma, instead of generating it a second time.  That quotient loses
+  ulp(z) / sigma: with sigma at its floor (rho = -12: sigma = 1e-4 + softplus(-12) = 1.06e-4) and |mu| ~ 1 the recovered
+  eps is off by ~6e-4 -- the worst case the parametrisation allows (sigma >= 1e-4).  The gradients wrt mu and rho must
+  still meet bars next to the oracle's, which uses the exact noise.  keep_z = 0 (the default with the device generator since
+  round 4): the noise is made again from the counter-based stream -- exact -- and meets the same bars."""
+  monkeypatch.setenv('BNF_VI_KEEP_Z', keep_z)
   n_rows, E, S = 150, 2, 3
   net, model, X, y = util.make_problem(n_rows=n_rows, width=64, depth=2)
   eng = _engine(net, X, y, mode='vi', members=E, vi_samples=S, kl_weight=0.2, seed=3, learning_rate=0.01, compute_dtype='fp32')
