@@ -1149,7 +1149,7 @@ static int step_map(bnf_handle* h, int64_t epoch, int64_t step, const LossSink& 
       }
   {
     LaunchScope ls(h, KID_ADAM);
-    hipLaunchKernelGGL(k_adam_map, dim3(cdiv(cdiv(h->P, 4), 256), (unsigned)E), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(k_adam_map, dim3(cdiv(cdiv(h->P, 4), 256 * BNF_ADAM_QUADS), (unsigned)E), dim3(256), 0, h->stream, a);
   }
   if (apply) h->adam_t = t;
   return BNF_OK;

@@ -735,12 +735,18 @@ __global__ void k_step_advance(StepState* st) {
 #endif
 // A thread owns four consecutive parameters (16-byte accesses at any 4-byte aligned address: load4u);
 // the last thread of a member takes the P % 4 tail element by element.
+#ifndef BNF_ADAM_QUADS
+#define BNF_ADAM_QUADS 4   // quads of parameters per thread, one after the other (a block covers 1024 x this many consecutive
+                           // parameters): C2 105.6 -> 85.5 us (1: 105.6, 2: 86.6, 3: 85.2, 4: 85.5, 8: 91.5), C5/8 41 -> 34
+#endif
 __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
   __shared__ float red[4];
   const int e = blockIdx.y;
-  const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const float bc1 = a.st ? a.st->bc1 : a.bc1, bc2 = a.st ? a.st->bc2 : a.bc2;
   float lp = 0.f;
+#pragma unroll
+  for (int qd = 0; qd < BNF_ADAM_QUADS; ++qd) {
+  const int p0 = ((blockIdx.x * BNF_ADAM_QUADS + qd) * blockDim.x + threadIdx.x) * 4;
   if (p0 < a.P) {
     const int nv = min(4, a.P - p0);
     const int64_t i0 = (int64_t)e * a.stride + p0;
@@ -777,6 +783,7 @@ __global__ __launch_bounds__(256) void k_adam_map(AdamArgs a) {
       store4u<BNF_ADAM_NT != 0>(a.m + i0, nv, m);
       store4u<BNF_ADAM_NT != 0>(a.v + i0, nv, v);
     }
+  }
   }
   const float s = wave_sum(lp);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -869,6 +876,8 @@ struct ViAdamArgs {
 #ifndef BNF_VIADAM_INFLIGHT
 #define BNF_VIADAM_INFLIGHT 1   // samples whose gradient loads are in flight together: 1 -> 78 registers, 6 waves per SIMD (C3/8: 179 us; 4 -> 90 registers, 208 us)
 #endif
+// (several quads per thread, one after the other -- what took k_adam_map from 106 to 86 us -- cost this kernel registers
+// and time: 179 -> 191 (2) -> 199 us (4) at C3/8, profiles/r04_panel_ab.md r04ab)
 #ifndef BNF_VIADAM_OCC
 #define BNF_VIADAM_OCC 4
 #endif
