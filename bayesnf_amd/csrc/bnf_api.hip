@@ -147,7 +147,6 @@ struct bnf_handle {
   // read at bnf_create: BNF_VI_SAMPLE_PACK=0 -> k_vi_sample + k_pack_layers instead of the fused sampler;
   // BNF_VI_KEEP_Z=1 -> every sample is written to theta_c and k_vi_adam recovers the noise from it (round-3 data flow)
   bool vi_sample_pack = true, vi_keep_z = false;
-  bool fragments_current = false;   // VI: k_vi_sample_pack already wrote this step's weight fragments + scalar table
   bool panel = false;         // row-panel forward + backward kernel (bnf_panel.h): bf16, depth 2, W = 256 / 512
   void* Wf[BNF_MAX_LAYERS]; void* Wb[BNF_MAX_LAYERS];   // fragment-major packed weights
   void* park[BNF_MAX_LAYERS];                            // row-panel pipeline, depth > 2: parked pre-activations of the middle layers
@@ -893,11 +892,13 @@ static void launch_panel(bnf_handle* h, const PanelArgs& pa) {
   else launch_panel_d<WN, RT, H0L, true, CH, FP>(h, pa);
 }
 
+// fragments_packed: the caller has ALREADY written this step's weight fragments and scalar table (the VI sampler packs
+// while it samples: k_vi_sample_pack) -- an argument of this call, not handle state, so that no early return or partial
+// replay between the sampler and this call can leave a stale "already packed" behind
 static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc& rs, float c,
-                      const LossSink& sink) {
+                      const LossSink& sink, bool fragments_packed = false) {
   const int64_t Bp = h->Bp;
-  if (h->fragments_current) h->fragments_current = false;     // the VI sampler packed while it sampled
-  else run_pack_fragments<bf16_t>(h, theta, nmem);            // also fills the member scalar table the next kernels read
+  if (!fragments_packed) run_pack_fragments<bf16_t>(h, theta, nmem);   // also fills the member scalar table the next kernels read
   if (!h->fin) {
     LaunchScope ls(h, KID_FEAT);
     dim3 grid(cdiv(h->B, kFeatRows) * (unsigned)nmem);
@@ -1225,7 +1226,6 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
       hipLaunchKernelGGL((k_vi_sample_pack<bf16_t, BNF_VI_SP_THREADS>), dim3((unsigned)tiles * (unsigned)E),
                          dim3(BNF_VI_SP_THREADS), 0, h->stream, sa, jb,
                          h->nd, h->scal);
-      h->fragments_current = true;     // run_panel: this step's fragments and scalar table are already in place
     }
   }
   const float kl = h->cfg.kl_weight;
@@ -1233,7 +1233,7 @@ static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride
   LossSink sink{loss, loss_stride, kl / (float)S, nullptr};
   const float* thf = fw_theta(h, h->theta_c, h->Ev);
   if (h->panel) {
-    run_panel(h, thf, h->Ev, rs, c, sink);
+    run_panel(h, thf, h->Ev, rs, c, sink, /*fragments_packed=*/fused);
   } else {
     run_pack<T>(h, thf, h->Ev);
     run_forward<T>(h, thf, h->Ev, rs, h->X, h->stab, h->y, h->B, true);
@@ -2173,8 +2173,20 @@ int rccl_load() {
   g_rccl.CommInitAll = (int (*)(void**, int, const int*))dlsym(lib, "ncclCommInitAll");
   g_rccl.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
   g_rccl.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
-  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
+  // the FULL capability is decided here (bnf_comm_available), so that every rank / caller agrees up front: the
+  // per-rank entry points and the one-process group forms (ncclCommInitAll / ncclGroupStart / ncclGroupEnd)
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy ||
+      !g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
+    g_rccl = RcclApi{};
     return fail(BNF_ERR_STATE, "librccl.so lacks an expected nccl* symbol");
+  }
+  if (int (*get_version)(int*) = (int (*)(int*))dlsym(lib, "ncclGetVersion")) {   // NCCL API >= 2.7: ncclChar all-gather,
+    int v = 0;                                                                    // group semantics as used here
+    if (get_version(&v) == 0 && v > 0 && v < 2700) {
+      g_rccl = RcclApi{};
+      return fail(BNF_ERR_STATE, "librccl.so reports NCCL API version %d (< 2.7)", v);
+    }
+  }
   g_rccl.lib = lib;
   return BNF_OK;
 }
@@ -2236,8 +2248,6 @@ int bnf_comm_create_local(int32_t n, const int32_t* devices, bnf_comm** out) {
     for (int j = 0; j < i; ++j)
       if (devices[i] == devices[j]) return fail(BNF_ERR_INVALID, "device %d listed twice: one RCCL rank per device", devices[i]);
   if (int rc = rccl_load()) return rc;
-  if (!g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd)
-    return fail(BNF_ERR_STATE, "librccl.so lacks ncclCommInitAll / ncclGroupStart / ncclGroupEnd");
   int prev = 0;
   (void)hipGetDevice(&prev);
   std::vector<void*> comms((size_t)n, nullptr);
@@ -2258,9 +2268,17 @@ int bnf_comm_create_local(int32_t n, const int32_t* devices, bnf_comm** out) {
 int bnf_allgather_group(int32_t n, bnf_comm* const* comms, const void* const* send, void* const* recv,
                         size_t bytes_per_rank, void* const* streams) {
   if (!comms || !send || !recv || n < 1) return fail(BNF_ERR_INVALID, "null");
-  for (int i = 0; i < n; ++i)
+  for (int i = 0; i < n; ++i) {
     if (!comms[i] || !send[i] || !recv[i]) return fail(BNF_ERR_INVALID, "null entry %d", i);
-  if (!g_rccl.GroupStart || !g_rccl.GroupEnd) return fail(BNF_ERR_STATE, "librccl.so not loaded");
+    // the set bnf_comm_create_local made, whole and in order: a partial or permuted set would leave ranks of the
+    // communicator without their call inside the group and ncclGroupEnd waiting for them
+    if (comms[i]->world != n || comms[i]->rank != i)
+      return fail(BNF_ERR_INVALID, "comms[%d] is rank %d of %d: the whole local set in rank order is expected (n = %d)", i,
+                  comms[i]->rank, comms[i]->world, n);
+    // (streams == NULL or streams[i] == NULL: that device's default stream -- a valid hipStream_t, what a torch host
+    // passes for its default current stream)
+  }
+  if (!g_rccl.lib) return fail(BNF_ERR_STATE, "librccl.so not loaded");
   int prev = 0;
   (void)hipGetDevice(&prev);
   if (int rc = g_rccl.GroupStart()) return rccl_fail("ncclGroupStart", rc);

@@ -632,11 +632,15 @@ __device__ __forceinline__ void box_muller_pair(uint32_t a, uint32_t b, float* n
   *n0 = rad * __builtin_amdgcn_cosf(u2);    // v_cos / v_sin take revolutions
   *n1 = rad * __builtin_amdgcn_sinf(u2);
 }
-// the normals of parameters 4 quad - 1 .. 4 quad + 2 (sample < 4096: bits 8..19 of counter word 3)
+// the normals of parameters 4 quad - 1 .. 4 quad + 2.  Counter word 3 = stream (bits 0..7) | sample (bits 8..23: up to
+// 65,535 -- bnf_vi_posterior_draws' limit) | bits 32..39 of the step (bits 24..31): the fields do not overlap (round 4
+// put the step's high bits at bit 20, which met the sample field from sample 4096 on; unchanged values for every
+// sample < 4096 at step < 2^32, i.e. for every stream drawn so far).  ABI 5 changelog: round 4 re-keyed this stream per
+// (sample, quad) -- 'philox' VI results for a given seed differ from rounds 1-3.
 __device__ __forceinline__ Normal4 vi_eps_quad(uint64_t seed, uint32_t member_global, uint32_t sample,
                                                uint32_t quad, uint64_t step, uint32_t stream) {
   const Philox r = philox4x32(quad, member_global, (uint32_t)step,
-                              (stream & 0xffu) | (sample << 8) | ((uint32_t)(step >> 32) << 20), (uint32_t)seed,
+                              (stream & 0xffu) | ((sample & 0xffffu) << 8) | ((uint32_t)(step >> 32) << 24), (uint32_t)seed,
                               (uint32_t)(seed >> 32));
   Normal4 n;
   box_muller_pair(r.v[0], r.v[1], &n.v[0], &n.v[1]);

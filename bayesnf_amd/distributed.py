@@ -8,7 +8,9 @@ communicates during training (/root/reference/src/bayesnf/inference.py:573-579, 
     open one engine handle per device -- `BNF_DEVICES=0,1,...` selects / orders them, default all
     visible -- device g owns the members `[g * E/G, (g + 1) * E/G)`, every device's whole
     optimisation is enqueued from its own host thread before anything is waited for, and the results
-    are assembled with the leading dims `(G, E/G)` by peer copies to the first device;
+    are assembled with the leading dims `(G, E/G)` by peer copies to the first device (default), or --
+    `BNF_GATHER=rccl`, opt-in until it has run on a box with two or more GPUs -- by one grouped RCCL
+    all-gather over a local communicator set (`bnf_comm_create_local` + `bnf_allgather_group`);
   * one process per GPU under `torch.distributed.run` (backend "nccl" == RCCL over xGMI): rank r
     owns device LOCAL_RANK and the members of global device index r; the only collective is the
     final all-gather of fitted parameters / predictive means.
@@ -113,17 +115,21 @@ _gather_note = {}
 def gather_shards(parts: list[torch.Tensor]) -> torch.Tensor:
   """One tensor (...) per local shard -> (device_count, ...) : the reference's implicit pmap output
   gather (inference.py:452,486-492).  torch.distributed: one all-gather (`all_gather_stack`).  One process with
-  several DISTINCT devices: ONE grouped RCCL all-gather over the local communicator set (`_native.allgather_local`:
-  bnf_comm_create_local + bnf_allgather_group -- every device receives every block, the first device's copy is
-  returned); `BNF_GATHER=peer`, a device named twice (BNF_DEVICES=0,0), CPU tensors or an RCCL set-up failure
-  fall back to peer copies to the first shard's device (`last_gather()` says which ran)."""
+  several devices: peer copies to the first shard's device (the default: the only in-process path that has run on
+  hardware).  `BNF_GATHER=rccl` opts in to ONE grouped RCCL all-gather over the local communicator set
+  (`_native.allgather_local`: bnf_comm_create_local + bnf_allgather_group -- every device allocates a
+  (device_count, ...) receive buffer and receives every block, the first device's copy is returned).  That path
+  needs DISTINCT cuda devices; it has only ever run with one device or against the gloo stand-in (no box with two
+  GPUs was available to any round), a hang inside ncclCommInitAll / ncclGroupEnd would stall `fit()` after the
+  training has finished, hence opt-in; an RCCL set-up exception falls back to the peer copies
+  (`last_gather()` says which ran)."""
   if is_distributed():
     assert len(parts) == 1
     return all_gather_stack(parts[0])
   dev0 = parts[0].device
   devs = [p.device for p in parts]
   if (len(parts) > 1 and all(d.type == 'cuda' for d in devs) and len(set(devs)) == len(devs)
-      and os.environ.get('BNF_GATHER', 'rccl') != 'peer'):
+      and os.environ.get('BNF_GATHER', 'peer') == 'rccl'):
     try:
       from . import _native
       sends = [p.contiguous() for p in parts]

@@ -11,17 +11,24 @@ to the HIP library instead of jax.
 
 Differences a caller can see:
   * `seed` is an int or a length-2 uint32 array (a `jax.random.PRNGKey` also
-    works, it is such an array).  MAP / MLE draw their initial parameters from the
-    reference's own streams for that seed (threefry + TFP seed chain, `jaxseed`: a
-    full-batch fit reproduces the reference's golden predictions); minibatch shuffles
-    and everything VI draws come from this package's counter-based generator.
+    works, it is such an array).  With `init_rng='jax'` (the default) every
+    estimator draws from the reference's own streams for that seed (threefry + the
+    TFP seed chain, `jaxseed`): the initial particles of MAP / MLE and their
+    per-member per-epoch minibatch shuffles (`jax.random.permutation`); the initial
+    surrogate means, the optimisation noise and the posterior draws of a full-batch
+    VI fit -- full-batch fits reproduce the reference's golden predictions.  Only a
+    VI fit WITH `batch_size` keeps this package's counter-based generator for its
+    noise and row batches (which split of the step seed the reference uses there is
+    pinned by no golden).  `init_rng='philox'` selects the device generator everywhere.
   * limits of the HIP engine, checked when the estimator is constructed / fitted
     (the reference accepts any size): `depth` <= 8 (any `width` up to 8192 -- widths that are
     not a multiple of 64 run zero-padded inside the engine, same model and parameters);
     at most 8 feature columns, 96 distinct seasonal frequencies, 16 interactions;
     at most 512 (fp32: 256) features in total; `batch_size` <= number of rows.
   * the leading `(num_devices, ensemble_size // num_devices)` dimensions use
-    `num_devices = torch.distributed world size` (one process per GPU).
+    `num_devices = distributed.device_count()`: the devices this ONE process drives
+    (every visible GPU, or `BNF_DEVICES`; the reference's `jax.local_devices()` shape),
+    or the torch.distributed world size under a one-process-per-GPU launcher.
   * `likelihood_model()` returns `bayesnf_amd.inference.EnsembleLikelihood`,
     not a TFP distribution.
 """

@@ -323,7 +323,10 @@ int bnf_allgather(bnf_comm* c, const void* send, void* recv, size_t bytes_per_ra
 /* ONE process driving n devices -- the reference's own shape (`jax.pmap` over `jax.local_devices()`,
  * inference.py:573-579,445): `bnf_comm_create_local` makes one communicator per listed device in one call
  * (ncclCommInitAll; out[n]; a device listed twice is refused), `bnf_allgather_group` enqueues every local rank's
- * all-gather in one group (send[i] / recv[i] / streams[i] on comms[i]'s device; recv[i] receives all n blocks). */
+ * all-gather in one group (send[i] / recv[i] / streams[i] on comms[i]'s device; recv[i] receives all n blocks;
+ * `comms` must be the WHOLE set of one bnf_comm_create_local call in rank order -- checked, BNF_ERR_INVALID
+ * otherwise: a partial set would leave ncclGroupEnd waiting; streams == NULL or a NULL entry = the default stream).
+ * `bnf_comm_available` already requires the group symbols, so callers agree on the full capability up front. */
 int bnf_comm_create_local(int32_t n, const int32_t* devices, bnf_comm** out);
 int bnf_allgather_group(int32_t n, bnf_comm* const* comms, const void* const* send, void* const* recv,
                         size_t bytes_per_rank, void* const* streams);
