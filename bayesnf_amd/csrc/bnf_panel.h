@@ -332,6 +332,9 @@ __global__ __launch_bounds__(NT) void k_vi_sample_pack(ViSampleArgs a, PackJobs 
 #ifndef BNF_PANEL_PKCLAMP
 #define BNF_PANEL_PKCLAMP 1  // backward epilogues: min(e, 1) of an element pair by one packed multiply with the clamp modifier
 #endif
+#ifndef BNF_PANEL_L1T
+#define BNF_PANEL_L1T 1      // round 5: the LAST hidden layer on transposed tiles with its activation evaluated ONCE (see k_panel_fwd_bwd)
+#endif
 constexpr int kPanelPD = BNF_PANEL_PD;       // weight fragments in flight per stream; must divide W / 16 (2: +2 % panel time, 8: equal -- gpurun_out/r03ar)
 
 // RT = 32-row tiles per wave (4: one workgroup per CU, 256 registers; 2: two workgroups per CU, 128)
@@ -930,6 +933,41 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
     __builtin_amdgcn_s_setprio(0);
 #endif
   };
+  // L1T: the copy of the dZ_L panel to HBM (for the weight gradient).  The backward epilogue of the last layer has no
+  // arithmetic left to hide 128 KiB of stores behind (HBM takes ~13 B/clk/CU with every CU storing: the epilogue measured
+  // 10.4k cycles with the copy inside it, 7.6k without), and stores issued DURING the next contraction sit in front of its
+  // weight-ring loads in the wave's in-order vmcnt (+2.7k cycles on that contraction: profiles/r05_panel_ab.md).  But the
+  // contraction that reads this panel is finished early by the four waves that run it at priority (BNF_PANEL_CPRIO: the
+  // second-dispatched half; 11k against 17.5k cycles), which then sit at the barrier: THEY copy the whole panel -- their own
+  // 64 columns and those of the wave they share a SIMD with -- while the other four are still multiplying.  Only LDS
+  // reads (complete before the barrier: lds_barrier) and fire-and-forget stores.
+  auto copy_panel_by_early_waves = [&](bf16_t* dst) {
+    if (BNF_ABL(a, 8)) return;
+    if ((BNF_PANEL_CPRIO == 2) == (wave >= 4)) return;       // (the waves that ran the contraction WITHOUT priority: busy)
+    const int lane = opaque_lane(tid) & 63;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int pw = b == 0 ? wave : (wave ^ 4);              // this wave's slab, then its SIMD partner's
+      const int prb = (pw / WN) * WR, pcb = (pw % WN) * CH * 64;
+      bf16_t* d = dst + (int64_t)e * a.act_batch + (int64_t)(m0 + prb) * W + pcb;   // uniform
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d, 0, 0x7fffffff, 0x00020000);
+      const bf16_t* sp = tile + prb * kPitchE + pcb;
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        u32x4 v[4 * CH];
+#pragma unroll
+        for (int u = 0; u < 4 * CH; ++u) {
+          const int idx = lane + 64 * u, row = i * 32 + (idx >> (3 + (CH - 1))), pc = idx & (8 * CH - 1);   // 16-byte pieces: 8 CH per row
+          v[u] = *reinterpret_cast<const u32x4*>(sp + row * kPitchE + pc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4 * CH; ++u) {
+          const int idx = lane + 64 * u, row = i * 32 + (idx >> (3 + (CH - 1))), pc = idx & (8 * CH - 1);
+          __builtin_amdgcn_raw_buffer_store_b128(v[u], rs, (uint32_t)(row * W * 2 + pc * 16), 0, BNF_PANEL_NT ? 2 : 0);
+        }
+      }
+    }
+  };
   auto contract_all = [&](const char* wp) { contract_all_t(wp, std::false_type{}); };
   ring_prefetch(wfl(1), opaque_lane(tid) & 63);   // in flight across the barrier
   lds_barrier();
@@ -1004,11 +1042,111 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   }
 
   // =============================== last hidden layer forward ==================================
+  // L1T (round 5): the last hidden layer runs on TRANSPOSED tiles (MFMA operand roles swapped like the F0 layer-0 forms:
+  // lane <-> row, registers 4 rg .. 4 rg + 3 <-> four consecutive hidden units) and its activation is evaluated ONCE:
+  //   * the forward epilogue (here) leaves  dg = (gamma_L k_o / sqrt W) act'(A_L)  in the accumulators -- dZ_L is then one
+  //     multiply with the row's dv --, writes H_{L+1} = act(A_L) as bf16 into the (dead) panel image with 8-byte stores,
+  //     and forms the per-ROW dots in-lane (no LDS round trip: a lane owns its row): sum_c k' s, sum_c k' r -- the output
+  //     dot AND the d alpha dot follow from these two -- and sum_c dg t (d gamma_L);
+  //   * the backward epilogue evaluates NO activation: z = dv dg, convert, store;
+  //   * the two per-COLUMN sums that are left go to the idle matrix pipe: d k_o = dv^T H_{L+1} and d b_L = 1^T dZ_L as
+  //     bf16 MFMAs over the wave's own 64 columns of the panel (ds_read_b64_tr_b16 fragments; a wave reads only what it
+  //     wrote itself, so no barrier is added).
+  // Per element pair: 17 VALU + 4 transcendentals forward, 2 VALU backward, where the r04 kernel spent 9 + 4 and 18 + 4
+  // (+ the 64-row LDS scratch of the row dots, + 2-byte panel stores): profiles/r05_panel_ab.md.
+  constexpr bool kL1T = BNF_PANEL_L1T != 0 && CH == 1;   // (CH = 2, the W = 1024 form: both slabs' accumulators + the column constants spill)
   if (!BNF_PANEL_ZPEEL) zero_acc();
-  contract_all(wfl(LL));
+  contract_all_t(wfl(LL), std::integral_constant<bool, kL1T>{});
   BNF_MARK(a, 3);
-  lds_barrier();     // every wave is done reading H1: the panel doubles as row-dot scratch below
+  // L1T: the per-register column constants of slab 0 (bias and output kernel of the wave's 64 columns: a lane holds the
+  // 32 columns of its half) are requested before the barrier -- the ring and fragment registers are dead -- and arrive
+  // under the wait
+  f32x4 cst_b[kL1T ? 8 : 1], cst_k[kL1T ? 8 : 1];
+  auto l1_consts = [&](int hc) {
+    const int kg = (opaque_lane(tid) & 63) >> 5;
+    const float* bp = th + a.off_bias[LL] + slab(hc) * 64 + 4 * kg;
+    const float* kp = th + a.off_ko + slab(hc) * 64 + 4 * kg;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {      // u = 4 j + rg: columns j * 32 + 8 rg + 4 kg + 0..3
+      cst_b[u] = *reinterpret_cast<const f32x4u*>(bp + (u >> 2) * 32 + (u & 3) * 8);
+      cst_k[u] = *reinterpret_cast<const f32x4u*>(kp + (u >> 2) * 32 + (u & 3) * 8);
+    }
+  };
+  if constexpr (kL1T) l1_consts(0);
+  lds_barrier();     // every wave is done reading H1: the panel doubles as row-dot scratch below (L1T: receives H_{L+1})
 
+  // L1T: per-row partial dots of this wave's slab(s), kept in registers from the forward to the backward epilogue
+  // (the row's dv is known only after the row phase): wrow = sum_c k' (s + 2 r) / gamma_L (d alpha), urow = sum_c dg t
+  float wrow[kL1T ? CH : 1][kL1T ? RT : 1], urow[kL1T ? CH : 1][kL1T ? RT : 1];
+  if constexpr (kL1T) {
+    float ksum_wave = 0.f;   // sum of k_o over all of this wave's columns
+#pragma unroll
+    for (int hc = 0; hc < CH; ++hc) {
+      const int cbase = slab(hc) * 64;
+      f32x16 (&acc)[RT][2] = accs[hc];
+      const LaneCtx L = lane_ctx();
+      const int lane = L.lane, frow = L.frow, kg = L.kg;
+      if (hc > 0) l1_consts(hc);
+      const float gs = gamma1 * inv_sw * kLog2e;
+      const float gl2 = gamma1 * kLog2e, gkw = gamma1 * inv_sw;
+      // t = A log2(e) = acc gs + gbp;  k' = gamma_L k_o / sqrt W  (per register pair: [j][2 rg + q / 2])
+      f32x2 gbp[2][8], kvp[2][8];
+      f32x2 ks2 = {0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        gbp[u >> 2][(u & 3) * 2] = f32x2{cst_b[u][0], cst_b[u][1]} * gl2;
+        gbp[u >> 2][(u & 3) * 2 + 1] = f32x2{cst_b[u][2], cst_b[u][3]} * gl2;
+        kvp[u >> 2][(u & 3) * 2] = f32x2{cst_k[u][0], cst_k[u][1]} * gkw;
+        kvp[u >> 2][(u & 3) * 2 + 1] = f32x2{cst_k[u][2], cst_k[u][3]} * gkw;
+        ks2 += f32x2{cst_k[u][0], cst_k[u][1]} + f32x2{cst_k[u][2], cst_k[u][3]};
+      }
+      float ksum = ks2.x + ks2.y;                    // sum of k_o over this lane's 32 columns ...
+      ksum += __shfl_xor(ksum, 32, 64);              // ... and over the slab's 64
+      ksum_wave += ksum;
+      if (hc == CH - 1 && lane == 0) s_sc[48 + wave] = ksum_wave;   // (read by thread 0 after the barriers below)
+      const float inv_g1 = 1.0f / gamma1;
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        f32x2 ds2 = {0.f, 0.f}, dr2 = {0.f, 0.f}, du2 = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bf16_t* rowp = tile + (rbase + i * 32 + frow) * kPitchE + cbase + j * 32 + 4 * kg;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            f32x2 hq[2];
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+              const f32x2 raw = {acc[i][j][rg * 4 + q], acc[i][j][rg * 4 + q + 1]};
+              const f32x2 kp = kvp[j][rg * 2 + (q >> 1)];
+              const f32x2 tv = raw * gs + gbp[j][rg * 2 + (q >> 1)];
+              const ActCore2 c = panel_act_core2(tv);
+              const f32x2 sv = kLn2 * c.mxt + c.dl;                                   // elu + 1
+              hq[q >> 1] = ak.c1 * c.r + (ak.alpha * sv + ak.c0);                   // act(A)
+              ds2 += kp * sv;
+              dr2 += kp * c.r;
+              const f32x2 dg = kp * (ak.c2 * (c.r - c.r * c.r) + ak.alpha * c.dl);  // k' act'(A)
+              du2 += dg * tv;
+              acc[i][j][rg * 4 + q] = dg.x;
+              acc[i][j][rg * 4 + q + 1] = dg.y;
+            }
+            store_quad_pk(rowp + 8 * rg, hq[0].x, hq[0].y, hq[1].x, hq[1].y);
+            asm volatile("" : "+v"(ds2), "+v"(dr2), "+v"(du2));
+            if (BNF_EPI_FENCE_EVERY == 1 || (rg & 1)) __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // this lane's half of the row (32 of the slab's 64 columns) + the other half's
+        float dsv = ds2.x + ds2.y, drv = dr2.x + dr2.y, duv = du2.x + du2.y;
+        dsv += __shfl_xor(dsv, 32, 64);
+        drv += __shfl_xor(drv, 32, 64);
+        duv += __shfl_xor(duv, 32, 64);
+        // sum_c k_o act = (c0 sum k' + c1 sum k' r + alpha sum k' s) sqrt W / gamma_L: what the row phase adds up over the slabs
+        if (kg == 0)
+          s_part[(rbase + i * 32 + frow) * kSlabs + slab(hc)] = ak.c0 * ksum + (ak.c1 * drv + ak.alpha * dsv) * (inv_g1 / inv_sw);
+        wrow[hc][i] = (dsv + 2.f * drv) * inv_g1;     // sum_c (k_o / sqrt W) (elu - tanh + 2)
+        urow[hc][i] = duv;
+      }
+    }
+  } else {
   // ---- A1 = gamma1 (acc / sqrt W + b1) kept in the accumulators; row dots act(A1) . k_o ----
   float ksum_wave = 0.f;   // sum of k_o over all of this wave's columns
 #pragma unroll
@@ -1079,6 +1217,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
       __builtin_amdgcn_wave_barrier();
     }
   }
+  }
   BNF_MARK(a, 4);
   lds_barrier();
   // the panel's scalar sums of the row phase (thread 0): loss and the gradients of the output-layer scalars
@@ -1128,6 +1267,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
         s_dvsum = dvv;
       }
       s_dv[tid] = dvv;
+      if constexpr (kL1T) reinterpret_cast<bf16_t*>(s_col)[tid].bits = f32_to_bf16_bits(dvv);   // A fragments of d k_o = dv^T H (s_col is idle until the next layer's sums)
       const float t0 = panel_wave_sum(ll), t1 = panel_wave_sum(s_doutv), t2 = panel_wave_sum(s_dvsum), t3 = panel_wave_sum(s_par),
                   t4 = panel_wave_sum(s_infl);
       if ((tid & 63) == 0) {
@@ -1139,6 +1279,115 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   lds_barrier();
   BNF_MARK(a, 5);
   if (tid == 0) row_scalars_out();
+  if constexpr (kL1T) {
+    // ---- L1T: dZ_L = dv dg (no activation left to evaluate); d k_o and d b_L on the matrix pipe --------------------
+    float wsa_all = 0.f, wsg_all = 0.f;
+#pragma unroll
+    for (int hc = 0; hc < CH; ++hc) {
+      const int cbase = slab(hc) * 64;
+      f32x16 (&acc)[RT][2] = accs[hc];
+      const LaneCtx L = lane_ctx();
+      const int lane = L.lane, frow = L.frow, kg = L.kg;
+      typedef __attribute__((address_space(3))) char lds_char_t;
+      const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char_t*)smem;
+      // Column sums over the wave's WR rows x 64 columns of the panel as v_mfma_f32_16x16x32_bf16 (K = 32 rows per
+      // instruction, four 16-column tiles = four independent accumulator chains).  B fragments by ds_read_b64_tr_b16: within
+      // a 16-lane group lane i receives element i % 4 of the 8-byte datum addressed by lane 4 j + i / 4 (j = 0 .. 3; measured
+      // with scripts/probes/tr_read_probe.hip) -- so with lane p of the group addressing row base + p / 4, columns
+      // 4 (p % 4) .. + 3, lane i ends up with rows base .. base + 3 of column i; the group's base is 8 (lane / 16) + 4 t:
+      // lane (n = lane % 16, kg4 = lane / 16) holds rows 32 ks + 8 kg4 + 0 .. 7 of column n -- a plain B fragment.
+      // All reads of a sum are issued at once (inline asm: hipcc must not put its own waits between them), one wait.
+      const uint32_t tr0 = lds0 + (uint32_t)((rbase + (lane >> 4) * 8 + ((lane & 15) >> 2)) * kPitchB + (cbase + (lane & 3) * 4) * 2);
+      const uint32_t dv0 = lds0 + (uint32_t)(reinterpret_cast<const char*>(s_col) - smem) + (uint32_t)((rbase + (lane >> 4) * 8) * 2);
+      constexpr int KS32 = WR / 32;
+      auto colsum = [&](float (&out)[4], auto with_dv) {
+        constexpr bool kDv = decltype(with_dv)::value;
+        u32x2_t rr[KS32][8];        // [k step][2 t + 4 ... ]: index 2 nt + t
+        u32x4 av[KS32];
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) {
+          const uint32_t ad = tr0 + (uint32_t)(ks * 32 * kPitchB);
+          rr[ks][0] = lds_tr16_b64<0>(ad);
+          rr[ks][1] = lds_tr16_b64<4 * kPitchB>(ad);
+          rr[ks][2] = lds_tr16_b64<32>(ad);
+          rr[ks][3] = lds_tr16_b64<4 * kPitchB + 32>(ad);
+          rr[ks][4] = lds_tr16_b64<64>(ad);
+          rr[ks][5] = lds_tr16_b64<4 * kPitchB + 64>(ad);
+          rr[ks][6] = lds_tr16_b64<96>(ad);
+          rr[ks][7] = lds_tr16_b64<4 * kPitchB + 96>(ad);
+          if constexpr (kDv) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(av[ks]) : "v"(dv0), "n"(ks * 64) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 d[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) d[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) {
+          asm volatile("" : "+v"(rr[ks][0]), "+v"(rr[ks][1]), "+v"(rr[ks][2]), "+v"(rr[ks][3]), "+v"(rr[ks][4]),
+                            "+v"(rr[ks][5]), "+v"(rr[ks][6]), "+v"(rr[ks][7]));   // (ordered behind the wait)
+          u32x4 aw = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};    // ones
+          if constexpr (kDv) {
+            asm volatile("" : "+v"(av[ks]));
+            aw = av[ks];
+          }
+          const bf16x8 fa = __builtin_bit_cast(bf16x8, aw);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const u32x4 wv = {rr[ks][2 * nt].x, rr[ks][2 * nt].y, rr[ks][2 * nt + 1].x, rr[ks][2 * nt + 1].y};
+            d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, __builtin_bit_cast(bf16x8, wv), d[nt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) out[nt] = d[nt][0];   // every output row holds the sums: lanes 0 .. 15 <-> column 16 nt + lane
+      };
+      float dvr[RT];
+      float wsa = 0.f, wsg = 0.f;
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        dvr[i] = s_dv[rbase + i * 32 + frow];
+        wsa += dvr[i] * wrow[hc][i];
+        wsg += dvr[i] * urow[hc][i];
+      }
+      // d k_o sqrt W = dv^T H_{L+1} over this wave's rows: A = dv (bf16) replicated over the 16 output rows
+      float dks[4];
+      colsum(dks, std::true_type{});
+      asm volatile("" : "+v"(dks[0]), "+v"(dks[1]), "+v"(dks[2]), "+v"(dks[3]));
+      BNF_MARK(a, 6);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bf16_t* rowp = tile + (rbase + i * 32 + frow) * kPitchE + cbase + j * 32 + 4 * kg;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const f32x2 z0 = f32x2{acc[i][j][rg * 4], acc[i][j][rg * 4 + 1]} * dvr[i];
+            const f32x2 z1 = f32x2{acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]} * dvr[i];
+            store_quad_pk(rowp + 8 * rg, z0.x, z0.y, z1.x, z1.y);
+          }
+        }
+      }
+      // (the copy of dZ_L to HBM: copy_panel_by_early_waves, behind the next contraction, which reads this panel)
+      BNF_MARK(a, 7);
+      if (hc == CH - 1) ring_prefetch(wbl(LL), lane);   // the accumulators are dead: weights of dH = dZ K^T on their way
+      // d b_L = 1^T dZ_L over the slab this wave has just written (its own LDS writes: in order behind them)
+      float dbs[4];
+      colsum(dbs, std::false_type{});
+      if (lane < 16) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          atomicAdd(&gr[a.off_ko + cbase + nt * 16 + lane], dks[nt] * inv_sw);
+          atomicAdd(&gr[a.off_bias[LL] + cbase + nt * 16 + lane], dbs[nt]);
+        }
+      }
+      // both halves of the wave hold every row's dots: count them once
+      wsa_all += panel_wave_sum(kg == 0 ? wsa : 0.f);
+      wsg_all += panel_wave_sum(kg == 0 ? (kLn2 / gamma1) * wsg : 0.f);
+      if (hc == CH - 1 && lane == 0) {
+        s_sc[32 + wave * 2] = wsa_all;
+        s_sc[33 + wave * 2] = wsg_all;
+      }
+    }
+  } else {
   // ---- dZ1 = gamma1 (dv k_o / sqrt W) act'(A1) -> panel; column sums and scalar gradients ----
   float wsa_all = 0.f, wsg_all = 0.f;
 #pragma unroll
@@ -1223,9 +1472,10 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
       s_sc[33 + wave * 2] = wsg_all;
     }
   }
-  BNF_MARK(a, 6);
+  }
+  BNF_MARK(a, 8);
   lds_barrier();
-  for (int c = tid; c < W; c += 512) {
+  for (int c = tid; !kL1T && c < W; c += 512) {   // (L1T: the waves added their column sums themselves)
     float b = 0.f, k = 0.f;
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -1266,6 +1516,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
       dst[1] = __builtin_nontemporal_load(src + 64);
     };
     park_load(park_ptr(l, 0), 0, pv[0]);
+    if (kL1T && l == LL - 1) copy_panel_by_early_waves(a.dZ[LL]);   // (behind that load: its wait does not cover these stores)
     lds_barrier();     // every wave is done reading dZ_{l+1}: the panel is overwritten with dZ_l
     float sa_all = 0.f, sg_all = 0.f;
 #pragma unroll
@@ -1348,12 +1599,13 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   }
 
   // =============================== dH1 = dZ1 K1^T ============================================
-  BNF_MARK(a, 7);
+  BNF_MARK(a, 9);
   if (!BNF_PANEL_ZPEEL) zero_acc();
   contract_all_t(wbl(1), std::integral_constant<bool, F0>{});   // (F0: transposed accumulators for the swapped dZ0 epilogue)
-  BNF_MARK(a, 8);
+  BNF_MARK(a, 10);
   const LaneCtx L2 = lane_ctx(0);
   l0_weights(L2);                         // first operands of the A0 recomputation, in flight across the barrier
+  if (kL1T && LL == 1) copy_panel_by_early_waves(a.dZ[1]);   // (behind those loads: their wait does not cover these stores)
   lds_barrier();     // every wave is done reading dZ1: the panel is overwritten with dZ0 (and s_col / s_sc reused)
 
   // ---- dZ0 = gamma0 (dH1 / sqrt W) act'(A0), A0 recomputed per 32-row block ----------------
@@ -1452,7 +1704,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
       }
     }
     if (!(BNF_PANEL_DK0 && a.dk0_fused)) block_to_global(L, a.dZ[0], RT - 1, cbase);
-    BNF_MARK(a, 9);
+    BNF_MARK(a, 11);
     if constexpr (!F0) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -1497,7 +1749,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
         if (wave < FP / 64) md_red = *reinterpret_cast<const int4*>(a.fbmeta + 4 * (wave * 64 + lane));
       }
     }
-    BNF_MARK(a, 10);
+    BNF_MARK(a, 12);
     lds_barrier();
     // the column sums and scalars of the dZ0 epilogue are complete: their atomics leave now, under the
     // contraction below, instead of in a serial tail after it
@@ -1635,7 +1887,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
     }
   }
 #endif
-  BNF_MARK(a, 11);
+  BNF_MARK(a, 13);
   if constexpr (H0L) {
     if (a.fbmeta) {
       lds_barrier();
@@ -1670,8 +1922,8 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
       }
     }
   }
-  BNF_MARK(a, 12);
-  BNF_MARK(a, 13);
+  BNF_MARK(a, 14);
+  BNF_MARK(a, 15);
 }
 
 }  // namespace bnf

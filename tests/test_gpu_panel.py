@@ -414,3 +414,30 @@ def test_vi_sampler_data_flows_agree(monkeypatch):
       np.testing.assert_allclose(f[1][1][k], o[1][1][k], rtol=0, atol=(2e-5 if same else 5e-4) * np.abs(o[1][1][k]).max())
     np.testing.assert_allclose(f[2], o[2], rtol=1e-5 if same else 1e-4)
     assert np.abs(f[3] - o[3]).max() <= (1e-3 if same else 5e-3)      # five Adam steps of 0.01 on top of that
+
+
+@pytest.mark.parametrize('width,depth,n_rows', [(512, 2, 1000), (256, 2, 700), (512, 3, 600)])
+def test_bias_and_output_kernel_gradients_keep_explicit_bars(width, depth, n_rows, monkeypatch):
+  """Leaves the row-panel kernel sums over bf16-ROUNDED panel values (f32 accumulation on the matrix pipe) instead of over
+  its f32 registers: `Dense_0/bias` since round 4 (the ones row of the layer-0 weight gradient, F0 forms; the forward bias is
+  a bf16 hi + lo pair), `Dense_L/bias` (1^T dZ_L) and the output kernel (dv^T H_{L+1}) since round 5 (L1T forms).  Explicit
+  bars on exactly those leaves, against the float64 oracle and against the fp32 engine: 6e-3 of the leaf's max (measured
+  <= 2.5e-3, scripts/l1t_leaf_diag.py: gpurun_out/r05a; the f32-register sums of round 3 / 4 measured 3e-4 .. 1.6e-3), and
+  the folded layer 0 against the unfolded one (`BNF_PANEL_FOLD0=0`: d bias0 from f32 column sums of z) at 4e-3."""
+  E = 3
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth)
+  theta = util.random_theta(model, E, scale=0.3)
+  _, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
+  res = {}
+  for name, kw, fold in (('panel', dict(compute_dtype='bf16', pipeline='panel'), '1'),
+                         ('unfolded', dict(compute_dtype='bf16', pipeline='panel'), '0'), ('fp32', dict(compute_dtype='fp32'), '1')):
+    monkeypatch.setenv('BNF_PANEL_FOLD0', fold)
+    eng = _engine(net, X, y, members=E, **kw)
+    eng.set_params(theta)
+    res[name] = eng.debug_loss_and_grad()[1]
+    eng.close()
+  leaves = [f'Dense_{l}/bias' for l in range(depth)] + [f'Dense_{depth}/kernel']
+  for ref_name, ref, bar in (('oracle', g_o, 6e-3), ('fp32', res['fp32'], 6e-3), ('unfolded', res['unfolded'], 4e-3)):
+    errs = _leaf_errs(model, res['panel'], ref)
+    bad = {k: errs[k] for k in leaves if errs[k] > bar}
+    assert not bad, (ref_name, bad)
