@@ -19,7 +19,7 @@ _lib = None
 
 ABI_VERSION = 5
 MAX_INPUTS, MAX_GROUPS, MAX_LAYERS, MAX_FREQS, MAX_INTERACT = 8, 12, 8, 96, 16
-DTYPE = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
+DTYPE = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1, 'fp8': 2}
 OBS = {'NORMAL': 0, 'NB': 1, 'ZINB': 2}
 MODE_MAP, MODE_VI = 0, 1
 PIPELINE = {'auto': 0, 'layers': 1, 'panel': 3}

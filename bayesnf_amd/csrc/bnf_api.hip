@@ -31,6 +31,7 @@
 #include "bnf_gemm.h"
 #include "bnf_kernels.h"
 #include "bnf_panel.h"
+#include "bnf_gemm8.h"
 
 using namespace bnf;
 
@@ -80,6 +81,9 @@ struct bnf_handle {
   NetDev nd;
   FreqTab ft;
   bool bf16 = false;
+  bool q8 = false;        // BNF_DTYPE_FP8: bf16 contractions + fp8 operand copies for the weight-gradient kernels (bnf_gemm8.h)
+  uint8_t* H0q = nullptr; // (Ev, Bp, Fp) e4m3 copy of the features (layer-0 weight gradient)
+  float* qscale = nullptr;   // (Ev) s_H s_dZ of the step: written by the panel kernel, read by the weight-gradient kernels
   int es = 4;          // element size of T
   int Ev = 0;          // virtual members = members * S
   int S = 1;
@@ -206,6 +210,8 @@ static size_t carve(bnf_handle* h, char* base) {
   h->stab = (float*)take((size_t)std::max<int64_t>(1, h->N * nf2) * 4);
   h->stab_pred = (float*)take((size_t)std::max<int64_t>(1, Bp * nf2) * 4);
   h->H0 = take((size_t)Ev * Bp * Fp * es);
+  h->H0q = (h->q8 && !fo) ? (uint8_t*)take((size_t)Ev * Bp * Fp) : nullptr;
+  h->qscale = (h->q8 && !fo) ? (float*)take((size_t)Ev * 4) : nullptr;
   // no transposed copies (the weight-gradient contraction reads row-major, gemm_tn); the row-panel
   // kernel reads the features as MFMA A fragments from a second, fragment-major copy (H0t slot)
   // (the H0L variant -- W = 512, Fp = 64 -- stages the row-major copy in LDS instead and skips it)
@@ -465,6 +471,38 @@ static void launch_gemm_tn(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep
   launch_gemm_tn_wg<T, TAG, 2>(h, kid, g, ep, st);
 }
 
+// the weight gradient on fp8 operand copies (bnf_gemm8.h): the same plan (wgrad_plan's kind and split-K), the fp8 kernel of
+// that kind; both 128 x 128 and 256 x 256 two-stage kinds go to the generic 128 x 128 kernel
+template <int TAG>
+static void launch_gemm_tn8(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep, hipStream_t st, int kind) {
+  if (g.splitk < 1) g.splitk = 1;
+  EpiArgs ep2 = ep;
+  ep2.ablate = h->ablate;
+  LaunchScope ls(h, kid, st, true);
+  if (kind == WG_SKINNY && TAG == 0) {
+    g.tiles_m = 1; g.tiles_n = g.N / 512;
+    static std::atomic<uint64_t> attr_done{0};
+    allow_lds(h, &gemm_tn_skinny8, kSk8Lds, &attr_done);
+    hipLaunchKernelGGL(gemm_tn_skinny8, dim3((unsigned)((int64_t)g.members * g.tiles_n * g.splitk)), dim3(512), kSk8Lds, st, g, ep2);
+  } else if (kind == WG_RING) {
+    g.tiles_m = g.M / 256; g.tiles_n = g.N / 256;
+    static std::atomic<uint64_t> attr_done{0}, attr_done_s{0};
+    const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk * (g.n_multi > 1 ? g.n_multi : 1));
+    if (g.splitk == 1) {
+      allow_lds(h, &gemm_tn_ring8<TAG, true>, kRgLds, &attr_done_s);
+      hipLaunchKernelGGL((gemm_tn_ring8<TAG, true>), dim3(blocks), dim3(512), kRgLds, st, g, ep2);
+    } else {
+      allow_lds(h, &gemm_tn_ring8<TAG, false>, kRgLds, &attr_done);
+      hipLaunchKernelGGL((gemm_tn_ring8<TAG, false>), dim3(blocks), dim3(512), kRgLds, st, g, ep2);
+    }
+  } else {
+    g.tiles_m = (g.M + 127) / 128; g.tiles_n = (g.N + 127) / 128;
+    static std::atomic<uint64_t> attr_done{0};
+    allow_lds(h, &gemm_tn8<TAG>, kTn8Lds, &attr_done);
+    hipLaunchKernelGGL((gemm_tn8<TAG>), dim3((unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk)), dim3(256), kTn8Lds, st, g, ep2);
+  }
+}
+
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------
@@ -618,6 +656,15 @@ static void run_wgrad_layer(bnf_handle* h, int nmem, int l, hipStream_t st) {
   if (l == 0 && h->panel && h->fold0) {   // the ones column behind the features: its row of the product is d bias0
     ep.bias_row = 1; ep.off_bias_row = h->nd.off_bias[0];
   }
+  if constexpr (sizeof(T) == 2) {
+    if (h->q8) {   // the fp8 copies: same shapes, one byte per element
+      if (l == 0) g.A = h->H0q;
+      ep.qscale = h->qscale;
+      if (l == 0) launch_gemm_tn8<0>(h, KID_WGRAD0, g, ep, st, plan.kind);
+      else launch_gemm_tn8<1>(h, KID_WGRAD, g, ep, st, plan.kind);
+      return;
+    }
+  }
   if (l == 0) launch_gemm_tn<T, 0>(h, KID_WGRAD0, g, ep, st, plan.kind);
   else launch_gemm_tn<T, 1>(h, KID_WGRAD, g, ep, st, plan.kind);
 }
@@ -684,7 +731,12 @@ static void run_wgrad(bnf_handle* h, int nmem) {
       EpiArgs ep{};
       ep.scale = 1.0f / sqrtf((float)h->Wt);
       ep.grad = h->gradf; ep.grad_stride = h->Pf; ep.off_out = h->nd.off_kernel[1]; ep.ld_f32 = h->W;
-      launch_gemm_tn<T, 1>(h, KID_WGRAD, g, ep, h->stream, WG_RING);
+      if (h->q8) {
+        ep.qscale = h->qscale;
+        launch_gemm_tn8<1>(h, KID_WGRAD, g, ep, h->stream, WG_RING);
+      } else {
+        launch_gemm_tn<T, 1>(h, KID_WGRAD, g, ep, h->stream, WG_RING);
+      }
       if (!l0_first && !panel_dk0_fused(h)) wgrad_after_dz<T>(h, nmem, 0);
       return;
     }
@@ -907,7 +959,7 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
     allow_lds(h, &k_featurize<bf16_t>, 160 * 1024, &attr_done);
     hipLaunchKernelGGL((k_featurize<bf16_t>), grid, dim3(kFeatRows), lds, h->stream, h->nd, rs, h->X, h->stab,
                        h->y, h->scal, h->B, (bf16_t*)h->H0, Bp * h->Fp, (bf16_t*)h->H0t,
-                       (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp, (int32_t)nmem, (int32_t)(h->fold0 ? 2 : 0));
+                       (int64_t)h->Fp * Bp, (int32_t)Bp, h->ybat, Bp, (int32_t)nmem, (int32_t)(h->fold0 ? 2 : 0), h->H0q);
   }
   bool feat_bwd_fused = false;
   PanelArgs pa{};
@@ -935,6 +987,7 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   pa.dk0_fused = panel_dk0_fused(h) ? 1 : 0;
   pa.fin = h->fin ? 1 : 0; pa.n_in = h->nd.D; pa.n_seas = 2 * h->ft.n;
   pa.X = h->X; pa.stab = h->stab; pa.y = h->y; pa.fcol = h->fcol; pa.H0out = (bf16_t*)h->H0; pa.rs = rs;
+  pa.q8 = h->q8 ? 1 : 0; pa.qscale = h->qscale;
   // 128-row panels at W = 512 (the feature panel staged in LDS when Fp = 64), 256-row panels at W = 256,
   // 64-row panels with two 64-column slabs per wave at W = 1024
   auto with_fused_featbwd = [&]() {
@@ -1298,7 +1351,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(BNF_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
                 cfg->device, prop.gcnArchName);
-  if (cfg->dtype != BNF_DTYPE_F32 && cfg->dtype != BNF_DTYPE_BF16)
+  if (cfg->dtype != BNF_DTYPE_F32 && cfg->dtype != BNF_DTYPE_BF16 && cfg->dtype != BNF_DTYPE_FP8)
     return fail(BNF_ERR_INVALID, "dtype %d", cfg->dtype);
   if (cfg->obs_model != BNF_OBS_NORMAL && cfg->obs_model != BNF_OBS_NB && cfg->obs_model != BNF_OBS_ZINB)
     return fail(BNF_ERR_INVALID, "observation model %d", cfg->obs_model);
@@ -1323,7 +1376,8 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
 
   bnf_handle* h = new bnf_handle();
   h->cfg = *cfg;
-  h->bf16 = cfg->dtype == BNF_DTYPE_BF16;
+  h->bf16 = cfg->dtype != BNF_DTYPE_F32;     // (fp8: bf16 contractions, fp8 operand copies for the weight gradients)
+  h->q8 = cfg->dtype == BNF_DTYPE_FP8;
   h->es = h->bf16 ? 2 : 4;
   h->S = S;
   h->Ev = cfg->members * S;
@@ -1435,6 +1489,11 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
       return fail(BNF_ERR_INVALID, "panel pipeline needs a bf16 training handle with depth >= 2, width 256/512/1024 and <= 128 features");
     }
     h->panel = can_panel && (want == 3 || want == 0);   // the default where it applies (C2: 2.71 -> 2.27 ms/step)
+    if (h->q8 && !h->panel && !cfg->forward_only) {
+      delete h;
+      return fail(BNF_ERR_INVALID, "dtype fp8 (fp8 operand storage for the weight gradients) needs the row-panel pipeline: "
+                  "depth >= 2, width 256 / 512 / 1024 after padding to 64, <= 128 padded features");
+    }
     if (h->panel) h->Bp = align_up(h->B, 256);
     // pipeline 0 (auto): layer kernels with the one-kernel last layer where the width allows;
     // pipeline 1: every layer kernel separate and every activation materialised (validation)
@@ -1999,6 +2058,13 @@ int bnf_debug_activation(bnf_handle* h, int32_t what, float* out) {
   }
   if (!src) return fail(BNF_ERR_STATE, "buffer not allocated on this handle");
   dim3 grid(cdiv(B * cols, 256), (unsigned)h->Ev);
+  if (h->q8 && h->panel && what != 0) {   // the fp8 copies: H_l e4m3 un-scaled, dZ_l e5m2 x qscale[member]
+    const bool dz = what >= 300;
+    hipLaunchKernelGGL(k_q8_to_f32, grid, dim3(256), 0, h->stream, (const uint8_t*)src, batch, ld, B, cols, out,
+                       dz ? 1 : 0, dz ? h->qscale : (const float*)nullptr);
+    HIPCHK(hipGetLastError());
+    return BNF_OK;
+  }
   if (h->bf16)
     hipLaunchKernelGGL((k_to_f32<bf16_t>), grid, dim3(256), 0, h->stream, (const bf16_t*)src, batch, ld, B, cols, out, transposed);
   else
@@ -2059,7 +2125,24 @@ int bnf_debug_gemm_tn(bnf_handle* h, const float* A, const float* B, int32_t R, 
   g.A = dA; g.B = dB; g.a_ld = M; g.b_ld = N; g.M = M; g.N = N; g.K = R; g.splitk = 1; g.members = 1;
   EpiArgs ep{};
   ep.scale = 1.f; ep.out_f32 = C; ep.f32_batch = 0; ep.ld_f32 = N;
-  if (h->bf16) {
+  if (h->q8) {
+    // A -> e4m3, B -> e5m2 (saturating, round to nearest even), then the fp8 kernel of the kind BNF_DEBUG_TN_KIND names
+    // (0: the generic 128 x 128 tile, 2: ring -- M, N multiples of 256 --, 3: skinny -- M = 64, N a multiple of 512),
+    // split-K BNF_DEBUG_TN_SPLITK: tests/test_gpu_fp8.py checks every kernel against the host product of the same
+    // quantised operands
+    const int kind = getenv("BNF_DEBUG_TN_KIND") ? atoi(getenv("BNF_DEBUG_TN_KIND")) : WG_TN128;
+    g.splitk = getenv("BNF_DEBUG_TN_SPLITK") ? std::max(1, atoi(getenv("BNF_DEBUG_TN_SPLITK"))) : 1;
+    if ((kind == WG_RING && (M % 256 || N % 256)) || (kind == WG_SKINNY && (M != 64 || N % 512)) ||
+        (kind != WG_RING && kind != WG_SKINNY && kind != WG_TN128) || M % 16 || N % 16) {
+      (void)hipFree(dA); (void)hipFree(dB);
+      return fail(BNF_ERR_INVALID, "fp8 weight-gradient kernel kind %d does not take (M, N) = (%d, %d)", kind, M, N);
+    }
+    hipLaunchKernelGGL((k_from_f32_q8<false>), dim3(cdiv((int64_t)R * M, 256)), dim3(256), 0, st, A, (int64_t)R, M, (uint8_t*)dA, M);
+    hipLaunchKernelGGL((k_from_f32_q8<true>), dim3(cdiv((int64_t)R * N, 256)), dim3(256), 0, st, B, (int64_t)R, N, (uint8_t*)dB, N);
+    if (g.splitk > 1) HIPCHK(hipMemsetAsync(C, 0, (size_t)M * N * 4, st));
+    if (kind == WG_SKINNY) launch_gemm_tn8<0>(h, KID_WGRAD0, g, ep, st, kind);
+    else launch_gemm_tn8<1>(h, KID_WGRAD, g, ep, st, kind);
+  } else if (h->bf16) {
     hipLaunchKernelGGL((k_from_f32<bf16_t>), dim3(cdiv((int64_t)R * M, 256)), dim3(256), 0, st, A, (int64_t)R, M, (bf16_t*)dA, M);
     hipLaunchKernelGGL((k_from_f32<bf16_t>), dim3(cdiv((int64_t)R * N, 256)), dim3(256), 0, st, B, (int64_t)R, N, (bf16_t*)dB, N);
     launch_gemm_tn<bf16_t, 2>(h, KID_WGRAD, g, ep, st, debug_tn_kind(h, g));

@@ -420,6 +420,25 @@ struct ActConst {
 __device__ __forceinline__ ActConst act_const(float alpha) {
   return ActConst{alpha, 1.f - 2.f * alpha, -2.f * (1.f - alpha), 4.f * (1.f - alpha)};
 }
+// Four bf16 values (two packed dwords) -> four fp8 bytes (one dword) by two v_cvt_scalef32_pk_{fp8,bf8}_bf16: the
+// gfx950 conversions take a bf16 PAIR straight from its packed dword, DIVIDE by `scale` (a power of two; measured:
+// scripts/probes/fp8_probe.hip) and write one half of the destination dword each.  Round to nearest even; with
+// MODE.FP16_OVFL set (the callers do: s_setreg) overflow clamps to the largest finite value (448 / 57344) instead of
+// giving NaN / inf.  fp8 = OCP e4m3 (activations), bf8 = OCP e5m2 (backward signals).
+typedef short v2s_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16x4_to_fp8(uint32_t lo, uint32_t hi, float scale) {
+  v2s_t r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(bf16x2_t, lo), scale, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, __builtin_bit_cast(bf16x2_t, hi), scale, true);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t bf16x4_to_bf8(uint32_t lo, uint32_t hi, float scale) {
+  v2s_t r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(r, __builtin_bit_cast(bf16x2_t, lo), scale, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(r, __builtin_bit_cast(bf16x2_t, hi), scale, true);
+  return __builtin_bit_cast(uint32_t, r);
+}
 // two bf16 values rounded by ONE v_cvt_pk_bf16_f32: hipcc splits a bf16x2 whose halves are stored
 // separately into two conversions (each with a zero partner); made opaque as ONE dword, the pair is
 // converted together and the halves leave as ds_write_b16 / ds_write_b16_d16_hi.  (The empty asm holds no

@@ -92,6 +92,8 @@ struct EpiArgs {
   // gemm_tn / gemm_tn_skinny, layer 0 of the panel kernel's F0 forms: row M of the (padded) output -- the ones column of
   // the feature operand -- is d bias0 (un-scaled), accumulated at grad[off_bias_row + n]
   int32_t bias_row, off_bias_row;
+  // fp8 operand copies (bnf_gemm8.h): per-member product of the operands' storage scales, folded into the output
+  const float* qscale;
   unsigned long long* prof;   // -DBNF_ENABLE_ABLATE builds: per-workgroup phase clocks (8 marks)
   int32_t ablate;      // perf experiments only (env BNF_ABLATE): 1 no transposed stores,
                        // 2 no row-major stores, 4 no activation math, 8 no row dot,

@@ -110,7 +110,10 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
     NetDev nd, RowSrc rs, const float* __restrict__ X, const float* __restrict__ Stab,
     const float* __restrict__ y, const float* __restrict__ scal, int64_t B,
     T* __restrict__ H0, int64_t h0_batch, T* __restrict__ H0f, int64_t h0f_batch, int32_t ldt,
-    float* __restrict__ ybat, int64_t ybat_batch, int32_t n_members, int32_t n_ones) {
+    float* __restrict__ ybat, int64_t ybat_batch, int32_t n_members, int32_t n_ones,
+    uint8_t* __restrict__ H0q = nullptr) {
+  // H0q (optional, 2-byte T; compute_dtype 'fp8'): a third copy, row-major (Bp, Fp) OCP e4m3 (un-scaled: features are O(1),
+  // the ones columns exact) -- the A operand of the layer-0 weight gradient on fp8 operands (bnf_gemm8.h)
   // n_ones (0 or 2; the panel kernel's F0 forms): that many feature columns behind the F real ones hold 1.0 -- the
   // contraction partners of the bias rows in the forward-packed layer-0 weights, and the row of the layer-0 weight
   // gradient that IS the bias gradient
@@ -210,6 +213,21 @@ __global__ __launch_bounds__(kFeatRows) void k_featurize(
           *reinterpret_cast<const u32x4*>(tile + lr * pitch + cc * kEpc);
   }
   if constexpr (sizeof(T) == 2) {
+    if (H0q) {
+      __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);   // MODE.FP16_OVFL: conversions clamp to the largest finite value
+      uint8_t* dq = H0q + (int64_t)e * h0_batch;     // (same element count per member, one byte each)
+      const int qpr = nd.Fp / 16;                     // 16-element pieces per row: 32 bytes of bf16 -> 16 bytes of e4m3
+      for (int q = threadIdx.x; q < kFeatRows * qpr; q += kFeatRows) {
+        const int lr = q / qpr, cc = q % qpr;
+        if (r0 + lr < B) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(tile + lr * pitch + cc * 16);
+          const u32x4 hi = *reinterpret_cast<const u32x4*>(tile + lr * pitch + cc * 16 + 8);
+          *reinterpret_cast<u32x4*>(dq + (r0 + lr) * nd.Fp + cc * 16) =
+              u32x4{bf16x4_to_fp8(lo[0], lo[1], 1.f), bf16x4_to_fp8(lo[2], lo[3], 1.f), bf16x4_to_fp8(hi[0], hi[1], 1.f),
+                    bf16x4_to_fp8(hi[2], hi[3], 1.f)};
+        }
+      }
+    }
     if (H0f) {
       T* df = H0f + (int64_t)e * h0f_batch;
       const int ks0 = nd.Fp / 16;

@@ -113,6 +113,13 @@ struct PanelArgs {
   const int32_t* fcol;
   bf16_t* H0out;
   RowSrc rs;
+  // q8 (compute_dtype 'fp8'): the copies this kernel leaves for the weight-gradient contractions are FP8 -- Hout[l] as OCP
+  // e4m3 (un-scaled), dZ[l] as OCP e5m2 divided by a per-member power of two s_dZ, written to qscale[member] for the
+  // consumers (bnf_gemm8.h) -- row-major (Bp, W) BYTES in the same buffers.  The panels in LDS and every contraction
+  // of this kernel stay bf16: the conversion happens where a block leaves for HBM (v_cvt_scalef32_pk_{fp8,bf8}_bf16:
+  // one instruction per element pair, half the store instructions and bytes).
+  int32_t q8;
+  float* qscale;
 };
 constexpr int kFbNone = 0, kFbInput = 1, kFbFourier = 2, kFbInter = 3;
 
@@ -599,6 +606,16 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   const float lns = th[a.off_lns];
   const float e_lns = expf(lns), sigma = 0.01f + e_lns, inv_sigma = 1.0f / sigma;
   const float ll_const = -logf(sigma) - 0.918938533204672742f;
+  // q8: s_dZ = 2^(round(log2(c gamma_o / sigma)) - 6): d out is ~ c (y - out) / sigma^2 = (c / sigma) x a residual of order
+  // one, and dZ_l is that times gamma_l k / sqrt W act' ~ a few 1e-2 -- stored values land around 2^0 .. 2^4 of e5m2's
+  // 2^-14 .. 2^15 normal range, with ten binades of head room either way (count models: no sigma, c gamma_o alone)
+  float q_dz = 1.f;
+  if (a.q8) {
+    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);   // MODE.FP16_OVFL: fp8 conversions clamp to the largest finite value
+    const float ref = a.lik_c * gam_o * (a.obs == BNF_OBS_NORMAL ? inv_sigma : 1.f);
+    q_dz = exp2f(rintf(log2f(fmaxf(ref, 1e-30f))) - 6.f);
+    if (pn == 0 && tid_k == 0) a.qscale[e] = q_dz;
+  }
   // the row phase's target value, fetched now (one thread per row; rows >= B read nothing)
   const float y_pre = (!(BNF_PANEL_FIN && H0L && a.fin) && tid < BM && m0 + tid < a.B) ? a.ybat[(int64_t)e * a.row_batch + m0 + tid] : 0.f;
 
@@ -648,8 +665,44 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   // writes must have landed (lgkmcnt), no workgroup barrier, and the stores (128-byte runs, 1 KiB
   // per wave instruction) issue underneath the VALU work of the next block instead of in a
   // 10k-cycle burst per panel (a CU issues stores at ~13 B/clk).
+  // q8: the block leaves as fp8 -- 32 rows x 64 BYTES = two 1 KiB wave stores; a lane converts two 16-element pieces
+  // (2 x 32 bytes of the bf16 panel -> 2 x 16 bytes); `is_dz`: e5m2 / s_dZ, else e4m3 un-scaled
+  auto block_to_global_q8 = [&](int lane, bf16_t* dst, int prb, int pcb, int i, bool is_dz) {
+    uint8_t* d = reinterpret_cast<uint8_t*>(dst) + (int64_t)e * a.act_batch + (int64_t)(m0 + prb + i * 32) * W + pcb;   // uniform
+    const bf16_t* sp = tile + (prb + i * 32) * kPitchE + pcb;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d, 0, 0x7fffffff, 0x00020000);
+    u32x4 v[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pc = lane + 64 * u, row = pc >> 2, p4 = pc & 3;
+      v[u][0] = *reinterpret_cast<const u32x4*>(sp + row * kPitchE + p4 * 16);
+      v[u][1] = *reinterpret_cast<const u32x4*>(sp + row * kPitchE + p4 * 16 + 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pc = lane + 64 * u, row = pc >> 2, p4 = pc & 3;
+      u32x4 o;
+      if (is_dz)
+        o = u32x4{bf16x4_to_bf8(v[u][0][0], v[u][0][1], q_dz), bf16x4_to_bf8(v[u][0][2], v[u][0][3], q_dz),
+                  bf16x4_to_bf8(v[u][1][0], v[u][1][1], q_dz), bf16x4_to_bf8(v[u][1][2], v[u][1][3], q_dz)};
+      else
+        o = u32x4{bf16x4_to_fp8(v[u][0][0], v[u][0][1], 1.f), bf16x4_to_fp8(v[u][0][2], v[u][0][3], 1.f),
+                  bf16x4_to_fp8(v[u][1][0], v[u][1][1], 1.f), bf16x4_to_fp8(v[u][1][2], v[u][1][3], 1.f)};
+      __builtin_amdgcn_raw_buffer_store_b128(o, rs, (uint32_t)(row * W + p4 * 16), 0, BNF_PANEL_NT ? 2 : 0);
+    }
+  };
+  auto is_dz_array = [&](const bf16_t* dst) {     // (uniform) one of the dZ arrays? else an activation copy
+    bool dz = false;
+#pragma unroll
+    for (int l = 0; l < BNF_MAX_LAYERS; ++l) dz = dz || dst == a.dZ[l];
+    return dz;
+  };
   auto block_to_global = [&](const LaneCtx& L, bf16_t* dst, int i, int cbase) {
     if (BNF_ABL(a, 8)) return;
+    if (a.q8) {
+      block_to_global_q8(L.lane, dst, rbase, cbase, i, is_dz_array(dst));
+      return;
+    }
     bf16_t* d = dst + (int64_t)e * a.act_batch + (int64_t)(m0 + rbase + i * 32) * W + cbase;   // uniform
     const bf16_t* sp = tile + (rbase + i * 32) * kPitchE + cbase;
     u32x4 v[4];
@@ -949,6 +1002,13 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
     for (int b = 0; b < 2; ++b) {
       const int pw = b == 0 ? wave : (wave ^ 4);              // this wave's slab, then its SIMD partner's
       const int prb = (pw / WN) * WR, pcb = (pw % WN) * CH * 64;
+      if (a.q8) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int hc = 0; hc < CH; ++hc) block_to_global_q8(lane, dst, prb, pcb + hc * 64, i, true);
+        continue;
+      }
       bf16_t* d = dst + (int64_t)e * a.act_batch + (int64_t)(m0 + prb) * W + pcb;   // uniform
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d, 0, 0x7fffffff, 0x00020000);
       const bf16_t* sp = tile + prb * kPitchE + pcb;

@@ -24,7 +24,9 @@ def default_dtype(compute_dtype=None) -> str:
   """'fp32' unless the caller or BNF_DTYPE says otherwise: the float32 engine is the parity path
   (exact-f32 MFMA; it reproduces the reference's golden predictions), 'bf16' the throughput path
   (bf16 contraction operands, f32 accumulation -- the numerics class of the reference's TPU runs;
-  ~5x the member-steps/s at the benchmark size).  Said once per process when the default applies."""
+  ~5x the member-steps/s at the benchmark size), 'fp8' = 'bf16' with FP8 OPERAND STORAGE for the weight-gradient
+  contractions (include/bnf.h BNF_DTYPE_FP8; training handles on the row-panel pipeline only -- a forward-only handle
+  of an 'fp8' estimator runs the bf16 forward).  Said once per process when the default applies."""
   global _warned_default_dtype
   if compute_dtype is None and 'BNF_DTYPE' not in os.environ and not _warned_default_dtype:
     _warned_default_dtype = True
@@ -35,7 +37,7 @@ def default_dtype(compute_dtype=None) -> str:
   dt = compute_dtype or os.environ.get('BNF_DTYPE', 'fp32')
   if dt not in _native.DTYPE:
     raise ValueError(f'compute_dtype must be one of {sorted(_native.DTYPE)}')
-  return 'bf16' if _native.DTYPE[dt] == 1 else 'fp32'
+  return {0: 'fp32', 1: 'bf16', 2: 'fp8'}[_native.DTYPE[dt]]
 
 
 def _ptr(t):

@@ -43,7 +43,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'fp8': 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md ('fp8': the dominant
+# kernel's contractions are bf16 and the weight-gradient kernels use the NON-scaled fp8 MFMA = the bf16 rate)
 
 # engine kernel name (bnf_profile_read) -> device symbol (rocprofv3 Kernel_Name), {T} = element type
 KERNEL_SYMBOL = {   # gemm_nt<T, epilogue, tag, wave rows, wave cols>
@@ -80,8 +81,8 @@ def _committed_counters(fname, kernel, dtype, members):
   rel = os.path.join('profiles', fname)
   path = os.path.join(ROOT, rel)
   src = {'file': rel, 'measured': 'separate rocprofv3 --pmc passes of this command, committed; NOT re-measured in this run'}
-  if members != 64 or kernel not in KERNEL_SYMBOL:
-    return None, dict(src, used=False, why='no committed measurement for this kernel / member count')
+  if members != 64 or kernel not in KERNEL_SYMBOL or dtype == 'fp8':
+    return None, dict(src, used=False, why='no committed measurement for this kernel / member count / dtype')
   if not os.path.exists(path):
     return None, dict(src, used=False, why='file absent')
   with open(path) as f:
@@ -91,7 +92,7 @@ def _committed_counters(fname, kernel, dtype, members):
   here = kernel_source_sha16()
   if meta.get('kernel_source_sha16') != here:
     return None, dict(src, used=False, why=f'stale: taken with kernel sources {meta.get("kernel_source_sha16")}, this build is {here}')
-  sym = KERNEL_SYMBOL[kernel].format(T='bnf::bf16_t' if dtype == 'bf16' else 'float').split('(')[0]
+  sym = KERNEL_SYMBOL[kernel].format(T='bnf::bf16_t' if dtype in ('bf16', 'fp8') else 'float').split('(')[0]
   for name, rec in table.items():
     if name != '_meta' and name.startswith(sym):
       return rec, dict(src, used=True, symbol=name)
@@ -583,7 +584,9 @@ def main(argv=None):
   ap.add_argument('--gather', default=None, choices=['cabi', 'torch'],
                   help="posterior gather through bnf_allgather of the engine library (default on GPUs; env "
                        "BNF_GATHER) or torch.distributed's all_gather_into_tensor")
-  ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+  ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp8'],
+                  help="bf16 (the headline), fp32 (the parity arithmetic), fp8 = bf16 contractions with fp8 operand storage for "
+                       'the weight-gradient streams (BASELINE configs[4])')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--preheat-ms', type=float, default=100.0,
                   help='bring the DEVICE to the power / clock state a long fit runs in: this many ms of untimed steps on a '

@@ -49,7 +49,13 @@ enum {
   BNF_ERR_STATE = -4       /* call order violated (e.g. train before bind) */
 };
 
-enum { BNF_DTYPE_F32 = 0, BNF_DTYPE_BF16 = 1 };   /* arithmetic of the dense contractions; accumulation is always f32 */
+enum { BNF_DTYPE_F32 = 0, BNF_DTYPE_BF16 = 1,   /* arithmetic of the dense contractions; accumulation is always f32 */
+       /* BASELINE.json configs[4] ("fp8 MFMA dense layers"): the bf16 row-panel pipeline with FP8 OPERAND STORAGE for the
+        * weight-gradient contractions -- the activation copies H_l leave as OCP e4m3, the backward signals dZ_l as OCP
+        * e5m2 over a per-member power of two, and dK_l = H_l^T dZ_l runs on the non-scaled fp8 MFMA; forward and
+        * backward-data contractions stay bf16.  Needs the row-panel pipeline (depth >= 2, padded width 256 / 512 / 1024,
+        * <= 128 padded features): bnf_create refuses other shapes. */
+       BNF_DTYPE_FP8 = 2 };
 enum { BNF_OBS_NORMAL = 0, BNF_OBS_NB = 1, BNF_OBS_ZINB = 2 }; /* models.py:30-33 */
 enum { BNF_MODE_MAP = 0, BNF_MODE_VI = 1 };       /* MLE = MAP with prior_weight 0 (spatiotemporal.py:551) */
 

@@ -1,0 +1,125 @@
+"""compute_dtype 'fp8' (BASELINE.json configs[4], SURVEY.md 8d's fp8 class): the bf16 row-panel pipeline with FP8 OPERAND
+STORAGE for the weight-gradient contractions -- activations as OCP e4m3, backward signals as OCP e5m2 over a per-member
+power of two, dK_l = H_l^T dZ_l on the non-scaled fp8 MFMA (bnf_gemm8.h).  (1) the three fp8 kernels against the host
+product of the SAME quantised operands (exact up to f32 summation order); (2) the copies the panel kernel leaves against
+its bf16 copies; (3) one step's gradients against the float64 oracle at fp8-class bars; (4) SURVEY 8d's statistical
+gate: final loss within 3 % and predictive RMSE within 5 % of the fp32 run from identical initial parameters."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bnf_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(net, X, y, **kw):
+  from bayesnf_amd.engine import Engine
+  return Engine(net, X=X, y=y, **kw)
+
+
+def _q(a, kind):
+  """round to nearest even into OCP e4m3 / e5m2 (saturating) the way the device conversions do -- through torch's
+  float8 dtypes, which implement the same formats"""
+  t = torch.tensor(np.asarray(a, dtype=np.float32))
+  if kind == 'e4m3':
+    return t.clamp(-448, 448).to(torch.float8_e4m3fn).float().numpy()
+  return t.clamp(-57344, 57344).to(torch.float8_e5m2).float().numpy()
+
+
+@pytest.mark.parametrize('kind,shape,splitk', [(0, (64, 128, 128), 1), (0, (320, 112, 208), 1), (0, (1024, 128, 256), 3),
+                                               (2, (640, 256, 256), 1), (2, (1216, 512, 256), 1), (2, (2048, 256, 512), 4),
+                                               (3, (320, 64, 512), 1), (3, (1600, 64, 1024), 3)])
+def test_fp8_weight_gradient_kernels_vs_host_product_of_the_quantised_operands(kind, shape, splitk, monkeypatch):
+  R, M, N = shape
+  monkeypatch.setenv('BNF_DEBUG_TN_KIND', str(kind))
+  monkeypatch.setenv('BNF_DEBUG_TN_SPLITK', str(splitk))
+  net, model, X, y = util.make_problem(n_rows=300, width=256, depth=2)
+  eng = _engine(net, X, y, members=1, compute_dtype='fp8')
+  rng = np.random.default_rng(R + M + kind)
+  # (a) operands that ARE fp8 numbers of one sign and similar size: exact products, exact f32 accumulation -- any wrong
+  # fragment, swizzle or tile index shows as a gross error
+  A1 = _q(rng.uniform(0.5, 2.0, (R, M)), 'e4m3')
+  B1 = _q(rng.uniform(0.5, 2.0, (R, N)), 'e5m2')
+  C1 = eng.debug_gemm_tn(A1, B1)
+  ref1 = A1.astype(np.float64).T @ B1.astype(np.float64)
+  assert util.rel_err(C1, ref1) < 2e-6, util.rel_err(C1, ref1)
+  # (b) signed operands over twelve decades: the fp8 MFMA adds the 16 products of one instruction with ~14 bits below the
+  # largest of them (measured: 6e-5 of max |C| at every K from 64 to 131,072, unbiased, exact into the f32 accumulator --
+  # scripts/fp8_accum_probe.py, profiles/r05_fp8_accumulation.txt; the bf16 MFMA keeps 24), far below fp8's own 2^-4
+  A = (rng.standard_normal((R, M)) * np.exp(rng.uniform(-3, 3, (R, 1)))).astype(np.float32)
+  B = (rng.standard_normal((R, N)) * np.exp(rng.uniform(-6, 6, (1, N)))).astype(np.float32)
+  ref = _q(A, 'e4m3').astype(np.float64).T @ _q(B, 'e5m2').astype(np.float64)
+  Cq = eng.debug_gemm_tn(_q(A, 'e4m3'), _q(B, 'e5m2'))
+  assert util.rel_err(Cq, ref) < 2e-4, util.rel_err(Cq, ref)
+  # (c) f32 operands: the device rounds to nearest even like the host emulation
+  Cd = eng.debug_gemm_tn(A, B)
+  assert util.rel_err(Cd, ref) < 1e-3, util.rel_err(Cd, ref)
+  eng.close()
+
+
+@pytest.mark.parametrize('width,depth,n_rows', [(512, 2, 700), (256, 3, 600), (1024, 2, 300)])
+def test_fp8_copies_and_step_gradients(width, depth, n_rows):
+  """The fp8 copies are the bf16 panel values rounded once more (e4m3: 2^-4 relative, e5m2: 2^-3), the scale a power of
+  two that keeps the backward signals in range; loss and every non-kernel leaf are the bf16 pipeline's (same kernel, same
+  arithmetic); the Dense kernels' gradients -- the only consumers of the copies -- within 4e-2 of the leaf's max."""
+  E = 3
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth)
+  theta = util.random_theta(model, E, scale=0.3)
+  res, acts = {}, {}
+  for dt in ('fp8', 'bf16'):
+    eng = _engine(net, X, y, members=E, compute_dtype=dt, pipeline='panel')
+    eng.set_params(theta)
+    res[dt] = eng.debug_loss_and_grad()
+    acts[dt] = dict(H=[eng.debug_activation(1 + l) for l in range(depth - 1)],
+                    dZ=[eng.debug_activation(300 + l) for l in range(depth)])
+    eng.close()
+  for l in range(depth - 1):
+    a, b = acts['fp8']['H'][l], acts['bf16']['H'][l]
+    assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 2.0 ** -6)) <= 2.0 ** -4 + 1e-6, l       # e4m3: 3 mantissa bits
+  for l in range(depth):
+    a, b = acts['fp8']['dZ'][l], acts['bf16']['dZ'][l]
+    big = np.abs(b) > 1e-3 * np.abs(b).max()
+    assert np.max(np.abs(a - b)[big] / np.abs(b)[big]) <= 2.0 ** -3 + 1e-6, l                      # e5m2: 2 mantissa bits
+    assert util.rel_err(a, b) < 0.13
+  loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
+  np.testing.assert_allclose(res['fp8'][0], res['bf16'][0], rtol=1e-6)
+  e8 = util.per_leaf_rel_err(model, res['fp8'][1], res['bf16'][1])
+  kernels = [f'Dense_{l}/kernel' for l in range(depth)] + ['Dense_0/bias']      # (d bias0 is a row of the layer-0 product)
+  bad = {k: v for k, v in e8.items() if k not in kernels and v > 1e-4}
+  assert not bad, ('leaves that do not read the copies', bad)
+  eo = util.per_leaf_rel_err(model, res['fp8'][1], g_o)
+  bad = {k: eo[k] for k in kernels if eo[k] > (8e-2 if k == 'Dense_0/bias' else 4e-2)}   # (d bias0 = 1^T dZq_0: e5m2 alone, no averaging partner)
+  assert not bad, ('vs oracle', bad)
+
+
+@pytest.mark.parametrize('layout', ['C2', 'C5'])
+def test_fp8_training_within_survey_8d_statistical_bars_of_fp32(layout):
+  """SURVEY.md 8d, fp8 class: from identical initial parameters, final loss within 3 % and RMSE of the ensemble-mean
+  prediction within 5 % of the fp32 run (C2's and C5's feature layouts and widths at a size the suite can afford)."""
+  if layout == 'C2':
+    kw = dict(n_rows=4000, width=512, depth=2, periods=(4.0, 52.1775), harmonics=(2, 10), T=522)
+  else:
+    kw = dict(n_rows=6000, width=256, depth=2, periods=(7.0, 30.4375, 365.25), harmonics=(3, 10, 10), T=2000,
+              interactions=())
+  net, model, X, y = util.make_problem(**kw)
+  E, steps = 8, 150
+  out = {}
+  for dt in ('fp32', 'fp8', 'bf16'):
+    eng = _engine(net, X, y, members=E, seed=3, learning_rate=0.005, compute_dtype=dt)
+    eng.init_params(float(np.log(np.nanstd(y) / 2)))
+    if dt == 'fp32':
+      theta0 = eng.get_params()
+    else:
+      eng.set_params(theta0)
+    losses = eng.train(0, steps).cpu().numpy()
+    th = eng.get_params().astype(np.float64)
+    pred = np.asarray(O.forward(model, th, X)).mean(axis=0)
+    out[dt] = (losses[:, -1], float(np.sqrt(np.mean((pred - y) ** 2))))
+    eng.close()
+  l32, r32 = out['fp32']
+  for dt in ('fp8', 'bf16'):
+    l, r = out[dt]
+    assert abs(np.mean(l) / np.mean(l32) - 1) < 0.03, (dt, np.mean(l), np.mean(l32))
+    assert abs(r / r32 - 1) < 0.05, (dt, r, r32)
