@@ -123,3 +123,27 @@ def test_committed_counter_files_are_quoted_only_for_the_build_they_measured(tmp
   ctr, src = bench.sq_counters('panel_fwd_bwd', 'bf16', 64)
   fl = bench.issue_floors(ctr, 1200.0)
   assert src['used'] and abs(fl['valu_per_mfma'] - 8.0) < 1e-9 and fl['valu_issue_floor_us'] > 0
+
+
+def test_inproc_and_torchrun_launchers_split_a_strong_scaling_ensemble_the_same_way():
+  """`--strong`: `--members-per-gpu` names the WHOLE ensemble and both launchers must deal it out identically -- same
+  ensemble size, same members per GPU, same scaling label, same gather shape -- so that a strong-scaling record taken
+  with one launcher is comparable with the other's."""
+  common = ['--selftest-cpu', '--gpus', '2', '--steps', '2', '--warmup', '1', '--members-per-gpu', '6', '--strong']
+  out = {}
+  for name, extra in (('torchrun', []), ('inproc', ['--launcher', 'inproc'])):
+    r = _run(common + extra)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+  a, b = out['torchrun'], out['inproc']
+  for d in (a, b):
+    assert d['scaling'] == 'strong' and d['n_gpus'] == 2
+    assert d['config']['ensemble_size'] == 6 and d['config']['members_per_gpu'] == 3
+    assert len(d['per_rank_ms_per_step']) == 2 and d['posterior_gather']['shape'] == [6, 16]
+    assert abs(d['value'] - 6 * 2 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']      # whole-job member-steps/s
+  assert a['launcher'].startswith('torch') and b['launcher'].startswith('inproc')
+  assert a['metric'] == b['metric'] and a['unit'] == b['unit'] and a['config']['parallelism'] == b['config']['parallelism']
+  # an ensemble that does not split evenly is refused by both
+  for extra in ([], ['--launcher', 'inproc']):
+    r = _run(['--selftest-cpu', '--gpus', '2', '--steps', '1', '--warmup', '1', '--members-per-gpu', '5', '--strong'] + extra)
+    assert r.returncode != 0 and 'do not split evenly' in (r.stderr + r.stdout)
