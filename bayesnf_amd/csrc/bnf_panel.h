@@ -1114,7 +1114,10 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   //     wrote itself, so no barrier is added).
   // Per element pair: 17 VALU + 4 transcendentals forward, 2 VALU backward, where the r04 kernel spent 9 + 4 and 18 + 4
   // (+ the 64-row LDS scratch of the row dots, + 2-byte panel stores): profiles/r05_panel_ab.md.
-  constexpr bool kL1T = BNF_PANEL_L1T != 0 && CH == 1;   // (CH = 2, the W = 1024 form: both slabs' accumulators + the column constants spill)
+  // (not CH = 2, the W = 1024 form: both slabs' accumulators + the column constants spill; not WN = 4, the W = 256 forms: a
+  // wave holds half as many elements, the column-sum MFMAs and their atomics -- two row blocks each -- weigh twice as much:
+  // C5/8 10.89k -> 10.79k member-steps/s same box, three alternations, profiles/r05_panel_ab.md)
+  constexpr bool kL1T = BNF_PANEL_L1T != 0 && CH == 1 && WN == 8;
   if (!BNF_PANEL_ZPEEL) zero_acc();
   contract_all_t(wfl(LL), std::integral_constant<bool, kL1T>{});
   BNF_MARK(a, 3);

@@ -15,7 +15,7 @@ name = sys.argv[1]
 gk, nk, ek, _ = CONFIGS[name]
 X, y, scales = grid(**gk)
 net = NetSpec(input_scales=scales, fourier_degrees=[5, 5, 5], interactions=[], **nk)
-eng = Engine(net, X=X, y=y, seed=0, compute_dtype='bf16', **ek)
+eng = Engine(net, X=X, y=y, seed=0, compute_dtype=__import__('os').environ.get('BNF_BENCH_DTYPE', 'bf16'), **ek)
 eng.init_params(0.0 if ek['mode'] == 'vi' else float(np.log(np.nanstd(y) / 2)))
 eng.train(0, 1)
 torch.cuda.synchronize()
