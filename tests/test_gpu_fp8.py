@@ -123,3 +123,29 @@ def test_fp8_training_within_survey_8d_statistical_bars_of_fp32(layout):
     l, r = out[dt]
     assert abs(np.mean(l) / np.mean(l32) - 1) < 0.03, (dt, np.mean(l), np.mean(l32))
     assert abs(r / r32 - 1) < 0.05, (dt, r, r32)
+
+
+def test_fp8_through_the_estimator_api_and_its_shape_limits(golden_dir):
+  """`compute_dtype='fp8'` behind the public `fit()` / `predict()` (MAP, minibatch and full batch; VI): the fit runs the
+  fp8-storage training handles, predict runs the bf16 forward; the golden training rows stay within the bf16 class of the
+  reference's predictions (5e-2, like the bf16 engine); a shape without the row-panel pipeline is refused with a message."""
+  import os
+  import pandas as pd
+  from bayesnf_amd import BayesianNeuralFieldMAP, BayesianNeuralFieldVI
+  df = pd.read_csv(os.path.join(golden_dir, 'chickenpox.8.train.csv'), index_col=0, parse_dates=['datetime'])
+  gold = pd.read_csv(os.path.join(golden_dir, 'bnf-map.chickenpox.8.mini.pred.csv'), index_col=0).iloc[:100]
+  model = dict(width=256, depth=2, seasonality_periods=np.asarray([4.0, 52.1775]), num_seasonal_harmonics=np.asarray([2.0, 10]),
+               observation_model='NORMAL', feature_cols=['datetime', 'latitude', 'longitude'], target_col='chickenpox',
+               timetype='index', freq='W', standardize=['latitude', 'longitude'])
+  est = BayesianNeuralFieldMAP(**model, compute_dtype='fp8').fit(df, seed=np.array([0, 0], dtype=np.uint32), ensemble_size=4,
+                                                                 num_epochs=5, learning_rate=0.005)
+  means, _ = est.predict(df, quantiles=(0.5,))
+  assert np.abs(means.mean(axis=(0, 1)) - gold.yhat.values).max() < 5e-2
+  est = BayesianNeuralFieldMAP(**model, compute_dtype='fp8').fit(df, seed=1, ensemble_size=4, num_epochs=8, batch_size=32)
+  assert np.all(np.isfinite(est.losses_)) and est.losses_.shape[-1] == 8
+  vi = BayesianNeuralFieldVI(**model, compute_dtype='fp8').fit(df, seed=2, ensemble_size=2, num_epochs=6, kl_weight=0.1,
+                                                                sample_size_divergence=3, sample_size_posterior=5)
+  m_vi, _ = vi.predict(df, quantiles=(0.5,))
+  assert np.all(np.isfinite(vi.losses_)) and np.all(np.isfinite(m_vi))
+  with pytest.raises(ValueError, match='row-panel pipeline'):
+    BayesianNeuralFieldMAP(**dict(model, depth=1), compute_dtype='fp8').fit(df, seed=0, ensemble_size=2, num_epochs=2)
