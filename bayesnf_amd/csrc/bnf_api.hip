@@ -81,6 +81,7 @@ struct bnf_handle {
   NetDev nd;
   FreqTab ft;
   bool bf16 = false;
+  int f32_split = 0;      // BNF_DTYPE_F32S: the f32 contractions on split-bf16 MFMAs (GemmArgs.f32_split)
   bool q8 = false;        // BNF_DTYPE_FP8: bf16 contractions + fp8 operand copies for the weight-gradient kernels (bnf_gemm8.h)
   uint8_t* H0q = nullptr; // (Ev, Bp, Fp) e4m3 copy of the features (layer-0 weight gradient)
   float* qscale = nullptr;   // (Ev) s_H s_dZ of the step: written by the panel kernel, read by the weight-gradient kernels
@@ -358,6 +359,22 @@ static void launch_gemm_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep
   g.tiles_m = (g.M + 64 * WGM - 1) / (64 * WGM);
   g.tiles_n = (g.N + 64 * WGN - 1) / (64 * WGN);
   if (g.splitk < 1) g.splitk = 1;
+  if constexpr (std::is_same<T, float>::value) {
+    if (h->f32_split) {      // BNF_DTYPE_F32S: the split-bf16 instantiation of the same kernel
+      static std::atomic<uint64_t> attr_done_s{0};
+      allow_lds(h, &gemm_nt<T, EPI, TAG, WGM, WGN, true>, kLds, &attr_done_s);
+      const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
+      EpiArgs ep2 = ep;
+      ep2.ablate = h->ablate;
+      phase_prof_begin(h, kid, blocks, &ep2);
+      {
+        LaunchScope ls(h, kid);
+        hipLaunchKernelGGL((gemm_nt<T, EPI, TAG, WGM, WGN, true>), dim3(blocks), dim3(64 * WGM * WGN), kLds, h->stream, g, ep2);
+      }
+      phase_prof_end(h, kid, blocks, 64 * WGM * WGN);
+      return;
+    }
+  }
   static std::atomic<uint64_t> attr_done{0};
   allow_lds(h, &gemm_nt<T, EPI, TAG, WGM, WGN>, kLds, &attr_done);
   const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
@@ -418,6 +435,16 @@ static void launch_gemm_tn_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs&
   g.tiles_m = (g.M + 64 * WG - 1) / (64 * WG);
   g.tiles_n = (g.N + 64 * WG - 1) / (64 * WG);
   if (g.splitk < 1) g.splitk = 1;
+  if constexpr (std::is_same<T, float>::value) {
+    if (h->f32_split) {      // BNF_DTYPE_F32S
+      static std::atomic<uint64_t> attr_done_s{0};
+      allow_lds(h, &gemm_tn<T, TAG, WG, true>, kLds, &attr_done_s);
+      const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
+      LaunchScope ls(h, kid, st, true);
+      hipLaunchKernelGGL((gemm_tn<T, TAG, WG, true>), dim3(blocks), dim3(64 * WG * WG), kLds, st, g, ep);
+      return;
+    }
+  }
   static std::atomic<uint64_t> attr_done{0};
   allow_lds(h, &gemm_tn<T, TAG, WG>, kLds, &attr_done);
   const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
@@ -1351,7 +1378,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(BNF_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
                 cfg->device, prop.gcnArchName);
-  if (cfg->dtype != BNF_DTYPE_F32 && cfg->dtype != BNF_DTYPE_BF16 && cfg->dtype != BNF_DTYPE_FP8)
+  if (cfg->dtype != BNF_DTYPE_F32 && cfg->dtype != BNF_DTYPE_BF16 && cfg->dtype != BNF_DTYPE_FP8 && cfg->dtype != BNF_DTYPE_F32S)
     return fail(BNF_ERR_INVALID, "dtype %d", cfg->dtype);
   if (cfg->obs_model != BNF_OBS_NORMAL && cfg->obs_model != BNF_OBS_NB && cfg->obs_model != BNF_OBS_ZINB)
     return fail(BNF_ERR_INVALID, "observation model %d", cfg->obs_model);
@@ -1376,7 +1403,8 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
 
   bnf_handle* h = new bnf_handle();
   h->cfg = *cfg;
-  h->bf16 = cfg->dtype != BNF_DTYPE_F32;     // (fp8: bf16 contractions, fp8 operand copies for the weight gradients)
+  h->bf16 = cfg->dtype == BNF_DTYPE_BF16 || cfg->dtype == BNF_DTYPE_FP8;   // (fp8: bf16 contractions, fp8 operand copies for the weight gradients)
+  h->f32_split = cfg->dtype == BNF_DTYPE_F32S ? 2 : 0;
   h->q8 = cfg->dtype == BNF_DTYPE_FP8;
   h->es = h->bf16 ? 2 : 4;
   h->S = S;

@@ -173,6 +173,36 @@ struct Mma<float> {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[j], b.hi[j], acc, 0, 0, 0);
   }
+  // BNF_DTYPE_F32S (round 5): the same contraction on SPLIT-bf16 MFMAs.  Each f32 operand is split IN REGISTERS into two
+  // bf16 pieces, x = hi + lo with hi = bf16(x) and lo = bf16(x - hi) (round to nearest even: 16 operand bits, |x - hi - lo| <=
+  // 2^-18 |x|), and the three products that matter -- lo*hi, hi*lo, hi*hi, smallest first -- are summed by three
+  // v_mfma_f32_32x32x16_bf16 (32 cycles each, f32 accumulate) where the exact chain issues eight v_mfma_f32_32x32x2_f32 of 64
+  // cycles: 96 against 512 matrix-pipe cycles per fragment pair, + 20 VALU per fragment for the split.  The lane layout needs
+  // no change: a lane's 8 consecutive k ARE the bf16 32x32x16 fragment.  Measured (profiles/r05_panel_ab.md r05l): a
+  // contraction is good to 5e-6 of its largest output (exact chain: 1e-7), the f32 storage, accumulation and epilogues are
+  // unchanged; every fp32 parity bar and all three golden reproductions (< 1e-4) hold, the C2 step goes from 11.1 to 6.5 ms.
+  // (A third piece -- six MFMAs, 24 operand bits -- passes even the 2e-6 exactness tests but is only 6 % faster than f32.)
+  struct Split {
+    bf16x8 hi, lo;
+  };
+  __device__ static __forceinline__ Split split(const Frag& f) {
+    Split s;
+    const float x[8] = {f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
+    uint32_t wh[4], wl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      wh[q] = pack_bf16x2(x[2 * q], x[2 * q + 1]);
+      wl[q] = pack_bf16x2(x[2 * q] - __builtin_bit_cast(float, wh[q] << 16), x[2 * q + 1] - __builtin_bit_cast(float, wh[q] & 0xffff0000u));
+    }
+    s.hi = __builtin_bit_cast(bf16x8, u32x4{wh[0], wh[1], wh[2], wh[3]});
+    s.lo = __builtin_bit_cast(bf16x8, u32x4{wl[0], wl[1], wl[2], wl[3]});
+    return s;
+  }
+  __device__ static __forceinline__ void mma_split(f32x16& acc, const Split& a, const Split& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+  }
 };
 
 // XCD-aware bijective remap of the linear workgroup id (8 XCDs, block b runs on
@@ -210,7 +240,10 @@ __host__ __device__ constexpr int epi_extra_lds(int epi, int wgm, int wgn, int e
 //   2 x N  128-row panels spanning the WHOLE layer width (EPI_LAST): the workgroup owns
 //          complete rows, so the output-layer dot, the likelihood and the backward pass of
 //          the last activation all happen on the accumulators (no A_L^T round trip).
-template <typename T, int EPI, int TAG, int WGM, int WGN>
+// SPLIT (float only): the contraction on split-bf16 MFMAs (BNF_DTYPE_F32S, Mma<float>::mma_split) -- its own instantiation:
+// with both arithmetic paths behind a run-time flag in one kernel every f32 contraction lost 2 - 4x to register pressure
+// (gpurun_out/r05m: C2 step 12.7 / 18.3 ms against 6.5 / 11.1 as separate instantiations)
+template <typename T, int EPI, int TAG, int WGM, int WGN, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void gemm_nt(const GemmArgs g, const EpiArgs ep) {
   using M_ = Mma<T>;
   constexpr int kBM = 64 * WGM, kBN = 64 * WGN, kThreads = 64 * WGM * WGN, kWaves = WGM * WGN;
@@ -380,10 +413,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
             fa[i] = M_::load(sA + a_row[i] * kRowBytes, a_swz[i], ks, kg);
             fb[i] = M_::load(sB + b_row[i] * kRowBytes, b_swz[i], ks, kg);
           }
+          if constexpr (std::is_same<T, float>::value && SPLIT) {   // BNF_DTYPE_F32S: three bf16 MFMAs per fragment pair
+            typename Mma<float>::Split sa[2], sb2[2];
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+              sa[i] = Mma<float>::split(fa[i]);
+              sb2[i] = Mma<float>::split(fb[i]);
+            }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) M_::mma(acc[i][j], fa[i], fb[j]);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) Mma<float>::mma_split(acc[i][j], sa[i], sb2[j]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) M_::mma(acc[i][j], fa[i], fb[j]);
+          }
         }
       }
     }
@@ -995,7 +1041,7 @@ __host__ __device__ constexpr int gemm_tn_lds(int wg) {
 // WG x WG waves, each a 64 x 64 sub-tile: WG = 2 -> 128 x 128 (default), WG = 4 -> 256 x 256
 // with 16 waves for the W x W weight gradients (W a multiple of 256, >= 512): this kernel is
 // almost pure K loop and bound by the operand stream into LDS, which the large tile halves.
-template <typename T, int TAG, int WG>
+template <typename T, int TAG, int WG, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WG * WG, WG == 2 ? 2 : 4) void gemm_tn(const GemmArgs g, const EpiArgs ep) {
   using C_ = TnCfg<T>;
   constexpr int kBM = 64 * WG, kBN = 64 * WG, kWaves = WG * WG;
@@ -1135,6 +1181,34 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 2 ? 2 : 4) void gemm_tn(const G
         // f32: MFMA step s of group ks contracts rows ks*16 + s (lanes 0-31) and ks*16 + 8 + s (32-63)
 #pragma unroll
         for (int ks = 0; ks < kRows / 16; ++ks) {
+          if constexpr (SPLIT) {
+            // BNF_DTYPE_F32S: the lane's 8 batch rows of one column = the bf16 32x32x16 fragment: gather, split,
+            // three bf16 MFMAs per fragment pair (Mma<float>::mma_split)
+            typename Mma<float>::Frag ga[2], gb[2];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+              const int row = ks * 16 + kg * 8 + s8;
+              const int rsw = (row & 3) << 6;
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const int ba = (wr * 64 + i * 32 + frow) * 4, bb = (wc * 64 + i * 32 + frow) * 4;
+                const float va = *reinterpret_cast<const float*>(sA + row * kRB + ((ba & ~63) ^ rsw) + (ba & 63));
+                const float vb = *reinterpret_cast<const float*>(sB + row * kRB + ((bb & ~63) ^ rsw) + (bb & 63));
+                if (s8 < 4) { ga[i].lo[s8] = va; gb[i].lo[s8] = vb; } else { ga[i].hi[s8 - 4] = va; gb[i].hi[s8 - 4] = vb; }
+              }
+            }
+            typename Mma<float>::Split sa[2], sb2[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              sa[i] = Mma<float>::split(ga[i]);
+              sb2[i] = Mma<float>::split(gb[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) Mma<float>::mma_split(acc[i][j], sa[i], sb2[j]);
+            continue;
+          }
 #pragma unroll
           for (int s8 = 0; s8 < 8; ++s8) {
             const int row = ks * 16 + kg * 8 + s8;

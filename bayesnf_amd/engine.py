@@ -21,8 +21,10 @@ _warned_default_dtype = False
 
 
 def default_dtype(compute_dtype=None) -> str:
-  """'fp32' unless the caller or BNF_DTYPE says otherwise: the float32 engine is the parity path
-  (exact-f32 MFMA; it reproduces the reference's golden predictions), 'bf16' the throughput path
+  """'fp32' unless the caller or BNF_DTYPE says otherwise: the float32 engine is the parity path (f32 storage, accumulation
+  and epilogues; contractions on split-bf16 MFMAs with 16 operand bits -- include/bnf.h BNF_DTYPE_F32S; it reproduces the
+  reference's golden predictions to < 1e-4 and holds every fp32 parity bar; 'fp32_exact' runs the exact f32 MFMA chain
+  instead, 1.7x slower), 'bf16' the throughput path
   (bf16 contraction operands, f32 accumulation -- the numerics class of the reference's TPU runs;
   ~5x the member-steps/s at the benchmark size), 'fp8' = 'bf16' with FP8 OPERAND STORAGE for the weight-gradient
   contractions (include/bnf.h BNF_DTYPE_FP8; training handles on the row-panel pipeline only -- a forward-only handle
@@ -32,12 +34,12 @@ def default_dtype(compute_dtype=None) -> str:
     _warned_default_dtype = True
     import warnings
     warnings.warn("bayesnf_amd: compute_dtype defaults to 'fp32' (parity arithmetic). Pass "
-                  "compute_dtype='bf16' (or set BNF_DTYPE=bf16) for the ~5x faster bf16-MFMA engine.",
+                  "compute_dtype='bf16' (or set BNF_DTYPE=bf16) for the ~4x faster bf16-MFMA engine.",
                   stacklevel=3)
   dt = compute_dtype or os.environ.get('BNF_DTYPE', 'fp32')
   if dt not in _native.DTYPE:
     raise ValueError(f'compute_dtype must be one of {sorted(_native.DTYPE)}')
-  return {0: 'fp32', 1: 'bf16', 2: 'fp8'}[_native.DTYPE[dt]]
+  return {0: 'fp32_exact', 1: 'bf16', 2: 'fp8', 3: 'fp32'}[_native.DTYPE[dt]]
 
 
 def _ptr(t):

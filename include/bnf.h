@@ -55,7 +55,13 @@ enum { BNF_DTYPE_F32 = 0, BNF_DTYPE_BF16 = 1,   /* arithmetic of the dense contr
         * e5m2 over a per-member power of two, and dK_l = H_l^T dZ_l runs on the non-scaled fp8 MFMA; forward and
         * backward-data contractions stay bf16.  Needs the row-panel pipeline (depth >= 2, padded width 256 / 512 / 1024,
         * <= 128 padded features): bnf_create refuses other shapes. */
-       BNF_DTYPE_FP8 = 2 };
+       BNF_DTYPE_FP8 = 2,
+       /* f32 storage, accumulation and epilogues like BNF_DTYPE_F32, but the contractions run on SPLIT-bf16 MFMAs: every f32
+        * operand is split in registers into two bf16 pieces (16 operand bits) and hi*hi + hi*lo + lo*hi are summed by three
+        * bf16 MFMAs -- products good to ~1e-5, every fp32 parity bar and the three reference goldens (< 1e-4) hold, 1.7x the
+        * speed of the exact f32 MFMA chain.  What the Python estimators run by default (compute_dtype 'fp32'); BNF_DTYPE_F32
+        * ('fp32_exact') keeps the exact v_mfma_f32_32x32x2_f32 arithmetic. */
+       BNF_DTYPE_F32S = 3 };
 enum { BNF_OBS_NORMAL = 0, BNF_OBS_NB = 1, BNF_OBS_ZINB = 2 }; /* models.py:30-33 */
 enum { BNF_MODE_MAP = 0, BNF_MODE_VI = 1 };       /* MLE = MAP with prior_weight 0 (spatiotemporal.py:551) */
 

@@ -192,11 +192,15 @@ def test_layout_parity_map_mle_fp32(name, pw):
   eng.close()
 
 
-def test_layout_parity_c4_minibatch_fp32():
-  """C4 layout, minibatch MLE with the device's own shuffles fed to the oracle: 2 epochs."""
+@pytest.mark.parametrize('dtype,param_bar', [('fp32_exact', 1e-3), ('fp32', 8e-3)])
+def test_layout_parity_c4_minibatch_fp32(dtype, param_bar):
+  """C4 layout (W = 1024, depth 4), minibatch MLE with the device's own shuffles fed to the oracle: 2 epochs.  Parameters
+  after 2 x 2 Adam steps from a random start: 1e-3 with the exact f32 chain; the split-bf16 contraction of the default
+  'fp32' (products good to ~1e-5) measured 4.9e-3 here -- Adam's first steps are lr * sign(g) on every element, so the
+  elements whose gradient sits at the 1e-5 level move by a whole lr either way (the losses agree to 1e-4 in both)."""
   n_rows, B, E = 300, 128, 2
   net, model, X, y = _small_problem('C4', n_rows, seed=3)
-  eng = _engine(net, X, y, members=E, batch=B, prior_weight=0.0, seed=4, compute_dtype='fp32')
+  eng = _engine(net, X, y, members=E, batch=B, prior_weight=0.0, seed=4, compute_dtype=dtype)
   eng.init_params(0.2)
   theta0 = eng.get_params().astype(np.float64)
   steps = n_rows // B
@@ -206,7 +210,7 @@ def test_layout_parity_c4_minibatch_fp32():
   theta_o, losses_o = O.train_map(model, theta0, X, y, lr=0.005, num_epochs=2, batch_size=B, prior_weight=0.0,
                                   row_index_fn=lambda ep: idx[ep])
   np.testing.assert_allclose(losses.cpu().numpy(), losses_o, rtol=1e-4)
-  assert util.rel_err(eng.get_params(), theta_o) < 1e-3
+  assert util.rel_err(eng.get_params(), theta_o) < param_bar, util.rel_err(eng.get_params(), theta_o)
   eng.close()
 
 

@@ -24,7 +24,14 @@ def _engine(net, X, y, **kw):
 
 
 # --------------------------------------------------------------------------- GEMM core
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+# The contraction cores on their own, max |C - ref| / max |ref|: 'fp32_exact' (BNF_DTYPE_F32: v_mfma_f32_32x32x2_f32, exact
+# products) and 'bf16' (against the product of the bf16-rounded operands) to f32 summation order; 'fp32' (BNF_DTYPE_F32S,
+# what fit() runs by default: f32 operands split in registers into two bf16 pieces, hi*hi + hi*lo + lo*hi on bf16 MFMAs:
+# 16 operand bits) measured 3.6e-6 .. 5.9e-6 (gpurun_out/r05l) -- bar 1e-5.
+_CORE_BAR = {'fp32_exact': 2e-6, 'fp32': 1e-5, 'bf16': 2e-6}
+
+
+@pytest.mark.parametrize('dtype', ['fp32_exact', 'fp32', 'bf16'])
 @pytest.mark.parametrize('shape', [(128, 128, 64), (300, 200, 128), (57, 512, 320), (1000, 64, 64)])
 def test_contraction_core(dtype, shape):
   M, N, K = shape
@@ -38,11 +45,11 @@ def test_contraction_core(dtype, shape):
     A = torch.tensor(A).bfloat16().float().numpy()
     Bt = torch.tensor(Bt).bfloat16().float().numpy()
   ref = A.astype(np.float64) @ Bt.astype(np.float64).T
-  assert util.rel_err(Cd, ref) < 2e-6, util.rel_err(Cd, ref)
+  assert util.rel_err(Cd, ref) < _CORE_BAR[dtype], util.rel_err(Cd, ref)
   eng.close()
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32_exact', 'fp32', 'bf16'])
 @pytest.mark.parametrize('shape', [(64, 128, 128), (320, 64, 192), (1024, 512, 512), (128, 56, 200)])
 def test_weight_gradient_core(dtype, shape):
   """C = A^T B on row-major operands (transpose reads in LDS)."""
@@ -57,11 +64,11 @@ def test_weight_gradient_core(dtype, shape):
     A = torch.tensor(A).bfloat16().float().numpy()
     B = torch.tensor(B).bfloat16().float().numpy()
   ref = A.astype(np.float64).T @ B.astype(np.float64)
-  assert util.rel_err(Cd, ref) < 2e-6, util.rel_err(Cd, ref)
+  assert util.rel_err(Cd, ref) < _CORE_BAR[dtype], util.rel_err(Cd, ref)
   eng.close()
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32_exact', 'fp32', 'bf16'])
 def test_large_tile_kernels_forced(dtype, monkeypatch):
   """256 x 256 tiles (16 waves) of the contraction cores, forced at sizes the oracle can check
   (production picks them only when they fill the chip): weight-gradient core + a train step."""
@@ -77,7 +84,7 @@ def test_large_tile_kernels_forced(dtype, monkeypatch):
     B = torch.tensor(B).bfloat16().float().numpy()
   Cd = eng.debug_gemm_tn(A, B)
   ref = A.astype(np.float64).T @ B.astype(np.float64)
-  assert util.rel_err(Cd, ref) < 2e-6, util.rel_err(Cd, ref)
+  assert util.rel_err(Cd, ref) < _CORE_BAR[dtype], util.rel_err(Cd, ref)
   eng.close()
   # whole step at W = 256: forward 4 x 4 tiles (bf16), W x W weight gradient 4 x 4 tiles
   n_rows, E = 300, 2
@@ -87,7 +94,7 @@ def test_large_tile_kernels_forced(dtype, monkeypatch):
   eng.set_params(theta)
   loss_d, g_d = eng.debug_loss_and_grad()
   loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
-  tol_l, tol_g = (2e-5, 5e-4) if dtype == 'fp32' else (5e-3, 6e-2)
+  tol_l, tol_g = (2e-5, 5e-4) if dtype.startswith('fp32') else (5e-3, 6e-2)
   np.testing.assert_allclose(loss_d, loss_o, rtol=tol_l)
   errs = util.per_leaf_rel_err(model, g_d, g_o)
   bad = {k: v for k, v in errs.items() if v > tol_g}
