@@ -1,7 +1,8 @@
 #!/bin/bash
 # Stall / utilisation counters of every kernel of the bench command, a few per pass
 # (counter-only passes: --pmc with --kernel-trace, nothing else).
-# Usage: bash scripts/gpu_counters.sh <tag> ; passes are the lines of PASSES below.
+# Usage: [CMD='python scripts/profile_config.py "C5/8 wind-like MAP (bf16)"'] bash scripts/gpu_counters.sh <tag> ; passes are the lines
+# of PASSES below (PASSn= overrides / empties a pass); CMD defaults to the bench command.
 TAG=${1:-ctr}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -10,7 +11,7 @@ while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $line --kernel-trace --output-format csv -d "$OUT/pass$i" -o pmc -- \
-     python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline > "$OUT/pass$i.json" 2> "$OUT/pass$i.err"
+     bash -c "cd $ROOT && ${CMD:-python bench.py --steps 3 --warmup 2 --no-cpu-baseline}" > "$OUT/pass$i.json" 2> "$OUT/pass$i.err"
   echo "pass $i ($line) rc=$?"
   find "$OUT/pass$i" -name "*kernel_trace*" -delete
 done <<PASSES
