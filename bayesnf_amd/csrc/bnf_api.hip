@@ -361,15 +361,17 @@ static void launch_gemm_wg(bnf_handle* h, int kid, GemmArgs g, const EpiArgs& ep
   if (g.splitk < 1) g.splitk = 1;
   if constexpr (std::is_same<T, float>::value) {
     if (h->f32_split) {      // BNF_DTYPE_F32S: the split-bf16 instantiation of the same kernel
+      // B is a packed Dense kernel (split when packed: k_pack_weights) everywhere but in the test entry's plain product
+      constexpr int kS = EPI == EPI_PLAIN ? 1 : 2;
       static std::atomic<uint64_t> attr_done_s{0};
-      allow_lds(h, &gemm_nt<T, EPI, TAG, WGM, WGN, true>, kLds, &attr_done_s);
+      allow_lds(h, &gemm_nt<T, EPI, TAG, WGM, WGN, kS>, kLds, &attr_done_s);
       const unsigned blocks = (unsigned)(g.members * g.tiles_m * g.tiles_n * g.splitk);
       EpiArgs ep2 = ep;
       ep2.ablate = h->ablate;
       phase_prof_begin(h, kid, blocks, &ep2);
       {
         LaunchScope ls(h, kid);
-        hipLaunchKernelGGL((gemm_nt<T, EPI, TAG, WGM, WGN, true>), dim3(blocks), dim3(64 * WGM * WGN), kLds, h->stream, g, ep2);
+        hipLaunchKernelGGL((gemm_nt<T, EPI, TAG, WGM, WGN, kS>), dim3(blocks), dim3(64 * WGM * WGN), kLds, h->stream, g, ep2);
       }
       phase_prof_end(h, kid, blocks, 64 * WGM * WGN);
       return;
@@ -545,7 +547,7 @@ static void run_pack(bnf_handle* h, const float* theta, int nmem) {
     dim3 grid((unsigned)((n_pad / 32) * (h->W / 32)), (unsigned)nmem);
     hipLaunchKernelGGL((k_pack_weights<T>), grid, dim3(256), 0, h->stream, theta, (int64_t)h->Pf,
                        h->nd.off_kernel[l], n_in, n_pad, h->W, (T*)h->Kn[l], (T*)h->Kt[l],
-                       h->pack_batch[l]);
+                       h->pack_batch[l], (int32_t)(sizeof(T) == 4 && h->f32_split ? 1 : 0));
   }
 }
 

@@ -186,6 +186,26 @@ struct Mma<float> {
     bf16x8 hi, lo;
   };
   __device__ static __forceinline__ Split split(const Frag& f) {
+    // five instructions per pair of elements: v_cvt_pk_bf16_f32 (hi), shift / mask back to two floats, ONE packed
+    // subtraction, v_cvt_pk_bf16_f32 (lo).  (Left to itself hipcc converts the first element of every pair twice.)
+    Split s;
+    const f32x2 x[4] = {{f.lo[0], f.lo[1]}, {f.lo[2], f.lo[3]}, {f.hi[0], f.hi[1]}, {f.hi[2], f.hi[3]}};
+    uint32_t wh[4], wl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      wh[q] = pack_bf16x2(x[q][0], x[q][1]);
+      asm("" : "+v"(wh[q]));
+      const f32x2 hf = {__builtin_bit_cast(float, wh[q] << 16), __builtin_bit_cast(float, wh[q] & 0xffff0000u)};
+      const f32x2 d = x[q] - hf;
+      wl[q] = pack_bf16x2(d[0], d[1]);
+    }
+    s.hi = __builtin_bit_cast(bf16x8, u32x4{wh[0], wh[1], wh[2], wh[3]});
+    s.lo = __builtin_bit_cast(bf16x8, u32x4{wl[0], wl[1], wl[2], wl[3]});
+    return s;
+  }
+  // the same split as hipcc schedules it on its own (seven instructions per pair, no opaque value in the chain): what
+  // gemm_tn's gathered fragments run fastest with (r05t: 1374 against 1532 us with the form above)
+  __device__ static __forceinline__ Split split_plain(const Frag& f) {
     Split s;
     const float x[8] = {f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
     uint32_t wh[4], wl[4];
@@ -196,6 +216,15 @@ struct Mma<float> {
     }
     s.hi = __builtin_bit_cast(bf16x8, u32x4{wh[0], wh[1], wh[2], wh[3]});
     s.lo = __builtin_bit_cast(bf16x8, u32x4{wl[0], wl[1], wl[2], wl[3]});
+    return s;
+  }
+  // an operand that was split when it was PACKED (the Dense kernels: k_pack_weights writes, in place of the 8 floats of
+  // every aligned group of 8 consecutive k, their 8 hi parts and then their 8 lo parts -- the same 32 bytes): the
+  // fragment's first 16 bytes are the hi operand, the second 16 the lo operand, no arithmetic
+  __device__ static __forceinline__ Split presplit(const Frag& f) {
+    Split s;
+    s.hi = __builtin_bit_cast(bf16x8, f.lo);
+    s.lo = __builtin_bit_cast(bf16x8, f.hi);
     return s;
   }
   __device__ static __forceinline__ void mma_split(f32x16& acc, const Split& a, const Split& b) {
@@ -242,8 +271,11 @@ __host__ __device__ constexpr int epi_extra_lds(int epi, int wgm, int wgn, int e
 //          the last activation all happen on the accumulators (no A_L^T round trip).
 // SPLIT (float only): the contraction on split-bf16 MFMAs (BNF_DTYPE_F32S, Mma<float>::mma_split) -- its own instantiation:
 // with both arithmetic paths behind a run-time flag in one kernel every f32 contraction lost 2 - 4x to register pressure
-// (gpurun_out/r05m: C2 step 12.7 / 18.3 ms against 6.5 / 11.1 as separate instantiations)
-template <typename T, int EPI, int TAG, int WGM, int WGN, bool SPLIT = false>
+// (gpurun_out/r05m: C2 step 12.7 / 18.3 ms against 6.5 / 11.1 as separate instantiations).  SPLIT 1: both operands split in
+// registers; 2: B is a Dense kernel that k_pack_weights split when it packed it (every launch but the test entry's plain
+// product) -- the K loop's VALU goes from 424 to 174 instructions per 48 MFMAs, the layer contractions get 9 - 12 % shorter
+// (they are then bound by the f32 operand stream through LDS-DMA, ~13 B/clk/CU: profiles/r05_panel_ab.md r05t)
+template <typename T, int EPI, int TAG, int WGM, int WGN, int SPLIT = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void gemm_nt(const GemmArgs g, const EpiArgs ep) {
   using M_ = Mma<T>;
   constexpr int kBM = 64 * WGM, kBN = 64 * WGN, kThreads = 64 * WGM * WGN, kWaves = WGM * WGN;
@@ -418,7 +450,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, Mma<T>::min_waves(WGM * WGN)) void 
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               sa[i] = Mma<float>::split(fa[i]);
-              sb2[i] = Mma<float>::split(fb[i]);
+              if constexpr (SPLIT == 2) sb2[i] = Mma<float>::presplit(fb[i]);   // B = Dense kernels packed as hi | lo
+              else sb2[i] = Mma<float>::split(fb[i]);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1200,8 +1233,8 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 2 ? 2 : 4) void gemm_tn(const G
             typename Mma<float>::Split sa[2], sb2[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              sa[i] = Mma<float>::split(ga[i]);
-              sb2[i] = Mma<float>::split(gb[i]);
+              sa[i] = Mma<float>::split_plain(ga[i]);
+              sb2[i] = Mma<float>::split_plain(gb[i]);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)

@@ -671,12 +671,30 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void k_last_bwd(NetDev
 //   Kt (W, n_pad)  = K^T          -> Bt of the forward contraction
 // 32x32 tiles through LDS so both writes are coalesced.
 // ---------------------------------------------------------------------------
+// split != 0 (T = float, BNF_DTYPE_F32S): every aligned group of 8 consecutive elements of a packed row -- 8 consecutive
+// k of the contraction the copy is the B operand of -- holds, in its 32 bytes, the 8 bf16 hi parts and then the 8 bf16 lo
+// parts of its floats (hi = bf16(x), lo = bf16(x - hi)): the split-bf16 contraction reads its B fragments ready-made
+// (Mma<float>::presplit) instead of splitting every weight once per workgroup that uses it.
+template <typename T>
+__device__ __forceinline__ void store_packed(T* row, int p, float v, int split) {
+  if constexpr (sizeof(T) == 4) {
+    if (split) {
+      uint16_t* q = reinterpret_cast<uint16_t*>(row + (p & ~7));
+      const uint16_t hi = f32_to_bf16_bits(v);
+      q[p & 7] = hi;
+      q[8 + (p & 7)] = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
+      return;
+    }
+  }
+  Elem<T>::store(row + p, v);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ theta,
                                                       int64_t theta_stride, int32_t off_kernel,
                                                       int32_t n_in, int32_t n_pad, int32_t W,
                                                       T* __restrict__ Kn, T* __restrict__ Kt,
-                                                      int64_t pack_batch) {
+                                                      int64_t pack_batch, int32_t split) {
   __shared__ float tile[32][33];
   const int e = blockIdx.y;
   const int tiles_j = W / 32;
@@ -690,13 +708,13 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
     const int i = ti * 32 + ty + s * 8, j = tj * 32 + tx;
     const float v = (i < n_in) ? K[(int64_t)i * W + j] : 0.f;
     tile[ty + s * 8][tx] = v;
-    if (i < n_pad) Elem<T>::store(kn + (int64_t)i * W + j, v);
+    if (i < n_pad) store_packed(kn + (int64_t)i * W, j, v, split);
   }
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int j = tj * 32 + ty + s * 8, i = ti * 32 + tx;
-    if (i < n_pad) Elem<T>::store(kt + (int64_t)j * n_pad + i, tile[tx][ty + s * 8]);
+    if (i < n_pad) store_packed(kt + (int64_t)j * n_pad, i, tile[tx][ty + s * 8], split);
   }
 }
 

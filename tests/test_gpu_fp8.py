@@ -94,6 +94,61 @@ def test_fp8_copies_and_step_gradients(width, depth, n_rows):
   assert not bad, ('vs oracle', bad)
 
 
+@pytest.mark.parametrize('obs,width,depth,n_rows', [('NB', 256, 2, 700), ('ZINB', 512, 3, 260)])
+def test_fp8_count_models_keep_the_backward_signals_in_range(obs, width, depth, n_rows):
+  """NB / ZINB (models.py:166-191): d out is a count residual (tens, not residual / sigma^2), the e5m2 scale is
+  2^(round(log2(c gamma_o)) - 6) without a sigma -- the stored backward signals must neither saturate (57344 s) nor flush:
+  every dZ copy within e5m2's 2^-3 of the bf16 copy where it matters, every other leaf the bf16 pipeline's, Dense-kernel
+  gradients within 6e-2 of the float64 oracle's leaf maximum (NORMAL: 4e-2 -- count residuals are heavy-tailed, a few rows
+  carry the sum and the two-mantissa-bit rounding of THEIR signals averages out over fewer terms; measured 4.4e-2)."""
+  E = 2
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth, observation_model=obs)
+  theta = util.random_theta(model, E, scale=0.3)
+  res, dz = {}, {}
+  for dt in ('fp8', 'bf16'):
+    eng = _engine(net, X, y, members=E, compute_dtype=dt, pipeline='panel')
+    eng.set_params(theta)
+    res[dt] = eng.debug_loss_and_grad()
+    dz[dt] = [eng.debug_activation(300 + l) for l in range(depth)]
+    eng.close()
+  for l in range(depth):
+    a, b = dz['fp8'][l], dz['bf16'][l]
+    assert np.all(np.isfinite(a))
+    big = np.abs(b) > 1e-3 * np.abs(b).max()
+    assert np.max(np.abs(a - b)[big] / np.abs(b)[big]) <= 2.0 ** -3 + 1e-6, l
+  _, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
+  np.testing.assert_allclose(res['fp8'][0], res['bf16'][0], rtol=1e-6)
+  kernels = [f'Dense_{l}/kernel' for l in range(depth)] + ['Dense_0/bias']
+  e8 = util.per_leaf_rel_err(model, res['fp8'][1], res['bf16'][1])
+  bad = {k: v for k, v in e8.items() if k not in kernels and v > 1e-4}
+  assert not bad, ('leaves that do not read the copies', bad)
+  eo = util.per_leaf_rel_err(model, res['fp8'][1], g_o)
+  bad = {k: eo[k] for k in kernels if eo[k] > (8e-2 if k == 'Dense_0/bias' else 6e-2)}
+  assert not bad, ('vs oracle', bad)
+
+
+@pytest.mark.parametrize('width,depth,S', [(256, 2, 3), (512, 3, 2)])
+def test_fp8_vi_step_against_the_bf16_panel_step(width, depth, S):
+  """ensemble_vi's step (inference.py:626-764) on fp8 operand storage: one scale per VIRTUAL member (member x Monte-Carlo
+  sample); same seed, same noise -- the loss is the bf16 step's, d mu / d rho of the Dense kernels within the fp8 bar of
+  it, every other leaf equal."""
+  n_rows, E = 300, 2
+  net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth)
+  res = {}
+  for dt in ('fp8', 'bf16'):
+    eng = _engine(net, X, y, mode='vi', members=E, vi_samples=S, kl_weight=0.2, seed=5, learning_rate=0.01,
+                  compute_dtype=dt, pipeline='panel')
+    eng.init_params(0.0)
+    res[dt] = eng.debug_loss_and_grad(0, 0)
+    eng.close()
+  np.testing.assert_allclose(res['fp8'][0], res['bf16'][0], rtol=1e-6)
+  kernels = [f'Dense_{l}/kernel' for l in range(depth)] + ['Dense_0/bias']
+  for k in (0, 1):
+    e8 = util.per_leaf_rel_err(model, res['fp8'][1][k], res['bf16'][1][k])
+    bad = {n: v for n, v in e8.items() if v > (8e-2 if n == 'Dense_0/bias' else 4e-2 if n in kernels else 1e-4)}
+    assert not bad, (('mu', 'rho')[k], bad)   # (d bias0 = 1^T dZq_0: e5m2 alone, no averaging partner -- as in the MAP test)
+
+
 @pytest.mark.parametrize('layout', ['C2', 'C5'])
 def test_fp8_training_within_survey_8d_statistical_bars_of_fp32(layout):
   """SURVEY.md 8d, fp8 class: from identical initial parameters, final loss within 3 % and RMSE of the ensemble-mean
