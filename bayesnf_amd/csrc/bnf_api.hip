@@ -540,15 +540,20 @@ static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1
 template <typename T>
 static void run_pack(bnf_handle* h, const float* theta, int nmem) {
   LaunchScope ls(h, KID_PACK);
-  hipLaunchKernelGGL(k_member_scalars, dim3(cdiv(nmem, 64)), dim3(64), 0, h->stream, h->nd, theta,
-                     (int64_t)h->Pf, (int32_t)nmem, h->scal);
+  PackWJobs jb{};
+  jb.n_layers = h->L;
+  int tiles = 0;
   for (int l = 0; l < h->L; ++l) {
-    const int n_in = (l == 0) ? h->F : h->W, n_pad = (l == 0) ? h->Fp : h->W;
-    dim3 grid((unsigned)((n_pad / 32) * (h->W / 32)), (unsigned)nmem);
-    hipLaunchKernelGGL((k_pack_weights<T>), grid, dim3(256), 0, h->stream, theta, (int64_t)h->Pf,
-                       h->nd.off_kernel[l], n_in, n_pad, h->W, (T*)h->Kn[l], (T*)h->Kt[l],
-                       h->pack_batch[l], (int32_t)(sizeof(T) == 4 && h->f32_split ? 1 : 0));
+    jb.off_kernel[l] = h->nd.off_kernel[l];
+    jb.n_in[l] = (l == 0) ? h->F : h->W;
+    jb.n_pad[l] = (l == 0) ? h->Fp : h->W;
+    jb.tile0[l] = tiles;
+    tiles += (jb.n_pad[l] / 32) * (h->W / 32);
+    jb.Kn[l] = h->Kn[l]; jb.Kt[l] = h->Kt[l]; jb.pack_batch[l] = h->pack_batch[l];
   }
+  jb.tile0[h->L] = tiles;
+  hipLaunchKernelGGL((k_pack_weights<T>), dim3((unsigned)tiles, (unsigned)nmem), dim3(256), 0, h->stream, theta,
+                     (int64_t)h->Pf, jb, (int32_t)h->W, (int32_t)(sizeof(T) == 4 && h->f32_split ? 1 : 0), h->nd, h->scal);
 }
 
 // featurise + forward contractions for `rows` batch rows of `nmem` (virtual)

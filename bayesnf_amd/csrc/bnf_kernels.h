@@ -11,7 +11,7 @@
 namespace bnf {
 
 // Device copy of the static network description (passed by value, ~700 B).
-// Per-member table of transformed scalar leaves (k_member_scalars, once per step):
+// Per-member table of transformed scalar leaves (member_scalars_row, once per step, by the kernel that packs the weights):
 //   [l]                 softplus(layer scale l)          [BNF_MAX_LAYERS]     sigmoid(activation weight)
 //   [BNF_MAX_LAYERS+1]  softplus(output scale)
 //   [kScalGroup + g]    softplus(feature-group scale g)  [kScalInput + d]     in_scale[d] * exp(log_scale_adjustment[d])
@@ -472,13 +472,6 @@ __device__ __forceinline__ void member_scalars_row(const NetDev& nd, const float
   for (int d = 0; d < nd.D; ++d) o[kScalInput + d] = nd.in_scale[d] * expf(th[nd.off_lsa + d]);
   for (int g = 0; g < nd.n_groups; ++g) o[kScalGfac + g] = sigmoidf(th[nd.group_scale_off[g]]) / o[kScalGroup + g];
 }
-__global__ void k_member_scalars(NetDev nd, const float* __restrict__ theta, int64_t stride, int32_t n,
-                                 float* __restrict__ scal) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  member_scalars_row(nd, theta + (int64_t)e * stride, scal + (int64_t)e * kScalStride);
-}
-
 // ---------------------------------------------------------------------------
 // output layer + likelihood, one thread per row.  The last forward contraction
 // has already accumulated vacc[row] = sum_j H_L[row][j] k_o[j] (EPI_FWD vdot).
@@ -689,20 +682,35 @@ __device__ __forceinline__ void store_packed(T* row, int p, float v, int split) 
   Elem<T>::store(row + p, v);
 }
 
+// ONE launch packs every layer (a job per layer: 32 x 32 tiles [tile0[l], tile0[l + 1]) of grid.x) and fills the member's
+// row of the scalar table (block 0 of the member, thread 0: what k_member_scalars does) -- the per-layer launches + the
+// scalar kernel were three dependent launches of a twelve-launch step at depth 2, i.e. a sixth of the step at the sizes
+// the reference's own fixtures have (100 rows: the step is launch latency).
+struct PackWJobs {
+  int32_t n_layers;
+  int32_t off_kernel[BNF_MAX_LAYERS], n_in[BNF_MAX_LAYERS], n_pad[BNF_MAX_LAYERS], tile0[BNF_MAX_LAYERS + 1];
+  void* Kn[BNF_MAX_LAYERS];
+  void* Kt[BNF_MAX_LAYERS];
+  int64_t pack_batch[BNF_MAX_LAYERS];
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ theta,
-                                                      int64_t theta_stride, int32_t off_kernel,
-                                                      int32_t n_in, int32_t n_pad, int32_t W,
-                                                      T* __restrict__ Kn, T* __restrict__ Kt,
-                                                      int64_t pack_batch, int32_t split) {
+__global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ theta, int64_t theta_stride, PackWJobs jb,
+                                                      int32_t W, int32_t split, NetDev nd, float* __restrict__ scal) {
   __shared__ float tile[32][33];
   const int e = blockIdx.y;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && scal)
+    member_scalars_row(nd, theta + (int64_t)e * theta_stride, scal + (int64_t)e * kScalStride);
+  int l = 0;
+  while (l + 1 < jb.n_layers && (int)blockIdx.x >= jb.tile0[l + 1]) ++l;
+  const int bx = (int)blockIdx.x - jb.tile0[l];
+  const int n_in = jb.n_in[l], n_pad = jb.n_pad[l];
   const int tiles_j = W / 32;
-  const int ti = blockIdx.x / tiles_j, tj = blockIdx.x % tiles_j;
+  const int ti = bx / tiles_j, tj = bx % tiles_j;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const float* K = theta + (int64_t)e * theta_stride + off_kernel;
-  T* kn = Kn + (int64_t)e * pack_batch;
-  T* kt = Kt + (int64_t)e * pack_batch;
+  const float* K = theta + (int64_t)e * theta_stride + jb.off_kernel[l];
+  T* kn = reinterpret_cast<T*>(jb.Kn[l]) + (int64_t)e * jb.pack_batch[l];
+  T* kt = reinterpret_cast<T*>(jb.Kt[l]) + (int64_t)e * jb.pack_batch[l];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int i = ti * 32 + ty + s * 8, j = tj * 32 + tx;
