@@ -10,7 +10,9 @@
 // READS PER MFMA: ds_read_b64_tr_b8 delivers a whole 8-deep fragment (one instruction where the bf16 kernels issue two
 // ds_read_b64_tr_b16), which is what bounds gemm_tn_ring (profiles/r02w_wgrad_streams.md: reads + barriers do not
 // overlap its MFMAs).  The matrix instruction is the non-scaled v_mfma_f32_32x32x16_fp8_bf8 (bf16 rate, K = 16, f32
-// accumulate): same tile shapes, same accumulator layout, same epilogues as the bf16 kernels of bnf_gemm.h.
+// accumulate): same tile shapes, same accumulator layout, same epilogues as the bf16 kernels of bnf_gemm.h -- and, in
+// gemm_tn_ring8 (the one of the three that was bound by the matrix pipe), the block-scaled K = 64 form at unit scales,
+// v_mfma_scale_f32_32x32x64_f8f6f4: twice the rate, the same products (mfma8x64 below; r05v: 226 -> 175 us at C2).
 //
 // Measured semantics (scripts/probes/fp8_probe.hip, gpurun_out/r05h/fp8_probe.txt):
 //   * ds_read_b64_tr_b8: lane i of a 16-lane group receives, for j = 0 .. 7, byte (i % 8) of the 8-byte datum addressed
@@ -38,6 +40,29 @@ template <bool SWAP>
 __device__ __forceinline__ f32x16 mfma8(const u32x2_t& h, const u32x2_t& dz, const f32x16& c) {
   if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(frag8(dz), frag8(h), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_fp8_bf8(frag8(h), frag8(dz), c, 0, 0, 0);
+}
+// The block-scaled form at unit scales: v_mfma_scale_f32_32x32x64_f8f6f4 contracts 64 k per instruction at TWICE the
+// rate of the non-scaled K = 16 form (64 against 4 x 32 matrix-pipe cycles; MI355X_MICROARCH.md: the only fp8 MFMA above
+// the bf16 rate), formats per operand (0 = e4m3, 1 = e5m2), scales E8M0 127 = 2^0.  A lane's 32 operand bytes are the four
+// transpose-read results of a 64-row stage back to back: lane (m, kg) byte 8 ks + b  <->  k = 16 ks + 8 kg + b for BOTH
+// operands, and the instruction pairs byte (kg, idx) of A with byte (kg, idx) of B, so the sum is the same set of products.
+#ifndef BNF_RING8_X64
+#define BNF_RING8_X64 1
+#endif
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <bool SWAP>
+__device__ __forceinline__ f32x16 mfma8x64(const i32x8& h, const i32x8& dz, const f32x16& c) {
+  if constexpr (SWAP) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(dz, h, c, 1, 0, 0, 127, 0, 127);
+  else return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(h, dz, c, 0, 1, 0, 127, 0, 127);
+}
+// LDS-DMA of one KiB per wave as inline assembly: the x64 loop below reads LDS through the compiler's own
+// ds_read_b64_tr_b8 builtin, and behind a builtin buffer_load ... lds the compiler puts s_waitcnt vmcnt(0) in front of
+// every LDS read that MAY alias its destination -- i.e. it drains the ring each stage.  The stage buffers a read and a
+// DMA in flight touch are different by construction (what the barriers order); assembly keeps the DMA out of that model.
+// lds_addr: wave-uniform LDS byte address (M0 is a reserved register: set here, used by nothing else in these kernels).
+__device__ __forceinline__ void dma_1k_asm(const char* p, uint32_t lane_off, uint32_t lds_addr) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, 0x7fffffff, 0x00020000);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(lane_off), "s"(r), "s"(lds_addr));
 }
 // per-lane constants of a transpose read: lane = 32 kg + 16 half + p, p = 2 j + q
 struct Tr8Lane {
@@ -346,10 +371,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_skinny8(const GemmArgs g, cons
 
 // ===========================================================================
 // gemm_tn_ring8 -- the W x W layers: gemm_tn_ring's 256 x 256 tile, eight waves of 128 x 64, four LDS-DMA stages of the
-// same 32 KiB -- but 64 batch rows each, so FOUR k steps (32 MFMAs per wave) per barrier, and 6 transpose reads per 8
-// MFMAs (bf16: 12).  Fragment sets double-buffered by k step: the set of step ks + 2 is requested right after the MFMAs
-// of step ks were issued (steps 2, 3 request steps 0, 1 of the NEXT stage, which the barrier at the top of this
-// iteration certified), waits are counted (the other set's 6 reads may stay in flight).
+// same 32 KiB -- but 64 batch rows each.  BNF_RING8_X64 (default): ONE K = 64 MFMA per fragment pair and stage (8 per wave
+// and barrier; a fragment = the stage's four transpose reads in an 8-register operand).  -DBNF_RING8_X64=0, the first
+// form: four K = 16 steps (32 MFMAs per wave) per barrier, 6 transpose reads per 8 MFMAs (bf16: 12), fragment sets
+// double-buffered by k step -- the set of step ks + 2 requested right after the MFMAs of step ks were issued (steps 2, 3
+// request steps 0, 1 of the NEXT stage, which the barrier at the top of this iteration certified), counted waits.
 // ===========================================================================
 template <int TAG, bool SWAP>
 __global__ __launch_bounds__(512, 2) void gemm_tn_ring8(const GemmArgs g, const EpiArgs ep) {
@@ -403,15 +429,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring8(const GemmArgs g, const 
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
     return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
   };
+  typedef __attribute__((address_space(3))) char lds_c_t;
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_c_t*)smem);
   auto stage = [&](int buf, int kt) {
-    char* sA = smem + buf * kStage;
-    char* sB = sA + kOp;
     const char* pa = pin(Ab + (int64_t)kt * kRows * g.a_ld);
     const char* pb = pin(Bb + (int64_t)kt * kRows * g.b_ld);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
+#if BNF_RING8_X64
+      const uint32_t la = lds_base + (uint32_t)(buf * kStage + (wave * 2 + q) * 1024);
+      dma_1k_asm(pa, src_a[q], la);
+      dma_1k_asm(pb, src_b[q], la + (uint32_t)kOp);
+#else
+      char* sA = smem + buf * kStage;
       dma_1k<BNF_TN_AUX>(pa, src_a[q], sA + (wave * 2 + q) * 1024);
-      dma_1k<BNF_TN_AUX>(pb, src_b[q], sB + (wave * 2 + q) * 1024);
+      dma_1k<BNF_TN_AUX>(pb, src_b[q], sA + kOp + (wave * 2 + q) * 1024);
+#endif
     }
   };
 
@@ -435,6 +468,81 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring8(const GemmArgs g, const 
 #pragma unroll
     for (int j = 0; j < 2; ++j) off_b[j] = lds0 + (uint32_t)(kOp + row * 256 + (((wc * 2 + j) ^ tl.j) << 5) + in);
   }
+  constexpr int kPerWave = 4;               // LDS-DMA loads of one stage per wave
+  auto vm = [](int n) constexpr { return (n & 15) | ((n >> 4) << 14) | 0x0F70; };   // s_waitcnt vmcnt(n) only
+  constexpr int kWait1 = vm(kPerWave);
+  constexpr int kWaitAll = 0x0F70;
+#if BNF_RING8_X64
+  // One K = 64 MFMA per fragment pair and stage (8 per wave and barrier instead of 32).  A fragment = the stage's four
+  // transpose reads (k steps 0 .. 3) in one 8-register operand -- through the BUILTIN read here, so that the register
+  // allocator places the four results in the operand's registers itself (assembled from inline-asm results they were
+  // copied: 394 v_mov_b64 and 588 bytes of scratch per wave) and counts its own lgkmcnt waits; what pins the order against
+  // the barriers and the LDS-DMA is a compiler-level memory barrier on either side.  The next stage's fragments are
+  // requested under this stage's MFMAs (the barrier at the top of this trip certified that stage).
+  typedef int v2i_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) v2i_t lds_v2i_t;
+  auto read4 = [&](uint32_t rel) {             // rel: byte offset from smem of this lane's k-step-0 datum
+    lds_v2i_t* p = (lds_v2i_t*)(smem + rel);
+    const v2i_t r0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32(p), r1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32(p + 16 * 256 / 8);
+    const v2i_t r2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32(p + 2 * 16 * 256 / 8), r3 = __builtin_amdgcn_ds_read_tr8_b64_v2i32(p + 3 * 16 * 256 / 8);
+    return i32x8{r0[0], r0[1], r1[0], r1[1], r2[0], r2[1], r3[0], r3[1]};
+  };
+  uint32_t rel_a[4], rel_b[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rel_a[i] = off_a[i] - lds0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) rel_b[j] = off_b[j] - lds0;
+#pragma unroll
+  for (int s = 0; s < kRgStages - 1; ++s)
+    if (kt0 + s < kt1) stage(s, kt0 + s);
+  if (kt0 + 1 < kt1) {
+    if (kt0 + 2 < kt1) __builtin_amdgcn_s_waitcnt(vm(2 * kPerWave));
+    else __builtin_amdgcn_s_waitcnt(kWait1);
+  } else {
+    __builtin_amdgcn_s_waitcnt(kWaitAll);
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  i32x8 fa[4], fb[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[i] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) fb[j] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (kt0 < kt1) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = read4(rel_b[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = read4(rel_a[i]);
+  }
+  for (int ktb = kt0; ktb < kt1; ktb += kRgStages) {
+#pragma unroll
+    for (int sb = 0; sb < kRgStages; ++sb) {
+      const int kt = ktb + sb;
+      if (kt >= kt1) break;
+      if (kt + 2 < kt1) __builtin_amdgcn_s_waitcnt(kWait1);
+      else __builtin_amdgcn_s_waitcnt(kWaitAll);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + kRgStages - 1 < kt1) stage((sb + kRgStages - 1) % kRgStages, kt + kRgStages - 1);
+      asm volatile("" ::: "memory");
+      const uint32_t nxt = (uint32_t)(((sb + 1) % kRgStages) * kStage);
+      // ONE fragment set: a[i] of the next stage is requested right after the two MFMAs that read a[i], b[0 .. 1] after
+      // the stage's last MFMA (sched_barrier: the scheduler would hoist the reads and hold two sets -- 96 registers on top
+      // of 128 accumulators spilled)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma8x64<SWAP>(fa[i], fb[j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        fa[i] = read4(rel_a[i] + nxt);     // (past the last stage: stale bytes of the ring, never multiplied)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = read4(rel_b[j] + nxt);
+      asm volatile("" ::: "memory");
+    }
+  }
+#else
   struct Frags {
     u32x2_t a[4], b[2];
   };
@@ -461,10 +569,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring8(const GemmArgs g, const 
   using K2 = std::integral_constant<int, 2>;
   using K3 = std::integral_constant<int, 3>;
 
-  constexpr int kPerWave = 4;               // LDS-DMA loads of one stage per wave
-  auto vm = [](int n) constexpr { return (n & 15) | ((n >> 4) << 14) | 0x0F70; };   // s_waitcnt vmcnt(n) only
-  constexpr int kWait1 = vm(kPerWave);
-  constexpr int kWaitAll = 0x0F70;
 #pragma unroll
   for (int s = 0; s < kRgStages - 1; ++s)
     if (kt0 + s < kt1) stage(s, kt0 + s);
@@ -505,6 +609,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring8(const GemmArgs g, const 
       if (more) read_k(f1, sn, K1{});
     }
   }
+
+#endif
 
   const float qs = ep.scale * (ep.qscale ? ep.qscale[e] : 1.f);
   float* out = ep.out_f32 ? ep.out_f32 + (int64_t)e * ep.f32_batch

@@ -141,7 +141,7 @@ def test_fp8_vi_step_against_the_bf16_panel_step(width, depth, S):
     eng.init_params(0.0)
     res[dt] = eng.debug_loss_and_grad(0, 0)
     eng.close()
-  np.testing.assert_allclose(res['fp8'][0], res['bf16'][0], rtol=1e-6)
+  np.testing.assert_allclose(res['fp8'][0], res['bf16'][0], rtol=1e-5)   # (f32 atomics across panels: the order varies)
   kernels = [f'Dense_{l}/kernel' for l in range(depth)] + ['Dense_0/bias']
   for k in (0, 1):
     e8 = util.per_leaf_rel_err(model, res['fp8'][1][k], res['bf16'][1][k])
