@@ -84,7 +84,7 @@ def test_fp8_copies_and_step_gradients(width, depth, n_rows):
     assert np.max(np.abs(a - b)[big] / np.abs(b)[big]) <= 2.0 ** -3 + 1e-6, l                      # e5m2: 2 mantissa bits
     assert util.rel_err(a, b) < 0.13
   loss_o, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
-  np.testing.assert_allclose(res['fp8'][0], res['bf16'][0], rtol=1e-6)
+  np.testing.assert_allclose(res['fp8'][0], res['bf16'][0], rtol=1e-5)   # (same arithmetic; f32 atomics across panels in varying order)
   e8 = util.per_leaf_rel_err(model, res['fp8'][1], res['bf16'][1])
   kernels = [f'Dense_{l}/kernel' for l in range(depth)] + ['Dense_0/bias']      # (d bias0 is a row of the layer-0 product)
   bad = {k: v for k, v in e8.items() if k not in kernels and v > 1e-4}
@@ -117,7 +117,7 @@ def test_fp8_count_models_keep_the_backward_signals_in_range(obs, width, depth, 
     big = np.abs(b) > 1e-3 * np.abs(b).max()
     assert np.max(np.abs(a - b)[big] / np.abs(b)[big]) <= 2.0 ** -3 + 1e-6, l
   _, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=n_rows)
-  np.testing.assert_allclose(res['fp8'][0], res['bf16'][0], rtol=1e-6)
+  np.testing.assert_allclose(res['fp8'][0], res['bf16'][0], rtol=1e-5)   # (same arithmetic; f32 atomics across panels in varying order)
   kernels = [f'Dense_{l}/kernel' for l in range(depth)] + ['Dense_0/bias']
   e8 = util.per_leaf_rel_err(model, res['fp8'][1], res['bf16'][1])
   bad = {k: v for k, v in e8.items() if k not in kernels and v > 1e-4}
