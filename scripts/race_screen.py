@@ -15,7 +15,7 @@ from bayesnf_amd.spec import NetSpec           # noqa: E402
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 X, y, scales = synthetic_grid()
 worst = 0.0
-for dtype, members in (('bf16', 16), ('fp32', 4)):
+for dtype, members in (('bf16', 16), ('fp8', 16), ('fp32', 4)):
   net = NetSpec(input_scales=scales, **MODEL_KW)
   eng = Engine(net, X=X, y=y, members=members, seed=1, compute_dtype=dtype)
   eng.init_params(float(np.log(np.nanstd(y) / 2)))
@@ -30,4 +30,4 @@ for dtype, members in (('bf16', 16), ('fp32', 4)):
       print(f'MISMATCH {dtype} rep {r}: loss {dl:.3e} grad {dg:.3e}')
       sys.exit(1)
   eng.close()
-print(f'race screen ok: {reps} repetitions x 2 dtypes, worst relative deviation {worst:.2e}')
+print(f'race screen ok: {reps} repetitions x 3 dtypes, worst relative deviation {worst:.2e}')
