@@ -180,12 +180,14 @@ def test_forward_only_bf16_matches_fp32_at_width_512():
   assert np.abs(outs['bf16'][0] - outs['fp32'][0]).max() < 2e-2 * scale
 
 
-def test_repeated_step_is_reproducible_at_c2():
-  """Race screen for the ring-buffered K loops (counted vmcnt + raw barriers, LDS-DMA): the same
-  forward + backward at the benchmark size must reproduce itself up to the order of f32 atomics."""
+@pytest.mark.parametrize('dtype', ['bf16', 'fp8'])
+def test_repeated_step_is_reproducible_at_c2(dtype):
+  """Race screen for the ring-buffered K loops (counted vmcnt + raw barriers, LDS-DMA -- in the fp8 W x W stream as
+  inline assembly beside compiler-scheduled transpose reads): the same forward + backward at the benchmark size must
+  reproduce itself up to the order of f32 atomics."""
   X, y, scales = _grid()
   net = _net(scales)
-  eng = _engine(net, X, y, members=8, seed=1, compute_dtype='bf16')
+  eng = _engine(net, X, y, members=8, seed=1, compute_dtype=dtype)
   eng.init_params(float(np.log(np.nanstd(y) / 2)))
   loss0, g0 = eng.debug_loss_and_grad()
   scale = np.abs(g0).max(axis=1, keepdims=True)
@@ -194,3 +196,29 @@ def test_repeated_step_is_reproducible_at_c2():
     assert np.abs(loss - loss0).max() <= 1e-5 * np.abs(loss0).max()
     assert (np.abs(g - g0) / scale).max() < 1e-4
   eng.close()
+
+
+@pytest.mark.parametrize('layout', ['C2', 'C5'])
+def test_fp8_tracks_bf16_at_full_size(layout):
+  """compute_dtype 'fp8' at BASELINE.json's C2 and C5 (per-GPU share of the rows, a few members) shapes: the fp8 operand
+  copies only feed the Dense-kernel gradients, so 12 Adam steps from the same initial parameters stay on the bf16
+  trajectory -- every loss within 2e-3 of the bf16 run's, the last one lower than the first.  (C5: W = 256, 128 padded
+  features, 71,000 rows = the split-K ring kernel + the generic fp8 kernel; C2: the ring kernel on the K = 64 MFMA +
+  the skinny stream.)"""
+  if layout == 'C2':
+    X, y, scales = _grid()
+    net = _net(scales)
+  else:
+    rng = np.random.default_rng(5)
+    n = 71000
+    t = rng.integers(0, 8760, n).astype(np.float64)
+    lat, lon = rng.standard_normal(n), rng.standard_normal(n)
+    X = np.stack([t, lat, lon], axis=1)
+    y = (np.sin(2 * np.pi * t / 24.0) + 0.5 * np.sin(2 * np.pi * t / 168.0) + lat * lon + 0.3 * rng.standard_normal(n))
+    net = NetSpec(width=256, depth=2, input_scales=[8759.0, 1.0, 1.0], fourier_degrees=[5, 5, 5], interactions=[],
+                  seasonality_periods=[24.0, 168.0, 8766.0], num_seasonal_harmonics=[6, 8, 9], observation_model='NORMAL')
+  kw = dict(members=4, seed=3, learning_rate=0.005)
+  th16, l16 = _fit(net, X, y, 12, compute_dtype='bf16', **kw)
+  th8, l8 = _fit(net, X, y, 12, compute_dtype='fp8', **kw)
+  assert np.all(np.isfinite(l8)) and np.all(l8[:, -1] < l8[:, 0])
+  assert np.abs(l8 / l16 - 1).max() < 2e-3, np.abs(l8 / l16 - 1).max()
