@@ -1097,6 +1097,11 @@ static RowSrc make_rowsrc(const bnf_handle* h, int64_t epoch, int64_t step) {
   } else if (h->cfg.mode == BNF_MODE_VI) {
     rs.mode = 2;
     rs.epoch = (uint64_t)step;  // VI: one shared random batch per optimisation step
+    if (h->row_keys && h->perm && h->perm_epoch == step) {   // the reference's own batch of this step (ensure_row_perm drew it):
+      rs.mode = 3;                                           // permutation(seed_step, N)[:B], the same rows for every member
+      rs.table_ld = 0;
+      rs.table = h->perm;
+    }
   } else {
     rs.mode = 1;
     rs.epoch = (uint64_t)epoch;
@@ -1121,11 +1126,14 @@ static RowSrc make_rowsrc(const bnf_handle* h, int64_t epoch, int64_t step) {
 static size_t row_perm_bytes(int64_t members, int64_t n_rows) {   // without the sort's own scratch (a few MB)
   return 4 * (size_t)members * (size_t)n_rows * 4 + (size_t)(members + 1) * sizeof(unsigned);
 }
+// (VI handles: `epoch` is the optimisation STEP and there is ONE permutation per step, shared by every member --
+// ensemble_vi's `jax.random.permutation(seed, arange(N))[:batch_size]`, inference.py:704-709)
+static int perm_members(const bnf_handle* h) { return h->cfg.mode == BNF_MODE_VI ? 1 : h->cfg.members; }
 static int ensure_row_perm(bnf_handle* h, int64_t epoch) {
   if (!h->row_keys || h->B >= h->N || epoch < h->row_keys_e0 || epoch >= h->row_keys_e0 + h->row_keys_epochs) return BNF_OK;
   if (h->row_tab && epoch >= h->row_tab_e0 && epoch < h->row_tab_e0 + h->row_tab_epochs) return BNF_OK;   // tables win
   if (h->perm_epoch == epoch) return BNF_OK;
-  const int E = h->cfg.members, R = h->row_key_rounds;
+  const int E = perm_members(h), R = h->row_key_rounds;
   const int64_t N = h->N, total = (int64_t)E * N;
   // (members x rows < 2^31 was checked by bnf_row_keys)
   const bool segmented = N <= (1 << 17);     // long segments: one device-wide sort per member instead
@@ -1286,6 +1294,7 @@ static JaxNoise jax_noise_for_step(const bnf_handle* h) {
 template <typename T>
 static int step_vi(bnf_handle* h, int64_t step, float* loss, int64_t loss_stride, bool apply,
                    float* gmu_out, float* grho_out) {
+  if (const int prc = ensure_row_perm(h, step)) return prc;
   const RowSrc rs = make_rowsrc(h, 0, step);
   const int E = h->cfg.members, S = h->S;
   float* mu = h->params;
@@ -1983,7 +1992,7 @@ int bnf_debug_loss_and_grad(bnf_handle* h, int64_t epoch, int64_t step, float* g
 int bnf_debug_row_index(bnf_handle* h, int64_t epoch, int64_t step, int32_t* out) {
   if (!h || !h->bound || !out) return fail(BNF_ERR_STATE, "not bound / null");
   HIPCHK(hipSetDevice(h->cfg.device));
-  if (const int prc = ensure_row_perm(h, epoch)) return prc;
+  if (const int prc = ensure_row_perm(h, h->cfg.mode == BNF_MODE_VI ? step : epoch)) return prc;
   RowSrc rs = make_rowsrc(h, epoch, step);
   rs.S = 1;  // indexed by real member
   dim3 grid(cdiv(h->B, 256), (unsigned)h->cfg.members);
@@ -2029,7 +2038,6 @@ int bnf_row_tables(bnf_handle* h, const int32_t* tables, int64_t epoch0, int64_t
 
 int bnf_row_keys(bnf_handle* h, const uint32_t* keys, int64_t epoch0, int64_t n_epochs, int32_t rounds) {
   if (!h || !h->bound) return fail(BNF_ERR_STATE, "not bound");
-  if (h->cfg.mode != BNF_MODE_MAP) return fail(BNF_ERR_STATE, "row keys serve MAP / MLE epochs");
   h->perm_epoch = -1;
   if (!keys) { h->row_keys = nullptr; h->row_keys_epochs = 0; return BNF_OK; }
   if (n_epochs < 1 || epoch0 < 0 || rounds < 1 || rounds > 8) return fail(BNF_ERR_INVALID, "epoch0 / n_epochs / rounds");
@@ -2038,8 +2046,8 @@ int bnf_row_keys(bnf_handle* h, const uint32_t* keys, int64_t epoch0, int64_t n_
   if (rounds != want) return fail(BNF_ERR_INVALID, "rounds = %d, jax.random.permutation of %lld rows takes %d", rounds, (long long)h->N, want);
   // the sort addresses (member, row) pairs with 32-bit offsets; refuse here, where the caller can still choose the
   // index-free shuffle instead (bayesnf_amd/inference.py does, with a warning), not in the middle of bnf_train
-  if ((int64_t)h->cfg.members * h->N > 0x7fffffffLL)
-    return fail(BNF_ERR_INVALID, "bnf_row_keys: members x rows = %lld exceeds 2^31 - 1", (long long)((int64_t)h->cfg.members * h->N));
+  if ((int64_t)perm_members(h) * h->N > 0x7fffffffLL)
+    return fail(BNF_ERR_INVALID, "bnf_row_keys: members x rows = %lld exceeds 2^31 - 1", (long long)((int64_t)perm_members(h) * h->N));
   h->row_keys = keys; h->row_keys_e0 = epoch0; h->row_keys_epochs = n_epochs; h->row_key_rounds = rounds;
   return BNF_OK;
 }

@@ -21,25 +21,26 @@ _warned_default_dtype = False
 
 
 def default_dtype(compute_dtype=None) -> str:
-  """'fp32' unless the caller or BNF_DTYPE says otherwise: the float32 engine is the parity path (f32 storage, accumulation
-  and epilogues; contractions on split-bf16 MFMAs with 16 operand bits -- include/bnf.h BNF_DTYPE_F32S; it reproduces the
-  reference's golden predictions to < 1e-4 and holds every fp32 parity bar; 'fp32_exact' runs the exact f32 MFMA chain
-  instead, 1.7x slower), 'bf16' the throughput path
-  (bf16 contraction operands, f32 accumulation -- the numerics class of the reference's TPU runs;
-  ~5x the member-steps/s at the benchmark size), 'fp8' = 'bf16' with FP8 OPERAND STORAGE for the weight-gradient
-  contractions (include/bnf.h BNF_DTYPE_FP8; training handles on the row-panel pipeline only -- a forward-only handle
-  of an 'fp8' estimator runs the bf16 forward).  Said once per process when the default applies."""
+  """Canonical name of the engine arithmetic.  'fp32' unless the caller or BNF_DTYPE says otherwise: the exact f32 engine
+  (f32 storage, accumulation and epilogues, contractions on `v_mfma_f32_32x32x2_f32` -- include/bnf.h BNF_DTYPE_F32) is the
+  parity path: SURVEY 8d's fp32 gates are stated for it.  'fp32_split' (BNF_DTYPE_F32S) keeps f32 storage and epilogues and
+  runs the contractions as three bf16 MFMAs on operands split in registers (16 operand bits, ~5e-6 per contraction; it
+  reproduces the reference's golden predictions to < 1e-4, 1.8x the exact chain); 'bf16' is the throughput path (bf16
+  contraction operands, f32 accumulation -- the numerics class of the reference's TPU runs; ~6x the exact chain at the
+  benchmark size); 'fp8' = 'bf16' with FP8 OPERAND STORAGE for the weight-gradient contractions (include/bnf.h
+  BNF_DTYPE_FP8; training handles on the row-panel pipeline only -- a forward-only handle of an 'fp8' estimator runs the
+  bf16 forward).  Said once per process when the default applies."""
   global _warned_default_dtype
   if compute_dtype is None and 'BNF_DTYPE' not in os.environ and not _warned_default_dtype:
     _warned_default_dtype = True
     import warnings
-    warnings.warn("bayesnf_amd: compute_dtype defaults to 'fp32' (parity arithmetic). Pass "
-                  "compute_dtype='bf16' (or set BNF_DTYPE=bf16) for the ~4x faster bf16-MFMA engine.",
-                  stacklevel=3)
+    warnings.warn("bayesnf_amd: compute_dtype defaults to 'fp32' (exact f32 MFMA: parity arithmetic). Pass "
+                  "compute_dtype='fp32_split' (f32 storage, split-bf16 contractions: 1.8x) or 'bf16' (~6x) -- or set "
+                  "BNF_DTYPE -- for the faster engines.", stacklevel=3)
   dt = compute_dtype or os.environ.get('BNF_DTYPE', 'fp32')
   if dt not in _native.DTYPE:
     raise ValueError(f'compute_dtype must be one of {sorted(_native.DTYPE)}')
-  return {0: 'fp32_exact', 1: 'bf16', 2: 'fp8', 3: 'fp32'}[_native.DTYPE[dt]]
+  return _native.DTYPE_NAME[_native.DTYPE[dt]]
 
 
 def _ptr(t):
@@ -201,8 +202,9 @@ class Engine:
       _native.check(self.lib.bnf_row_keys(self.handle, None, 0, 0, 0), 'bnf_row_keys')
       return
     k = np.ascontiguousarray(subkeys, dtype=np.uint32)
-    if k.ndim != 4 or k.shape[1] != self.members or k.shape[3] != 2:
-      raise ValueError(f'row keys must be uint32 (n_epochs, {self.members}, rounds, 2); got {k.shape}')
+    per = 1 if self.mode == 'vi' else self.members     # VI: one batch per step, shared by every member (jaxseed.vi_batch_subkeys)
+    if k.ndim != 4 or k.shape[1] != per or k.shape[3] != 2:
+      raise ValueError(f'row keys must be uint32 (n_epochs, {per}, rounds, 2); got {k.shape}')
     t = torch.from_numpy(k.view(np.int32)).to(self.device)
     self._row_keys = t
     _native.check(self.lib.bnf_row_keys(self.handle, _ptr(t), int(epoch0), int(k.shape[0]), int(k.shape[2])), 'bnf_row_keys')

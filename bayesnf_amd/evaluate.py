@@ -134,7 +134,7 @@ def main(argv=None):
   ap.add_argument('--stop_id', type=int, default=None)
   ap.add_argument('--num_particles', type=int, default=None)
   ap.add_argument('--seed', type=int, default=0)
-  ap.add_argument('--compute_dtype', default=None, choices=[None, 'fp32', 'bf16'])
+  ap.add_argument('--compute_dtype', default=None, choices=[None, 'fp32', 'fp32_split', 'bf16', 'fp8'])
   args = ap.parse_args(argv)
   from . import distributed
   distributed.maybe_init_from_env()

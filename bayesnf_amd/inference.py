@@ -192,14 +192,17 @@ def fit_vi(features, target, seed, observation_model, model_args, ensemble_size,
     else:
       # the reference's own initial surrogate means for this seed (key chain on the host, values on the device)
       eng.init_params_keys(mu_keys[sh.index], 0.0)
-      if full_batch:
-        # full batch: the optimisation noise and the posterior draws come from the reference's stream too
-        # (keys on the host once per fit, normals on the device), so a full-batch fit uses the reference's numbers
-        # (pinned by the reference's VI golden: 2 optimisation steps; longer fits extrapolate the same key recurrence);
-        # minibatch fits also need its per-step row permutation and stay on the engine's generator
-        eng.set_vi_noise_keys(jaxseed.vi_noise_keys(net, seed, world, sh.index, num_epochs, sample_size_divergence),
-                              jaxseed.vi_draw_keys(net, seed, world, sh.index, sample_size_posterior),
-                              jaxseed.leaf_offsets(net))
+      # the optimisation noise and the posterior draws come from the reference's stream too (keys on the host once per
+      # fit, normals on the device), so the fit runs on the reference's numbers (pinned by the reference's VI golden:
+      # 2 full-batch optimisation steps; longer fits extrapolate the same key recurrence) ...
+      eng.set_vi_noise_keys(jaxseed.vi_noise_keys(net, seed, world, sh.index, num_epochs, sample_size_divergence),
+                            jaxseed.vi_draw_keys(net, seed, world, sh.index, sample_size_posterior),
+                            jaxseed.leaf_offsets(net))
+      if not full_batch:
+        # ... and so does the ONE minibatch every step shares between the device's members: permutation(seed_step, N)[:B]
+        # (inference.py:704-709), sort-round keys from the host, bits and sorts on the device.  Unpinned by any golden
+        # (jaxseed.vi_batch_subkeys states the one assumption it rests on).
+        eng.set_row_keys(jaxseed.vi_batch_subkeys(seed, world, sh.index, num_epochs, n_rows))
     loss_dev = eng.train(0, num_epochs)
     return eng, loss_dev, eng.vi_posterior_draws(sample_size_posterior)   # draws (n, E_local, P)
 

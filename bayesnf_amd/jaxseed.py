@@ -211,6 +211,15 @@ def vi_noise_keys(net, seed, world: int, rank: int, num_steps: int, sample_size:
      the step's `sample_size` joint samples: keys = split(fold_in(s, 'iid_sample_stateless'), sample_size),
      each -> fold_in 'JointDistribution', one split per leaf
   -> uint32 (num_steps, sample_size, n_leaves, 2).  (Two steps are what the golden validates.)"""
+  states = vi_step_seeds(seed, world, rank, num_steps)
+  sample_keys = _split_many(_fold_in_many(states, _IID_SALT), sample_size)     # (steps, S, 2)
+  return _jd_leaf_keys(sample_keys, len(net.leaves))
+
+
+def vi_step_seeds(seed, world: int, rank: int, num_steps: int) -> np.ndarray:
+  """(num_steps, 2): the seed of every optimisation step of device `rank` -- what tfp.math.minimize_stateless hands the
+  variational loss: s_0 = fold_in(split(fit_seed, devices)[rank], 'minimize'), s_k = split(s_{k-1})[0].  Pinned (two
+  steps) by the reference's VI golden through the reparameterisation noise derived from it (`vi_noise_keys`)."""
   opt_seed = split(as_key(seed), 2)[1]
   fit_seed = split(opt_seed, 2)[0]
   s = fold_in(split(fit_seed, world)[rank], _MINIMIZE_SALT)
@@ -218,8 +227,25 @@ def vi_noise_keys(net, seed, world: int, rank: int, num_steps: int, sample_size:
   for k in range(num_steps):
     s = split(s, 2)[0]
     states[k] = s
-  sample_keys = _split_many(_fold_in_many(states, _IID_SALT), sample_size)     # (steps, S, 2)
-  return _jd_leaf_keys(sample_keys, len(net.leaves))
+  return states
+
+
+def vi_batch_subkeys(seed, world: int, rank: int, num_steps: int, n_rows: int) -> np.ndarray:
+  """For `bnf_row_keys` on a VI handle: uint32 (num_steps, 1, rounds, 2), the sub keys of the sort rounds of the ONE
+  minibatch permutation ensemble_vi draws per step and shares between the members of a device
+  (/root/reference/src/bayesnf/inference.py:704-709: `jax.random.permutation(seed, arange(N))[:batch_size]` with the `seed`
+  keyword tfp.vi.fit_surrogate_posterior_stateless passes `target_log_prob_fn`).
+  ASSUMPTION, unpinned by any golden (the reference's VI golden is full batch): that keyword is the step's own seed
+  s_k of `vi_step_seeds` -- the same value the surrogate's samples are drawn from (golden-pinned: the sampler receives
+  s_k unsplit) -- tfp 0.24's `monte_carlo_variational_loss` source is not available in this environment.  The sort
+  rounds themselves are jax's `_shuffle` as in `map_shuffle_subkeys`."""
+  states = vi_step_seeds(seed, world, rank, num_steps)
+  return map_shuffle_subkeys(states[None], n_rows)      # members axis = 1
+
+
+def vi_batches(seed, world: int, rank: int, num_steps: int, n_rows: int, batch: int) -> np.ndarray:
+  """int32 (num_steps, batch): the row ids of every step's shared batch (host restatement of `vi_batch_subkeys`)."""
+  return permutations(vi_step_seeds(seed, world, rank, num_steps), n_rows)[:, :batch]
 
 
 def vi_draw_keys(net, seed, world: int, rank: int, num_draws: int):

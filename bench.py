@@ -43,9 +43,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 2500.0 / 3, 'fp32_exact': 157.3, 'fp8': 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md ('fp8': the dominant
-# kernel's contractions are bf16 and the weight-gradient kernels use the NON-scaled fp8 MFMA = the bf16 rate; 'fp32': the
-# split-bf16 contraction issues three bf16 MFMAs per product; 'fp32_exact': the f32 MFMA)
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32_split': 2500.0 / 3, 'fp32': 157.3, 'fp8': 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md ('fp8': the dominant
+# kernel's contractions are bf16 and the weight-gradient kernels use the NON-scaled fp8 MFMA = the bf16 rate; 'fp32_split':
+# the split-bf16 contraction issues three bf16 MFMAs per product; 'fp32': the exact f32 MFMA)
 
 # engine kernel name (bnf_profile_read) -> device symbol (rocprofv3 Kernel_Name), {T} = element type
 KERNEL_SYMBOL = {   # gemm_nt<T, epilogue, tag, wave rows, wave cols>
@@ -585,7 +585,7 @@ def main(argv=None):
   ap.add_argument('--gather', default=None, choices=['cabi', 'torch'],
                   help="posterior gather through bnf_allgather of the engine library (default on GPUs; env "
                        "BNF_GATHER) or torch.distributed's all_gather_into_tensor")
-  ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp32_exact', 'fp8'],
+  ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp32_split', 'fp8'],
                   help="bf16 (the headline), fp32 (the parity arithmetic), fp8 = bf16 contractions with fp8 operand storage for "
                        'the weight-gradient streams (BASELINE configs[4])')
   ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BNF_ABI_VERSION 5
+#define BNF_ABI_VERSION 6
 
 /* limits of the static network description */
 #define BNF_MAX_INPUTS   8    /* D  : time + spatial covariates              */
@@ -58,9 +58,10 @@ enum { BNF_DTYPE_F32 = 0, BNF_DTYPE_BF16 = 1,   /* arithmetic of the dense contr
        BNF_DTYPE_FP8 = 2,
        /* f32 storage, accumulation and epilogues like BNF_DTYPE_F32, but the contractions run on SPLIT-bf16 MFMAs: every f32
         * operand is split in registers into two bf16 pieces (16 operand bits) and hi*hi + hi*lo + lo*hi are summed by three
-        * bf16 MFMAs -- products good to ~1e-5, every fp32 parity bar and the three reference goldens (< 1e-4) hold, 1.7x the
-        * speed of the exact f32 MFMA chain.  What the Python estimators run by default (compute_dtype 'fp32'); BNF_DTYPE_F32
-        * ('fp32_exact') keeps the exact v_mfma_f32_32x32x2_f32 arithmetic. */
+        * bf16 MFMAs -- products good to ~5e-6 of the largest output (exact chain: 1e-7), the three reference goldens (< 1e-4)
+        * hold, 1.8x the speed of the exact f32 MFMA chain.  OPT-IN (compute_dtype 'fp32_split'): the Python estimators'
+        * default and an explicit 'fp32' are BNF_DTYPE_F32, the exact v_mfma_f32_32x32x2_f32 arithmetic (ABI 6; ABI 5's
+        * Python layer had mapped 'fp32' here). */
        BNF_DTYPE_F32S = 3 };
 enum { BNF_OBS_NORMAL = 0, BNF_OBS_NB = 1, BNF_OBS_ZINB = 2 }; /* models.py:30-33 */
 enum { BNF_MODE_MAP = 0, BNF_MODE_VI = 1 };       /* MLE = MAP with prior_weight 0 (spatiotemporal.py:551) */
@@ -214,7 +215,12 @@ int bnf_row_tables(bnf_handle* h, const int32_t* tables, int64_t epoch0, int64_t
  * Work buffers (4 x members x N x 4 bytes + sort scratch) are allocated by the engine at the first such epoch
  * (the only allocation the engine makes itself: bnf_owned_bytes reports it) and freed by bnf_destroy.
  * BNF_ERR_INVALID when members x N exceeds 2^31 - 1 (32-bit sort offsets): use bnf_row_tables or the engine's
- * index-free shuffle for such fits.  A table from bnf_row_tables covering the same epoch wins.  NULL switches it off. */
+ * index-free shuffle for such fits.  A table from bnf_row_tables covering the same epoch wins.  NULL switches it off.
+ * VI handles (ABI 6): ensemble_vi draws ONE batch per optimisation step, shared by every member --
+ * `jax.random.permutation(seed, arange(N))[:batch_size]` with the seed tfp hands `target_log_prob_fn` at that step
+ * (inference.py:704-709) -- so `keys` is uint32 (n_steps, 1, rounds, 2) for the steps [epoch0, epoch0 + n_steps)
+ * (bayesnf_amd/jaxseed.py vi_batch_subkeys), the permutation is drawn when the step is enqueued and its first `batch`
+ * entries are the rows of every member; work buffers 4 x N x 4 bytes + sort scratch. */
 int bnf_row_keys(bnf_handle* h, const uint32_t* keys, int64_t epoch0, int64_t n_epochs, int32_t rounds);
 
 /* The reference's OWN random stream for the VI noise (optional; without it the noise comes from the

@@ -274,6 +274,22 @@ def reference_vi_step_noise(model, seed, num_steps: int, sample_size: int, n_mem
   return out
 
 
+def reference_vi_batches(seed, num_steps: int, n_rows: int, batch_size: int):
+  """(num_steps, batch_size) row ids of ensemble_vi's per-step minibatch on a single device (inference.py:704-709:
+  `jax.random.permutation(seed, arange(N))[:batch_size]`, one batch per step shared by the members).  `seed` is the
+  keyword tfp.vi.fit_surrogate_posterior_stateless passes `target_log_prob_fn`: taken to be the step's own seed -- the
+  value the golden-pinned reparameterisation draws of that step come from (`reference_vi_step_noise`).  UNPINNED by any
+  golden (the VI golden is full batch) and an assumption about tfp 0.24's `monte_carlo_variational_loss`, whose source
+  is not available here; the permutation itself rests on the pinned `split` / `random_bits` restatements."""
+  _, fit_seed, _ = reference_vi_seeds(seed)
+  s = fold_in(fit_seed, tfp_salt('minimize'))
+  out = np.empty((num_steps, batch_size), dtype=np.int64)
+  for k in range(num_steps):
+    s = split(s, 2)[0]
+    out[k] = permutation(s, n_rows)[:batch_size]
+  return out
+
+
 def reference_vi_posterior_noise(model, seed, num_samples: int, n_members: int):
   """(num_samples, n_members, P) standard normals of the posterior draws (inference.py:741-753)."""
   _, _, sample_seed = reference_vi_seeds(seed)

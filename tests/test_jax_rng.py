@@ -212,3 +212,28 @@ def test_leaf_keys_of_the_device_side_initialiser_reproduce_the_host_chain():
       for i, lf in enumerate(net.leaves):
         if len(lf.shape) == 2:
           np.testing.assert_array_equal(J.truncated_normal_std(vk[d, e, i], lf.size), mu[d, e, lf.offset:lf.offset + lf.size])
+
+
+def test_vi_minibatch_stream_of_the_host_glue_equals_the_oracles():
+  """ensemble_vi's per-step shared minibatch, `permutation(seed_step, N)[:B]` (inference.py:704-709): the oracle's
+  restatement (oracle/jax_rng.py reference_vi_batches) and the product's host glue (jaxseed.vi_batches, and the sort-round
+  sub keys jaxseed.vi_batch_subkeys hands the device) agree bit for bit.  UNPINNED by any golden: the reference's VI
+  golden is full batch, and which seed tfp passes `target_log_prob_fn` is an assumption both restate (the step's own
+  seed, from which the golden-pinned reparameterisation draws of that step come)."""
+  from bayesnf_amd import jaxseed as J
+  for n, b, steps in ((333, 100, 4), (2000, 1999, 2), (50, 1, 3)):
+    ref = R.reference_vi_batches(R.prng_key(11), steps, n, b)
+    got = J.vi_batches(11, 1, 0, steps, n, b)
+    np.testing.assert_array_equal(got, ref)
+    assert got.shape == (steps, b) and all(len(set(r.tolist())) == b for r in got) and not np.array_equal(got[0], got[1])
+    sub = J.vi_batch_subkeys(11, 1, 0, steps, n)
+    assert sub.shape == (steps, 1, J.shuffle_rounds(n), 2) and sub.dtype == np.uint32
+    # the sub keys are those of the sort rounds: replay round by round on the host
+    for k in range(steps):
+      x = np.arange(n)
+      for r in range(sub.shape[2]):
+        x = x[np.argsort(R.random_bits(sub[k, 0, r], (n,)), kind='stable')]
+      np.testing.assert_array_equal(x[:b], ref[k])
+  # the step seeds are the ones the (golden-pinned) noise keys are derived from, and differ per device
+  s0, s1 = J.vi_step_seeds(11, 2, 0, 3), J.vi_step_seeds(11, 2, 1, 3)
+  assert s0.shape == (3, 2) and not np.array_equal(s0, s1)

@@ -25,6 +25,16 @@ def make_problem(n_rows=300, width=64, depth=2, seed=0, interactions=((0, 1), (1
   return NetSpec(**kw), O.Model(**kw), X, y
 
 
+# SURVEY 8d "Parity gates", fp32 class, verbatim -- held against BOTH f32-class engines ('fp32' = exact f32 MFMA, the
+# default; 'fp32_split' = split-bf16 contractions): forward rel-err <= 1e-5, loss rel-err <= 1e-5, gradients rel-err <= 1e-4
+# (vs the float64 oracle; per leaf, max |g - g_o| over the leaf's max |g_o|), parameters after 100 full-batch Adam steps
+# rel-err <= 1e-3.  Measured (scripts/fp32_contract_diag.py, profiles/r06_fp32_contract_diag.txt): 'fp32' out <= 3.5e-7,
+# loss <= 2.4e-7, worst leaf 8.9e-5 (log_scale_adjustment at W = 256: the Fourier argument 2 pi 2^k u amplifies the f32
+# rounding of u), parameters <= 4.3e-6; 'fp32_split' 3.1e-6 / 2.4e-7 / 7.7e-5 / 2.7e-5.
+FP32_GATE = dict(out=1e-5, loss=1e-5, grad=1e-4, params100=1e-3)
+FP32_DTYPES = ('fp32', 'fp32_split')
+
+
 def random_theta(model, E, seed=1, scale=0.5):
   """Generic (not init-like) parameters so every gradient path is exercised."""
   rng = np.random.default_rng(seed)
