@@ -728,7 +728,8 @@ static void wgrad_join(bnf_handle* h) {
 static bool panel_dk0_fused(const bnf_handle* h) {
 #if BNF_PANEL_DK0
   static const bool on = getenv("BNF_PANEL_DK0") && atoi(getenv("BNF_PANEL_DK0")) != 0;
-  return on && h->panel && h->h0l && h->W == 512 && h->Fp == 64 && h->cfg.mode == BNF_MODE_MAP && !h->pad;
+  return on && h->panel && h->h0l && h->W == 512 && h->Fp == 64 && h->cfg.mode == BNF_MODE_MAP && !h->pad &&
+         h->cfg.dtype != BNF_DTYPE_FP8;     // (the fused form contracts the bf16 panels: it knows nothing of the fp8 copies)
 #else
   (void)h;
   return false;
@@ -1548,7 +1549,8 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   }
   h->h0l = h->panel && (((h->W == 512 || h->W == 1024) && h->Fp == 64) || (h->W == 256 && (h->Fp == 64 || h->Fp == 128))) && !getenv("BNF_PANEL_NO_H0L");
   h->fold0 = h->h0l && h->F + 2 <= h->Fp && !(getenv("BNF_PANEL_FOLD0") && atoi(getenv("BNF_PANEL_FOLD0")) == 0);
-  h->fin = BNF_PANEL_FIN != 0 && h->h0l && getenv("BNF_PANEL_FIN") && atoi(getenv("BNF_PANEL_FIN")) != 0;   // (experiment builds only)
+  // (experiment builds only; not with fp8 operand storage: the fp8 feature copy H0q is written by k_featurize alone)
+  h->fin = BNF_PANEL_FIN != 0 && h->h0l && cfg->dtype != BNF_DTYPE_FP8 && getenv("BNF_PANEL_FIN") && atoi(getenv("BNF_PANEL_FIN")) != 0;
   if (h->fin) {
     // what every padded feature column holds (k_featurize's group loop, one entry per column) -- models.py:218-252
     std::vector<int32_t>& m = h->fcol_h;
@@ -2304,12 +2306,16 @@ int rccl_load() {
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy ||
       !g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
     g_rccl = RcclApi{};
+    dlclose(lib);     // (a retry opens it again: do not pile up references)
     return fail(BNF_ERR_STATE, "librccl.so lacks an expected nccl* symbol");
   }
   if (int (*get_version)(int*) = (int (*)(int*))dlsym(lib, "ncclGetVersion")) {   // NCCL API >= 2.7: ncclChar all-gather,
     int v = 0;                                                                    // group semantics as used here
+    // NCCL_VERSION_CODE is major * 1000 + minor * 100 + patch up to 2.8 and major * 10000 + minor * 100 + patch from 2.9 on
+    // (2.7.8 = 2708, 2.9.6 = 20906): every code below 2700 is older than 2.7 under either encoding
     if (get_version(&v) == 0 && v > 0 && v < 2700) {
       g_rccl = RcclApi{};
+      dlclose(lib);
       return fail(BNF_ERR_STATE, "librccl.so reports NCCL API version %d (< 2.7)", v);
     }
   }

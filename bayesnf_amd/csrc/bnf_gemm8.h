@@ -62,7 +62,9 @@ __device__ __forceinline__ f32x16 mfma8x64(const i32x8& h, const i32x8& dz, cons
 // lds_addr: wave-uniform LDS byte address (M0 is a reserved register: set here, used by nothing else in these kernels).
 __device__ __forceinline__ void dma_1k_asm(const char* p, uint32_t lane_off, uint32_t lds_addr) {
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, 0x7fffffff, 0x00020000);
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(lane_off), "s"(r), "s"(lds_addr));
+  // (clobbers: M0 -- so the compiler never keeps a value of its own there across this statement -- and memory: the DMA
+  // writes LDS behind the compiler's back; the explicit vmcnt waits and barriers of the callers stay what orders it)
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(lane_off), "s"(r), "s"(lds_addr) : "m0", "memory");
 }
 // per-lane constants of a transpose read: lane = 32 kg + 16 half + p, p = 2 j + q
 struct Tr8Lane {

@@ -8,9 +8,10 @@ communicates during training (/root/reference/src/bayesnf/inference.py:573-579, 
     open one engine handle per device -- `BNF_DEVICES=0,1,...` selects / orders them, default all
     visible -- device g owns the members `[g * E/G, (g + 1) * E/G)`, every device's whole
     optimisation is enqueued from its own host thread before anything is waited for, and the results
-    are assembled with the leading dims `(G, E/G)` by peer copies to the first device (default), or --
-    `BNF_GATHER=rccl`, opt-in until it has run on a box with two or more GPUs -- by one grouped RCCL
-    all-gather over a local communicator set (`bnf_comm_create_local` + `bnf_allgather_group`);
+    are assembled with the leading dims `(G, E/G)` by one grouped RCCL all-gather over a local
+    communicator set (`bnf_comm_create_local` + `bnf_allgather_group`) -- the default once the device set
+    has passed a time-limited 1 KiB first-use check (`group_gather_verdict`) -- or by peer copies to the
+    first device (repeated ordinals, a failed check, `BNF_GATHER=peer`);
   * one process per GPU under `torch.distributed.run` (backend "nccl" == RCCL over xGMI): rank r
     owns device LOCAL_RANK and the members of global device index r; the only collective is the
     final all-gather of fitted parameters / predictive means.
@@ -72,7 +73,8 @@ class Shard(NamedTuple):
 def local_shards() -> list[Shard]:
   """The (global device index, local ordinal) pairs this process is responsible for."""
   if is_distributed():
-    return [Shard(rank(), local_device_index())]
+    # (a gloo job without GPUs -- the CPU tests of the sharding arithmetic -- has no ordinal to offer: the engine refuses)
+    return [Shard(rank(), local_device_index() if torch.cuda.device_count() > 0 else 0)]
   return [Shard(i, d) for i, d in enumerate(local_devices())]
 
 
@@ -110,35 +112,88 @@ def run_shards(fn: Callable[[Shard], object], shards: list[Shard] | None = None)
 
 
 _gather_note = {}
+_group_verdict: dict = {}        # device ordinals of a local set -> did the grouped all-gather pass its first-use check?
+
+
+def _group_allgather(sends: list[torch.Tensor], recvs: list[torch.Tensor]) -> None:
+  """The one grouped RCCL all-gather of the in-process mode (seam: the CPU tests put a stand-in here)."""
+  from . import _native
+  _native.allgather_local(sends, recvs)
+
+
+def _sync(t: torch.Tensor) -> None:
+  if t.is_cuda:
+    torch.cuda.current_stream(t.device).synchronize()
+
+
+def _distinct_gpus(parts: list[torch.Tensor]) -> bool:
+  devs = [p.device for p in parts]
+  return len(parts) > 1 and all(d.type == 'cuda' for d in devs) and len(set(devs)) == len(devs)
+
+
+def group_gather_verdict(parts: list[torch.Tensor]) -> bool:
+  """First use of a set of local devices: ONE 1 KiB grouped all-gather (the `bench.py --check` exchange) on a watchdog
+  thread with a time limit (`BNF_GATHER_TIMEOUT_S`, default 20 s) -- communicator set-up, the collective, a value check
+  of every block on every device.  The verdict is cached per device set: True makes the RCCL all-gather the default
+  posterior gather of that set, False (exception, wrong values, or no answer in time -- the thread is then left behind
+  as a daemon, it cannot be cancelled) the peer copies.  So the north star's path is the default the first time two
+  GPUs exist, and a hang inside ncclCommInitAll / ncclGroupEnd cannot stall a `fit()` whose training has finished."""
+  key = tuple(str(p.device) for p in parts)
+  if key in _group_verdict:
+    return _group_verdict[key]
+  n, res = len(parts), {}
+
+  def probe():
+    try:
+      sends = [torch.full((256,), float(i + 1), dtype=torch.float32, device=p.device) for i, p in enumerate(parts)]
+      recvs = [torch.zeros((n, 256), dtype=torch.float32, device=p.device) for p in parts]
+      for t in sends:
+        _sync(t)
+      _group_allgather(sends, recvs)
+      for t in recvs:
+        _sync(t)
+      want = torch.arange(1, n + 1, dtype=torch.float32)[:, None].expand(n, 256)
+      res['ok'] = all(bool(torch.equal(r.cpu(), want)) for r in recvs)
+      if not res['ok']:
+        res['error'] = 'grouped all-gather delivered wrong blocks'
+    except BaseException as exc:   # pylint: disable=broad-except
+      res['ok'], res['error'] = False, f'{type(exc).__name__}: {exc}'[:300]
+
+  limit = float(os.environ.get('BNF_GATHER_TIMEOUT_S', '20'))
+  th = threading.Thread(target=probe, name='bnf-rccl-check', daemon=True)
+  th.start()
+  th.join(limit)
+  if th.is_alive():
+    res['ok'], res['error'] = False, f'grouped all-gather check gave no answer within {limit:g} s'
+  _group_verdict[key] = bool(res.get('ok'))
+  _gather_note['check'] = {'devices': key, 'ok': _group_verdict[key], **({'error': res['error']} if res.get('error') else {})}
+  return _group_verdict[key]
 
 
 def gather_shards(parts: list[torch.Tensor]) -> torch.Tensor:
   """One tensor (...) per local shard -> (device_count, ...) : the reference's implicit pmap output
   gather (inference.py:452,486-492).  torch.distributed: one all-gather (`all_gather_stack`).  One process with
-  several devices: peer copies to the first shard's device (the default: the only in-process path that has run on
-  hardware).  `BNF_GATHER=rccl` opts in to ONE grouped RCCL all-gather over the local communicator set
-  (`_native.allgather_local`: bnf_comm_create_local + bnf_allgather_group -- every device allocates a
-  (device_count, ...) receive buffer and receives every block, the first device's copy is returned).  That path
-  needs DISTINCT cuda devices; it has only ever run with one device or against the gloo stand-in (no box with two
-  GPUs was available to any round), a hang inside ncclCommInitAll / ncclGroupEnd would stall `fit()` after the
-  training has finished, hence opt-in; an RCCL set-up exception falls back to the peer copies
-  (`last_gather()` says which ran)."""
+  several DISTINCT GPUs: ONE grouped RCCL all-gather over the local communicator set (`_native.allgather_local`:
+  bnf_comm_create_local + bnf_allgather_group -- every device allocates a (device_count, ...) receive buffer and receives
+  every block, the first device's copy is returned) once that set has passed `group_gather_verdict`'s first-use check;
+  peer copies to the first shard's device otherwise (repeated ordinals, a failed or timed-out check, an RCCL exception).
+  `BNF_GATHER=peer` forces the copies, `BNF_GATHER=rccl` the collective without the check; `last_gather()` says which
+  ran and what the check found.  (No box with two GPUs was available to any round: the check is what stands between an
+  untried communicator set-up and a user's finished fit.)"""
   if is_distributed():
     assert len(parts) == 1
     return all_gather_stack(parts[0])
   dev0 = parts[0].device
-  devs = [p.device for p in parts]
-  if (len(parts) > 1 and all(d.type == 'cuda' for d in devs) and len(set(devs)) == len(devs)
-      and os.environ.get('BNF_GATHER', 'peer') == 'rccl'):
+  mode = os.environ.get('BNF_GATHER', 'auto')
+  if _distinct_gpus(parts) and mode != 'peer' and (mode == 'rccl' or group_gather_verdict(parts)):
     try:
-      from . import _native
       sends = [p.contiguous() for p in parts]
       for p in sends:
-        torch.cuda.current_stream(p.device).synchronize()   # producers ran on other host threads' streams
+        _sync(p)                                            # producers ran on other host threads' streams
       recvs = [torch.empty((len(parts),) + tuple(p.shape), dtype=p.dtype, device=p.device) for p in sends]
-      _native.allgather_local(sends, recvs)
+      _group_allgather(sends, recvs)
       for p in sends:
-        torch.cuda.current_stream(p.device).synchronize()
+        _sync(p)
       _gather_note['impl'] = 'rccl-group'
       return recvs[0]
     except (RuntimeError, OSError) as exc:
@@ -148,7 +203,7 @@ def gather_shards(parts: list[torch.Tensor]) -> torch.Tensor:
 
 
 def last_gather() -> dict:
-  """{'impl': 'rccl-group' | 'peer-copies', 'error': ...} of the last in-process `gather_shards`."""
+  """{'impl': 'rccl-group' | 'peer-copies', 'error': ..., 'check': {...}} of the last in-process `gather_shards`."""
   return dict(_gather_note)
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# phase clocks of ab/libbnf_<lib>.so for the listed threads: LIBS="ablate ..." THREADS="0 448" bash scripts/visits/gpu_clk.sh tag
+# phase clocks of ab/libbnf_<lib>.so for the listed threads: LIBS="ablate ..." THREADS="0 448" bash scripts/gpu_clk.sh tag
 set -u; ulimit -c 0
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/${1:-clk}; mkdir -p "$OUT"; cd "$ROOT"
 for lib in ${LIBS:-ablate}; do

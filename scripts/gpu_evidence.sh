@@ -1,9 +1,9 @@
 #!/bin/bash
-# r05 evidence visit: -m gpu suite, smoke, bench (+cpu_baseline), rocprof kernel stats, PMC HBM traffic, SQ counters
+# evidence visit (parametrized by tag; was scripts/visits/gpu_r05z.sh): -m gpu suite, smoke, bench (+cpu_baseline), rocprof kernel stats, PMC HBM traffic, SQ counters
 # (-> profiles/sq_counters.json, pmc_traffic.json), the other configurations in bf16 AND fp8 with per-kernel tables, phase
 # clocks, fp32 / fp8 bench lines, PMC traffic of C5/8 in both dtypes, same-box A/B against the round-4 kernels
 set -u; ulimit -c 0
-TAG=${1:-r05z}
+TAG=${1:-r06z}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; cd "$ROOT"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -vE "^(RCCL|HIP|ROCm|Hostname|Librccl)" > "$OUT/pytest_gpu.txt"; tail -3 "$OUT/pytest_gpu.txt"
@@ -24,7 +24,7 @@ PASS1="SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_
 python scripts/counter_summary.py "$OUT/../${TAG}_ctr" "$OUT/sq_counters.json" > /dev/null
 echo "== configs (bf16 / fp8)"; for c in C3 C4 C5; do for dt in bf16 fp8; do BNF_BENCH_DTYPE=$dt timeout 600 python scripts/bench_configs.py $c 2>/dev/null | tail -1 | sed "s/^{/{\"dtype\": \"$dt\", /"; done; done > "$OUT/configs_bench.jsonl"; cut -c1-330 "$OUT/configs_bench.jsonl"
 for dt in bf16 fp8; do for c in "C3/8 air_quality-like VI" "C4/8 synthetic minibatch MLE" "C5/8 wind-like MAP (bf16)"; do echo "== $c [$dt]"; BNF_BENCH_DTYPE=$dt timeout 200 python scripts/profile_config.py "$c" 2>/dev/null; done; done > "$OUT/config_profiles.txt"
-echo "== phase clocks"; LIBS=ablate THREADS="0 448" bash scripts/visits/gpu_clk.sh ${TAG}_clk 2>&1 | tee "$OUT/phase_clocks.txt"
+echo "== phase clocks"; LIBS=ablate THREADS="0 448" bash scripts/gpu_clk.sh ${TAG}_clk 2>&1 | tee "$OUT/phase_clocks.txt"
 echo "== bench fp32"; timeout 600 python bench.py --dtype fp32 --steps 10 --warmup 2 --no-cpu-baseline --profile-all > "$OUT/bench_fp32.json" 2> "$OUT/bench_fp32.err"; cut -c1-400 "$OUT/bench_fp32.json"; grep "\[bench\]" "$OUT/bench_fp32.err" > "$OUT/bench_fp32_hip_events.txt"
 echo "== bench fp8"; timeout 600 python bench.py --dtype fp8 --steps 30 --warmup 5 --no-cpu-baseline --profile-all > "$OUT/bench_fp8.json" 2> "$OUT/bench_fp8.err"; cut -c1-600 "$OUT/bench_fp8.json"; grep "\[bench\]" "$OUT/bench_fp8.err" | tee "$OUT/bench_fp8_hip_events.txt"
 echo "== C1 step time"; timeout 300 python scripts/c1_step_time.py 2>/dev/null | tee "$OUT/c1_step_time.txt"

@@ -1,8 +1,8 @@
-"""N>1 path on CPU: two gloo ranks exercise the member sharding arithmetic and the
-posterior gather used by fit_map / predict_bnf (bayesnf_amd/distributed.py).  The
-compute itself is HIP-only, so each rank fabricates its shard's "fitted"
-parameters / predictive means as a deterministic function of the GLOBAL member id;
-the gathered result must equal the single-process result."""
+"""N>1 path on CPU: two gloo ranks run a REAL sharded `fit_map` -- the product's own function, with the CPU stand-in
+engine of tests/standin_engine.py injected through the one name `bayesnf_amd.inference.Engine` (compute itself is HIP-only;
+the stand-in trains its members with the float64 oracle from the reference's initial particles) -- so that the members'
+parameters and losses flow through run_shards -> gather_shards (one all-gather) -> _struct_tuple, and the gathered
+ensemble equals the one-process fit of all members, full batch and minibatch (bayesnf_amd/distributed.py)."""
 import os
 import subprocess
 import sys
@@ -20,6 +20,7 @@ WORKER = textwrap.dedent('''
     from bayesnf_amd import distributed
     from bayesnf_amd.spec import NetSpec
     from bayesnf_amd import inference
+    from bayesnf_amd import jaxseed as jaxseed_mod
 
     torch.distributed.init_process_group(backend='gloo')
     world, rank = distributed.device_count(), distributed.rank()
@@ -29,16 +30,35 @@ WORKER = textwrap.dedent('''
     assert (first, count) == (rank * 3, 3)
     net = NetSpec(width=64, depth=1, input_scales=[9.0, 1.0], fourier_degrees=[2, 0],
                   interactions=[(0, 1)])
-    gid = np.arange(first, first + count)
-    theta_local = (gid[:, None] * 1000 + np.arange(net.P)[None, :]).astype(np.float32)
-    means_local = (gid[:, None] * 10.0 + np.arange(R)[None, :]).astype(np.float32)
-    theta = distributed.all_gather_stack(torch.from_numpy(theta_local)).numpy()
+    # ---- a real sharded fit through the product's fit_map: stand-in engine behind the one seam ----
+    from tests.standin_engine import StandInEngine
+    kw = dict(width=64, depth=1, input_scales=[9.0, 1.0], fourier_degrees=[2, 0], interactions=[[0, 1]],
+              seasonality_periods=[], num_seasonal_harmonics=[])
+    StandInEngine.model_kwargs = dict(kw, observation_model='NORMAL')
+    inference.Engine = StandInEngine
+    rng = np.random.default_rng(0)
+    X = np.stack([rng.integers(0, 10, 40).astype(float), rng.standard_normal(40)], axis=1)
+    y = np.sin(X[:, 0]) + X[:, 1] + 0.1 * rng.standard_normal(40)
+    args = dict(kw, init_x=X[:2])
+    for bs in (None, 16):
+      StandInEngine.created.clear()
+      params, losses = inference.fit_map(X, y, 7, 'NORMAL', args, num_particles=E, learning_rate=0.01, num_epochs=3,
+                                         batch_size=bs)
+      assert StandInEngine.created == [(rank * 3, 3, 0)], StandInEngine.created      # this rank trained ITS members only
+      assert losses.shape == (2, 3, 3) and params.var0.shape == (2, 3) and params[4].shape == (2, 3) + net.leaves[4].shape
+      theta = inference._flatten_struct(net, params)                               # (2, 3, P), every rank holds all of it
+      # the same fit in ONE shard (all six members on "device" 0 of a one-device job)
+      eng = StandInEngine(net, X=X, y=y, batch=bs, members=E, learning_rate=0.01)
+      eng.init_params_keys(jaxseed_mod.map_leaf_keys(net, jaxseed_mod.member_keys(7, 1, E)[0]), float(np.log(np.nanstd(y) / 2)))
+      if bs is not None:
+        eng.set_row_keys(jaxseed_mod.map_shuffle_subkeys(jaxseed_mod.map_permute_keys(7, 1, E, 3)[0], 40))
+      l_one = eng.train(0, 3).numpy()
+      np.testing.assert_array_equal(theta.reshape(E, net.P), eng.params.numpy().reshape(E, net.P))
+      np.testing.assert_array_equal(losses.reshape(E, 3), l_one)
+      assert np.abs(theta).max() > 0.5 and not np.array_equal(theta[0, 0], theta[1, 0])
+    means_local = (np.arange(first, first + count)[:, None] * 10.0 + np.arange(R)[None, :]).astype(np.float32)
     means = distributed.all_gather_numpy(means_local)
-    assert theta.shape == (2, 3, net.P) and means.shape == (2, 3, R)
-    full = (np.arange(E)[:, None] * 1000 + np.arange(net.P)[None, :]).astype(np.float32)
-    np.testing.assert_array_equal(theta.reshape(E, net.P), full)
-    np.testing.assert_array_equal(means.reshape(E, R),
-                                  np.arange(E)[:, None] * 10.0 + np.arange(R)[None, :])
+    np.testing.assert_array_equal(means.reshape(E, R), np.arange(E)[:, None] * 10.0 + np.arange(R)[None, :])
     # real sharded work (host side of fit_map): every rank draws ITS members' initial parameters
     # from the reference's seed chain; the gathered ensemble equals the one-process result
     from bayesnf_amd import jaxseed
@@ -48,10 +68,6 @@ WORKER = textwrap.dedent('''
     ref = jaxseed.map_initial_params(net, jaxseed.member_keys(7, 1, 6)[0], 0.5)
     np.testing.assert_array_equal(init_all.reshape(6, net.P), ref)
     assert np.abs(ref).max() > 0.5 and not np.array_equal(ref[0], ref[3])
-    # StructTuple round trip with the (devices, E/devices) leading dims of the reference
-    params = inference._struct_tuple(net, theta)
-    assert params.var0.shape == (2, 3) and params[4].shape == (2, 3) + net.leaves[4].shape
-    np.testing.assert_array_equal(inference._flatten_struct(net, params), theta)
     # ensemble_size smaller than the device count is rejected like the reference
     from bayesnf_amd import BayesianNeuralFieldMAP
     import pandas as pd
