@@ -83,6 +83,8 @@ struct bnf_handle {
   bool bf16 = false;
   int f32_split = 0;      // BNF_DTYPE_F32S: the f32 contractions on split-bf16 MFMAs (GemmArgs.f32_split)
   bool q8 = false;        // BNF_DTYPE_FP8: bf16 contractions + fp8 operand copies for the weight-gradient kernels (bnf_gemm8.h)
+  bool c8 = false;        // ... and the W x W contractions of the two-layer MAP row-panel forms on the fp8 MFMA (PanelArgs.c8)
+  uint8_t* Wf8[BNF_MAX_LAYERS] = {}; uint8_t* Wb8[BNF_MAX_LAYERS] = {};   // e4m3 x 2^5 K = 64 weight fragments (layers >= 1)
   uint8_t* H0q = nullptr; // (Ev, Bp, Fp) e4m3 copy of the features (layer-0 weight gradient)
   float* qscale = nullptr;   // (Ev) s_H s_dZ of the step: written by the panel kernel, read by the weight-gradient kernels
   int es = 4;          // element size of T
@@ -234,6 +236,8 @@ static size_t carve(bnf_handle* h, char* base) {
     h->Wf[l] = h->panel ? take((size_t)Ev * npad * W * es) : nullptr;
     h->Wb[l] = h->panel ? take((size_t)Ev * npad * W * es) : nullptr;
     h->park[l] = (h->panel && !fo && l >= 1 && l < h->L - 1) ? take((size_t)Ev * Bp * W * es) : nullptr;
+    h->Wf8[l] = (h->c8 && l >= 1) ? (uint8_t*)take((size_t)Ev * W * W) : nullptr;
+    h->Wb8[l] = (h->c8 && l >= 1) ? (uint8_t*)take((size_t)Ev * W * W) : nullptr;
   }
   h->dH0 = fo ? nullptr : (float*)take((size_t)Ev * Fp * Bp * 4);            // dH0^T (Fp, Bp)
   h->out = (float*)take((size_t)Ev * Bp * 4);
@@ -923,6 +927,8 @@ static PackJobs pack_jobs(const bnf_handle* h, int* n_tiles) {
   }
   jb.tile0[h->L] = tiles;
   jb.fold0 = h->fold0 ? 1 : 0; jb.F0n = h->F; jb.off_bias0 = h->nd.off_bias[0]; jb.off_ls0 = h->nd.off_ls[0];
+  for (int l = 0; l < h->L; ++l) { jb.wf8[l] = h->Wf8[l]; jb.wb8[l] = h->Wb8[l]; }
+  jb.batch8 = (int64_t)h->W * h->W;
   *n_tiles = tiles;
   return jb;
 }
@@ -942,12 +948,12 @@ static void run_pack_fragments(bnf_handle* h, const float* theta, int nmem) {
 #ifndef BNF_PANEL_BM64
 #define BNF_PANEL_BM64 0
 #endif
-template <int WN, int RT, bool H0L, bool DEEP, int CH, int FP, bool F0>
+template <int WN, int RT, bool H0L, bool DEEP, int CH, int FP, bool F0, bool C8 = false>
 static void launch_panel_f(bnf_handle* h, const PanelArgs& pa) {
   constexpr int kLds = panel_lds_bytes(WN, RT, H0L, CH, FP);
   static_assert(kLds <= 160 * 1024, "LDS per workgroup");
   static std::atomic<uint64_t> attr_done{0};
-  allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH, FP, F0>, kLds, &attr_done);
+  allow_lds(h, &k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH, FP, F0, C8>, kLds, &attr_done);
   PanelArgs pa2 = pa;
   pa2.ablate = h->ablate;
   const unsigned blocks = (unsigned)(pa.members * pa.panels);
@@ -958,7 +964,7 @@ static void launch_panel_f(bnf_handle* h, const PanelArgs& pa) {
   }
   {
     LaunchScope ls(h, KID_PANEL);
-    hipLaunchKernelGGL((k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH, FP, F0>), dim3(blocks), dim3(512), kLds, h->stream, pa2);
+    hipLaunchKernelGGL((k_panel_fwd_bwd<WN, RT, H0L, DEEP, CH, FP, F0, C8>), dim3(blocks), dim3(512), kLds, h->stream, pa2);
   }
   phase_prof_end(h, KID_PANEL, blocks, 512);
 }
@@ -966,6 +972,12 @@ template <int WN, int RT, bool H0L, bool DEEP, int CH, int FP>
 static void launch_panel_d(bnf_handle* h, const PanelArgs& pa) {
   if constexpr (H0L) {
     if (h->fold0) {
+      if constexpr (!DEEP && CH == 1) {
+        if (pa.c8) {      // fp8 W x W contractions: the folded two-layer forms only (bnf_create decides h->c8)
+          launch_panel_f<WN, RT, H0L, DEEP, CH, FP, true, true>(h, pa);
+          return;
+        }
+      }
       launch_panel_f<WN, RT, H0L, DEEP, CH, FP, true>(h, pa);
       return;
     }
@@ -1023,6 +1035,8 @@ static void run_panel(bnf_handle* h, const float* theta, int nmem, const RowSrc&
   pa.fin = h->fin ? 1 : 0; pa.n_in = h->nd.D; pa.n_seas = 2 * h->ft.n;
   pa.X = h->X; pa.stab = h->stab; pa.y = h->y; pa.fcol = h->fcol; pa.H0out = (bf16_t*)h->H0; pa.rs = rs;
   pa.q8 = h->q8 ? 1 : 0; pa.qscale = h->qscale;
+  pa.c8 = h->c8 ? 1 : 0; pa.w8_batch = (int64_t)h->W * h->W;
+  for (int l = 0; l < L; ++l) { pa.Wf8[l] = h->Wf8[l]; pa.Wb8[l] = h->Wb8[l]; }
   // 128-row panels at W = 512 (the feature panel staged in LDS when Fp = 64), 256-row panels at W = 256,
   // 64-row panels with two 64-column slabs per wave at W = 1024
   auto with_fused_featbwd = [&]() {
@@ -1540,6 +1554,9 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
                   "depth >= 2, width 256 / 512 / 1024 after padding to 64, <= 128 padded features");
     }
     if (h->panel) h->Bp = align_up(h->B, 256);
+    // fp8 W x W contractions (PanelArgs.c8): the two-layer row-panel forms with one 64-column slab per wave (W = 256 / 512);
+    // BNF_FP8_CONTRACT=0 keeps the round-5 arithmetic (bf16 contractions, fp8 copies only)
+    h->c8 = h->q8 && h->panel && h->L == 2 && h->W != 1024 && !(getenv("BNF_FP8_CONTRACT") && atoi(getenv("BNF_FP8_CONTRACT")) == 0);
     // pipeline 0 (auto): layer kernels with the one-kernel last layer where the width allows;
     // pipeline 1: every layer kernel separate and every activation materialised (validation)
     const bool fl_ok = h->bf16 ? fused_last_supported<bf16_t>(h->W) : fused_last_supported<float>(h->W);
@@ -1549,6 +1566,7 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
   }
   h->h0l = h->panel && (((h->W == 512 || h->W == 1024) && h->Fp == 64) || (h->W == 256 && (h->Fp == 64 || h->Fp == 128))) && !getenv("BNF_PANEL_NO_H0L");
   h->fold0 = h->h0l && h->F + 2 <= h->Fp && !(getenv("BNF_PANEL_FOLD0") && atoi(getenv("BNF_PANEL_FOLD0")) == 0);
+  h->c8 = h->c8 && h->fold0;     // (the fp8-contraction kernels are instantiated for the folded forms: every BASELINE layout)
   // (experiment builds only; not with fp8 operand storage: the fp8 feature copy H0q is written by k_featurize alone)
   h->fin = BNF_PANEL_FIN != 0 && h->h0l && cfg->dtype != BNF_DTYPE_FP8 && getenv("BNF_PANEL_FIN") && atoi(getenv("BNF_PANEL_FIN")) != 0;
   if (h->fin) {

@@ -120,7 +120,22 @@ struct PanelArgs {
   // one instruction per element pair, half the store instructions and bytes).
   int32_t q8;
   float* qscale;
+  // c8 (round 6; compute_dtype 'fp8', the folded two-layer forms): the two W x W contractions of the panel run on the
+  // block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4: K = 64 per instruction at twice the bf16 rate) -- weights
+  // pre-packed as OCP e4m3 x 2^5 in K = 64 fragments (Wf8 / Wb8, k_pack_layers; the 2^-5 rides in the instruction's E8M0
+  // scale), and the panels those contractions read live in LDS AS FP8 (row pitch W + 16 bytes): H_1 as e4m3, written by the
+  // layer-0 forward epilogue (one v_cvt_pk_fp8_f32 per element pair where the bf16 form spends one v_cvt_pk_bf16_f32), dZ_L
+  // as e5m2 / s_dZ.  The copies for the weight-gradient kernels are then plain byte copies of those panels.  Layer 0, its
+  // backward-data and everything that is not a W x W contraction stay bf16 (the dZ_0 panel, the column-sum MFMAs).
+  // (A first form converted the bf16 panel in registers on its way to the instruction -- every wave the same rows, 16
+  // v_cvt_scalef32_pk per fragment: as slow as the bf16 contraction, profiles/r06_fp8_contract_ab.txt.)
+  int32_t c8;
+  const uint8_t* Wf8[BNF_MAX_LAYERS];   // [n / 32][k / 64][2][64 lanes][16 bytes]: lane (n % 32, kg) holds k = 64 ks + 32 kg + 0 .. 31
+  const uint8_t* Wb8[BNF_MAX_LAYERS];
+  int64_t w8_batch;
 };
+constexpr float kW8Scale = 32.f;          // packed fp8 weights are K x 2^5 (|K| < 14 stays finite; e4m3 is normal down to 2^-6 / 32)
+constexpr int kW8ScaleE8M0 = 127 - 5;
 constexpr int kFbNone = 0, kFbInput = 1, kFbFourier = 2, kFbInter = 3;
 
 // ---- fragment-major weight packing -------------------------------------------------
@@ -140,6 +155,10 @@ struct PackJobs {
   // fold0 (the panel kernel's F0 forms): layer 0's FORWARD fragments carry gamma0 log2(e) / sqrt F, and the K rows F and
   // F + 1 hold gamma0 log2(e) b0 split into a bf16 hi and lo part (against the two ones columns of k_featurize)
   int32_t fold0, F0n, off_bias0, off_ls0;
+  // c8 (PanelArgs): layers l >= 1 also leave as e4m3 x 2^5 fragments of K = 64 (one 64 x 64 tile = 2 forward + 2 backward
+  // fragments of 2 KiB: one 16-byte piece per thread)
+  void* wf8[BNF_MAX_LAYERS]; void* wb8[BNF_MAX_LAYERS];
+  int64_t batch8;
 };
 // Workgroup 0 of a member also fills the member's row of the transformed-scalar table
 // (k_member_scalars folded in: one launch and one dependent-launch gap less per step).
@@ -185,6 +204,29 @@ __device__ __forceinline__ void pack_tile_fragments(const float (&tile)[64][65],
       for (int j = 0; j < 8; ++j) v[j] = tile[il][cl + j];
       const int64_t f = (int64_t)((k0 + il) / 32) * KSb + (n0 + cl) / 16;
       store8(wb + (f * 64 + fl) * 8, v);
+    }
+  }
+  if (jb.wf8[l] && l >= 1) {
+    // K = 64 fp8 fragments (PanelArgs.c8): item q = (layout, fragment of the tile, 16-byte piece, lane); W / 64 k steps per
+    // 32-wide tile row in both layouts
+    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);   // MODE.FP16_OVFL: saturate
+    const int KS64 = W / 64;
+    for (int q = tid; q < 512; q += NT) {
+      const int lay = q >> 8, fr = (q >> 7) & 1, pc = (q >> 6) & 1, fl = q & 63;
+      const int ml = fr * 32 + (fl & 31), kb = (fl >> 5) * 32 + pc * 16;      // tile-local m (n or i) and first k (k or c)
+      uint32_t w4[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        float x[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) x[b] = (lay == 0 ? tile[kb + 4 * d + b][ml] : tile[ml][kb + 4 * d + b]) * kW8Scale;
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], pk, true);
+        w4[d] = (uint32_t)pk;
+      }
+      uint8_t* base = (uint8_t*)(lay == 0 ? jb.wf8[l] : jb.wb8[l]) + e * jb.batch8;
+      const int64_t f = lay == 0 ? (int64_t)((n0 + ml) / 32) * KS64 + k0 / 64 : (int64_t)((k0 + ml) / 32) * KS64 + n0 / 64;
+      *reinterpret_cast<u32x4*>(base + f * 2048 + pc * 1024 + fl * 16) = u32x4{w4[0], w4[1], w4[2], w4[3]};
     }
   }
 }
@@ -499,6 +541,73 @@ __device__ __forceinline__ void panel_contract(f32x16 (&acc)[RT][2], const char*
   for (int ks0 = ZERO ? PD : 0; ks0 < KS; ks0 += PD) group(ks0, std::false_type{});
 }
 
+// The same contraction on the block-scaled fp8 MFMA (PanelArgs.c8): acc[RT][2] = P8[rows of this wave][0 .. 64 KS64) . W8
+// fragments, K = 64 per instruction.  The panel is FP8 in LDS (row pitch KPITCH8 = W + 16 bytes: the 16 lanes of a
+// ds_read_b128 group -- 16 rows -- fall on 64 different banks): a lane's 32 operand bytes are two ds_read_b128 of its own
+// row.  Weight fragments (e4m3 x 2^5, scale byte 127 - 5): two 16-byte pieces per lane, one k step ahead in registers.
+// Byte idx of lane (m, kg) <-> k = 32 kg + idx in BOTH operands (the instruction pairs equal (kg, idx): bnf_gemm8.h).
+// BF8: the panel holds backward signals, e5m2 of dZ / s_dZ, and `pscale` (the E8M0 byte of s_dZ) puts the factor back.
+// Accumulator layout = the bf16 instruction's.
+typedef int pc8_i32x8 __attribute__((ext_vector_type(8)));
+template <int KPITCH8, int RT, bool SWAP, bool BF8>
+__device__ __forceinline__ void panel_contract8(f32x16 (&acc)[RT][2], const char* prow8, const uint8_t* wp8, int nt0, int KS64,
+                                                int lane, int pscale) {
+  // prow8: this lane's row of the panel + kg * 32 bytes; rows frow + 32 i
+  const PanelW w = panel_wbase(reinterpret_cast<const char*>(wp8));
+  const uint32_t o0 = (uint32_t)nt0 * (uint32_t)KS64 * 2048u, o1 = o0 + (uint32_t)KS64 * 2048u;   // uniform
+  const uint32_t loff = (uint32_t)lane * 16u;
+  auto wload = [&](uint32_t o) {
+    const u32x4 a = __builtin_bit_cast(u32x4, panel_wload(w, o, loff));
+    const u32x4 b = __builtin_bit_cast(u32x4, panel_wload(w, o + 1024u, loff));
+    return pc8_i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+  };
+  int hi_off = 64 * KPITCH8;
+  asm volatile("" : "+v"(hi_off));
+  const char* prow_hi = prow8 + hi_off;
+  auto load_a = [&](int i, int ks) {
+    const char* p = ((i >> 1) ? prow_hi : prow8) + (i & 1) * 32 * KPITCH8 + ks * 64;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(p), b = *reinterpret_cast<const u32x4*>(p + 16);
+    return pc8_i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+  };
+  pc8_i32x8 fb[2][2], fa[2][RT];
+  fb[0][0] = wload(o0); fb[0][1] = wload(o1);
+#pragma unroll
+  for (int i = 0; i < RT; ++i) fa[0][i] = load_a(i, 0);
+  auto step = [&](int ks, auto first_tag, auto cur_tag) {
+    constexpr bool kFirst = decltype(first_tag)::value;
+    constexpr int cur = decltype(cur_tag)::value;
+    const int kn = min(ks + 1, KS64 - 1);                         // (the tail re-reads the last fragment: unused)
+    fb[cur ^ 1][0] = wload(o0 + (uint32_t)kn * 2048u);
+    fb[cur ^ 1][1] = wload(o1 + (uint32_t)kn * 2048u);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) fa[cur ^ 1][i] = load_a(i, kn);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // formats: 0 = e4m3, 1 = e5m2; weights carry 2^5 (scale byte 127 - 5), the panel operand s_dZ (pscale)
+        if constexpr (kFirst) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[i][j] = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[cur][j], fa[cur][i], z, 0, BF8 ? 1 : 0, 0, kW8ScaleE8M0, 0, pscale)
+                           : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[cur][i], fb[cur][j], z, BF8 ? 1 : 0, 0, 0, pscale, 0, kW8ScaleE8M0);
+        } else {
+          acc[i][j] = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[cur][j], fa[cur][i], acc[i][j], 0, BF8 ? 1 : 0, 0, kW8ScaleE8M0, 0, pscale)
+                           : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[cur][i], fb[cur][j], acc[i][j], BF8 ? 1 : 0, 0, 0, pscale, 0, kW8ScaleE8M0);
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // (KS64 is even: W = 256 / 512) two k steps per trip so that the fragment buffers alternate without copies
+  step(0, std::true_type{}, std::integral_constant<int, 0>{});
+  step(1, std::false_type{}, std::integral_constant<int, 1>{});
+#pragma unroll 1
+  for (int ks = 2; ks < KS64; ks += 2) {
+    step(ks, std::false_type{}, std::integral_constant<int, 0>{});
+    step(ks + 1, std::false_type{}, std::integral_constant<int, 1>{});
+  }
+}
+
 // Layer-0 contraction of one 32-row block x this wave's 64 columns, both operands from global
 // memory, both fragment-major (one contiguous 1 KiB wave load per 32 x 16 fragment).
 // One 32 x 32 output tile at a time (16 accumulator registers: the backward epilogue runs with the
@@ -541,13 +650,14 @@ __device__ __forceinline__ void l0_mma(f32x16& a0, const L0Blk& bk) {
 // the ones column.  With no per-column constant left in the two layer-0 epilogues, both run with the MFMA operand
 // roles SWAPPED (weights as A, panel rows as B): a lane then owns ONE row and four consecutive hidden units per
 // register group, and the bf16 panel store is one ds_write_b64 per four elements instead of four ds_write_b16.
-template <int WN, int RT, bool H0L, bool DEEP = false, int CH = 1, int FP = 64, bool F0 = false>
+template <int WN, int RT, bool H0L, bool DEEP = false, int CH = 1, int FP = 64, bool F0 = false, bool C8 = false>
 __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_panel_fwd_bwd(const PanelArgs a) {   // (4: the r04s experiment form only)
   static_assert(!F0 || H0L, "the folded layer 0 needs the LDS feature panel");
   constexpr int W = 64 * WN * CH, RB = 8 / WN, WR = 32 * RT, BM = WR * RB;   // WR = rows per wave
   constexpr int kSlabs = WN * CH;           // 64-column slabs of the layer
   constexpr int kPitchE = W + 8;            // panel row pitch, elements (16 bytes of padding)
   constexpr int kPitchB = kPitchE * 2;
+  constexpr int kPitch8 = W + 16;           // C8: row pitch of an fp8 panel image, bytes
   constexpr int KS1 = W / 16;
   constexpr int kHalves = (RT + 1) / 2;     // row dots go through a 64-row scratch image per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -609,6 +719,9 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   // q8: s_dZ = 2^(round(log2(c gamma_o / sigma)) - 6): d out is ~ c (y - out) / sigma^2 = (c / sigma) x a residual of order
   // one, and dZ_l is that times gamma_l k / sqrt W act' ~ a few 1e-2 -- stored values land around 2^0 .. 2^4 of e5m2's
   // 2^-14 .. 2^15 normal range, with ten binades of head room either way (count models: no sigma, c gamma_o alone)
+  static_assert(!C8 || (!DEEP && CH == 1), "fp8 contractions: two-layer forms with one slab per wave");
+  constexpr bool c8 = C8;     // the W x W contractions on the fp8 MFMA (PanelArgs.c8): its own instantiation -- as a run-time branch
+                              // both contraction bodies were live in one kernel (256 registers + 112 bytes of scratch for bf16, too)
   float q_dz = 1.f;
   if (a.q8) {
     __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);   // MODE.FP16_OVFL: fp8 conversions clamp to the largest finite value
@@ -616,6 +729,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
     q_dz = exp2f(rintf(log2f(fmaxf(ref, 1e-30f))) - 6.f);
     if (pn == 0 && tid_k == 0) a.qscale[e] = q_dz;
   }
+  const float inv_qdz = 1.0f / q_dz;     // (a power of two: exact)
   // the row phase's target value, fetched now (one thread per row; rows >= B read nothing)
   const float y_pre = (!(BNF_PANEL_FIN && H0L && a.fin) && tid < BM && m0 + tid < a.B) ? a.ybat[(int64_t)e * a.row_batch + m0 + tid] : 0.f;
 
@@ -691,6 +805,24 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
       __builtin_amdgcn_raw_buffer_store_b128(o, rs, (uint32_t)(row * W + p4 * 16), 0, BNF_PANEL_NT ? 2 : 0);
     }
   };
+  // C8: a 32-row x 64-column block of an FP8 panel image (H_1 as e4m3, dZ_L as e5m2 / s_dZ) is already what the
+  // weight-gradient kernels read: 32 rows x 64 bytes leave as two 1 KiB stores, no conversion
+  auto block_to_global_p8 = [&](int lane, bf16_t* dst, int prb, int pcb, int i) {
+    uint8_t* d = reinterpret_cast<uint8_t*>(dst) + (int64_t)e * a.act_batch + (int64_t)(m0 + prb + i * 32) * W + pcb;   // uniform
+    const char* sp = smem + (prb + i * 32) * kPitch8 + pcb;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d, 0, 0x7fffffff, 0x00020000);
+    u32x4 v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pc = lane + 64 * u, row = pc >> 2, p4 = pc & 3;
+      v[u] = *reinterpret_cast<const u32x4*>(sp + row * kPitch8 + p4 * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pc = lane + 64 * u, row = pc >> 2, p4 = pc & 3;
+      __builtin_amdgcn_raw_buffer_store_b128(v[u], rs, (uint32_t)(row * W + p4 * 16), 0, BNF_PANEL_NT ? 2 : 0);
+    }
+  };
   auto is_dz_array = [&](const bf16_t* dst) {     // (uniform) one of the dZ arrays? else an activation copy
     bool dz = false;
 #pragma unroll
@@ -699,6 +831,12 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   };
   auto block_to_global = [&](const LaneCtx& L, bf16_t* dst, int i, int cbase) {
     if (BNF_ABL(a, 8)) return;
+    if constexpr (C8) {
+      if (dst == a.Hout[0] || dst == a.dZ[1]) {     // the panels the fp8 contractions read: fp8 images
+        block_to_global_p8(L.lane, dst, rbase, cbase, i);
+        return;
+      }
+    }
     if (a.q8) {
       block_to_global_q8(L.lane, dst, rbase, cbase, i, is_dz_array(dst));
       return;
@@ -904,7 +1042,13 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
             hq[q >> 1] = ak.c1 * c.r + (ak.alpha * s + ak.c0);
 #endif
           }
-          store_quad_pk(rowp + 8 * rg, hq[0].x, hq[0].y, hq[1].x, hq[1].y);
+          if constexpr (C8) {      // H_1 leaves as e4m3 into the fp8 panel image: four consecutive hidden units = one dword
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(hq[0].x, hq[0].y, 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(hq[1].x, hq[1].y, pk, true);
+            *reinterpret_cast<int*>(smem + (rbase + i * 32 + frow) * kPitch8 + cbase + j * 32 + 4 * kg + 8 * rg) = pk;
+          } else {
+            store_quad_pk(rowp + 8 * rg, hq[0].x, hq[0].y, hq[1].x, hq[1].y);
+          }
         }
         return;
       }
@@ -973,6 +1117,23 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
 #pragma unroll
     for (int hc = 0; hc < CH; ++hc) panel_prefetch(ring[hc], wp, 2 * slab(hc), KS1, lane);
   };
+  // c8: the W x W contraction on the fp8 MFMA (panel_contract8) out of the fp8 panel image; bf8: backward signals (e5m2 / s_dZ)
+  auto contract_all8 = [&](const uint8_t* wp8, auto swap_tag, auto bf8_tag) {
+    constexpr bool kBf8 = decltype(bf8_tag)::value;
+    const int lane = opaque_lane(tid) & 63;
+    const char* prow8 = smem + (rbase + (lane & 31)) * kPitch8 + (lane >> 5) * 32;
+    // s_dZ = 2^k exactly: its E8M0 byte is the float's own exponent field
+    const int pscale = kBf8 ? (int)((__float_as_uint(q_dz) >> 23) & 0xffu) : 127;
+#if BNF_PANEL_CPRIO
+    if ((BNF_PANEL_CPRIO == 1) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int hc = 0; hc < CH; ++hc)
+      panel_contract8<kPitch8, RT, decltype(swap_tag)::value, kBf8>(accs[hc], prow8, wp8, 2 * slab(hc), W / 64, lane, pscale);
+#if BNF_PANEL_CPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
   auto contract_all_t = [&](const char* wp, auto swap_tag) {   // accs[hc] (+)= panel . W[:, slab hc] for every slab
     const LaneCtx L = lane_ctx();
 #if BNF_PANEL_CPRIO
@@ -1002,6 +1163,11 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
     for (int b = 0; b < 2; ++b) {
       const int pw = b == 0 ? wave : (wave ^ 4);              // this wave's slab, then its SIMD partner's
       const int prb = (pw / WN) * WR, pcb = (pw % WN) * CH * 64;
+      if constexpr (C8) {          // (only ever called for dZ_L: the e5m2 panel image as it stands)
+#pragma unroll
+        for (int i = 0; i < RT; ++i) block_to_global_p8(lane, dst, prb, pcb, i);
+        continue;
+      }
       if (a.q8) {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
@@ -1029,7 +1195,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
     }
   };
   auto contract_all = [&](const char* wp) { contract_all_t(wp, std::false_type{}); };
-  ring_prefetch(wfl(1), opaque_lane(tid) & 63);   // in flight across the barrier
+  if (!c8) ring_prefetch(wfl(1), opaque_lane(tid) & 63);   // in flight across the barrier
   lds_barrier();
   BNF_MARK(a, 2);
 
@@ -1119,7 +1285,10 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   // C5/8 10.89k -> 10.79k member-steps/s same box, three alternations, profiles/r05_panel_ab.md)
   constexpr bool kL1T = BNF_PANEL_L1T != 0 && CH == 1 && WN == 8;
   if (!BNF_PANEL_ZPEEL) zero_acc();
-  contract_all_t(wfl(LL), std::integral_constant<bool, kL1T>{});
+  if constexpr (c8)
+    contract_all8(a.Wf8[1] + (int64_t)e * a.w8_batch, std::integral_constant<bool, kL1T>{}, std::false_type{});
+  else
+    contract_all_t(wfl(LL), std::integral_constant<bool, kL1T>{});
   BNF_MARK(a, 3);
   // L1T: the per-register column constants of slab 0 (bias and output kernel of the wave's 64 columns: a lane holds the
   // 32 columns of its half) are requested before the barrier -- the ring and fragment registers are dead -- and arrive
@@ -1431,7 +1600,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
       }
       // (the copy of dZ_L to HBM: copy_panel_by_early_waves, behind the next contraction, which reads this panel)
       BNF_MARK(a, 7);
-      if (hc == CH - 1) ring_prefetch(wbl(LL), lane);   // the accumulators are dead: weights of dH = dZ K^T on their way
+      if (hc == CH - 1 && !c8) ring_prefetch(wbl(LL), lane);   // the accumulators are dead: weights of dH = dZ K^T on their way
       // d b_L = 1^T dZ_L over the slab this wave has just written (its own LDS writes: in order behind them)
       float dbs[4];
       colsum(dbs, std::false_type{});
@@ -1500,7 +1669,14 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
             cs[j] += dv2 * s;
             sg[j] += z * tv;
             cp[j] += z;
-            store_pair_pk(tile_i + (8 * rg + q) * kPitchE + lc, tile_i + (8 * rg + q + 1) * kPitchE + lc, z.x, z.y);
+            if constexpr (C8) {      // dZ_L leaves as e5m2 / s_dZ into the fp8 panel image (rows lr + q, lr + q + 1, column lc)
+              const int pk = __builtin_amdgcn_cvt_pk_bf8_f32(z.x * inv_qdz, z.y * inv_qdz, 0, false);
+              char* p8 = smem + (rbase + i * 32 + 4 * kg + 8 * rg + q) * kPitch8 + lc;
+              *reinterpret_cast<uint8_t*>(p8) = (uint8_t)pk;
+              *reinterpret_cast<uint8_t*>(p8 + kPitch8) = (uint8_t)(pk >> 8);
+            } else {
+              store_pair_pk(tile_i + (8 * rg + q) * kPitchE + lc, tile_i + (8 * rg + q + 1) * kPitchE + lc, z.x, z.y);
+            }
           }
         }
         asm volatile("" : "+v"(cr[0]), "+v"(cr[1]), "+v"(sg[0]), "+v"(sg[1]), "+v"(cp[0]), "+v"(cp[1]),
@@ -1510,7 +1686,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
       }
     }
     block_to_global(L, a.dZ[LL], RT - 1, cbase);
-    if (hc == CH - 1) ring_prefetch(wbl(LL), lane);   // the accumulators are dead: weights of dH = dZ K^T on their way
+    if (hc == CH - 1 && !c8) ring_prefetch(wbl(LL), lane);   // the accumulators are dead: weights of dH = dZ K^T on their way
     const float crj[2] = {cr[0].x + cr[0].y, cr[1].x + cr[1].y}, csj[2] = {cs[0].x + cs[0].y, cs[1].x + cs[1].y};
     float wsa = kvn[0] * (2.f * crj[0] + csj[0]) + kvn[1] * (2.f * crj[1] + csj[1]);
     float wsg = (kLn2 / gamma1) * ((sg[0].x + sg[0].y) + (sg[1].x + sg[1].y));
@@ -1535,6 +1711,29 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
       s_sc[33 + wave * 2] = wsg_all;
     }
   }
+  }
+  if constexpr (C8 && kL1T) {
+    // The column-sum MFMAs above read the bf16 dZ_L panel (each wave its own region); the contraction that follows wants
+    // the e5m2 image, whose rows lie elsewhere in the same buffer: one more barrier, then dZ_L = dv dg again (dg is still in
+    // the accumulators), scaled by 1 / s_dZ, one dword per four hidden units.
+    lds_barrier();
+    const LaneCtx L = lane_ctx();
+    const int frow = L.frow, kg = L.kg;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const float dvs = s_dv[rbase + i * 32 + frow] * inv_qdz;
+      char* rowp8 = smem + (rbase + i * 32 + frow) * kPitch8 + slab(0) * 64 + 4 * kg;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const f32x2 z0 = f32x2{accs[0][i][j][rg * 4], accs[0][i][j][rg * 4 + 1]} * dvs;
+          const f32x2 z1 = f32x2{accs[0][i][j][rg * 4 + 2], accs[0][i][j][rg * 4 + 3]} * dvs;
+          int pk = __builtin_amdgcn_cvt_pk_bf8_f32(z0.x, z0.y, 0, false);
+          pk = __builtin_amdgcn_cvt_pk_bf8_f32(z1.x, z1.y, pk, true);
+          *reinterpret_cast<int*>(rowp8 + j * 32 + 8 * rg) = pk;
+        }
+    }
   }
   BNF_MARK(a, 8);
   lds_barrier();
@@ -1664,7 +1863,10 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   // =============================== dH1 = dZ1 K1^T ============================================
   BNF_MARK(a, 9);
   if (!BNF_PANEL_ZPEEL) zero_acc();
-  contract_all_t(wbl(1), std::integral_constant<bool, F0>{});   // (F0: transposed accumulators for the swapped dZ0 epilogue)
+  if constexpr (c8)
+    contract_all8(a.Wb8[1] + (int64_t)e * a.w8_batch, std::integral_constant<bool, F0>{}, std::true_type{});
+  else
+    contract_all_t(wbl(1), std::integral_constant<bool, F0>{});   // (F0: transposed accumulators for the swapped dZ0 epilogue)
   BNF_MARK(a, 10);
   const LaneCtx L2 = lane_ctx(0);
   l0_weights(L2);                         // first operands of the A0 recomputation, in flight across the barrier

@@ -1,9 +1,13 @@
-"""compute_dtype 'fp8' (BASELINE.json configs[4], SURVEY.md 8d's fp8 class): the bf16 row-panel pipeline with FP8 OPERAND
-STORAGE for the weight-gradient contractions -- activations as OCP e4m3, backward signals as OCP e5m2 over a per-member
-power of two, dK_l = H_l^T dZ_l on the non-scaled fp8 MFMA (bnf_gemm8.h).  (1) the three fp8 kernels against the host
-product of the SAME quantised operands (exact up to f32 summation order); (2) the copies the panel kernel leaves against
-its bf16 copies; (3) one step's gradients against the float64 oracle at fp8-class bars; (4) SURVEY 8d's statistical
-gate: final loss within 3 % and predictive RMSE within 5 % of the fp32 run from identical initial parameters."""
+"""compute_dtype 'fp8' (BASELINE.json configs[4], SURVEY.md 8d's fp8 class).  Two layers of it:
+  * FP8 OPERAND STORAGE for the weight-gradient contractions, on every row-panel form -- activations as OCP e4m3, backward
+    signals as OCP e5m2 over a per-member power of two, dK_l = H_l^T dZ_l on the fp8 MFMA (bnf_gemm8.h);
+  * (round 6) the W x W FORWARD and BACKWARD-DATA contractions of the folded two-layer forms (W = 256 / 512: C2, C5) on the
+    block-scaled fp8 MFMA out of fp8 panels in LDS (bnf_panel.h PanelArgs.c8; BNF_FP8_CONTRACT=0 switches it off).
+(1) the three fp8 weight-gradient kernels against the host product of the SAME quantised operands (exact up to f32
+summation order); (2) with the fp8 contractions off: the copies the panel kernel leaves against its bf16 copies, one step's
+gradients against the float64 oracle at fp8-class bars; (3) the fp8 contractions against the bf16 step and the oracle;
+(4) SURVEY 8d's statistical gate: final loss within 3 % and predictive RMSE within 5 % of the fp32 run from identical
+initial parameters -- on the default 'fp8' (contractions included where they apply)."""
 import numpy as np
 import pytest
 import torch
@@ -60,10 +64,11 @@ def test_fp8_weight_gradient_kernels_vs_host_product_of_the_quantised_operands(k
 
 
 @pytest.mark.parametrize('width,depth,n_rows', [(512, 2, 700), (256, 3, 600), (1024, 2, 300)])
-def test_fp8_copies_and_step_gradients(width, depth, n_rows):
-  """The fp8 copies are the bf16 panel values rounded once more (e4m3: 2^-4 relative, e5m2: 2^-3), the scale a power of
+def test_fp8_copies_and_step_gradients(width, depth, n_rows, monkeypatch):
+  """(fp8 contractions off: storage semantics.)  The fp8 copies are the bf16 panel values rounded once more (e4m3: 2^-4 relative, e5m2: 2^-3), the scale a power of
   two that keeps the backward signals in range; loss and every non-kernel leaf are the bf16 pipeline's (same kernel, same
   arithmetic); the Dense kernels' gradients -- the only consumers of the copies -- within 4e-2 of the leaf's max."""
+  monkeypatch.setenv('BNF_FP8_CONTRACT', '0')
   E = 3
   net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth)
   theta = util.random_theta(model, E, scale=0.3)
@@ -95,12 +100,13 @@ def test_fp8_copies_and_step_gradients(width, depth, n_rows):
 
 
 @pytest.mark.parametrize('obs,width,depth,n_rows', [('NB', 256, 2, 700), ('ZINB', 512, 3, 260)])
-def test_fp8_count_models_keep_the_backward_signals_in_range(obs, width, depth, n_rows):
-  """NB / ZINB (models.py:166-191): d out is a count residual (tens, not residual / sigma^2), the e5m2 scale is
+def test_fp8_count_models_keep_the_backward_signals_in_range(obs, width, depth, n_rows, monkeypatch):
+  """(fp8 contractions off: storage semantics.)  NB / ZINB (models.py:166-191): d out is a count residual (tens, not residual / sigma^2), the e5m2 scale is
   2^(round(log2(c gamma_o)) - 6) without a sigma -- the stored backward signals must neither saturate (57344 s) nor flush:
   every dZ copy within e5m2's 2^-3 of the bf16 copy where it matters, every other leaf the bf16 pipeline's, Dense-kernel
   gradients within 6e-2 of the float64 oracle's leaf maximum (NORMAL: 4e-2 -- count residuals are heavy-tailed, a few rows
   carry the sum and the two-mantissa-bit rounding of THEIR signals averages out over fewer terms; measured 4.4e-2)."""
+  monkeypatch.setenv('BNF_FP8_CONTRACT', '0')
   E = 2
   net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth, observation_model=obs)
   theta = util.random_theta(model, E, scale=0.3)
@@ -128,10 +134,11 @@ def test_fp8_count_models_keep_the_backward_signals_in_range(obs, width, depth, 
 
 
 @pytest.mark.parametrize('width,depth,S', [(256, 2, 3), (512, 3, 2)])
-def test_fp8_vi_step_against_the_bf16_panel_step(width, depth, S):
-  """ensemble_vi's step (inference.py:626-764) on fp8 operand storage: one scale per VIRTUAL member (member x Monte-Carlo
+def test_fp8_vi_step_against_the_bf16_panel_step(width, depth, S, monkeypatch):
+  """(fp8 contractions off: storage semantics.)  ensemble_vi's step (inference.py:626-764) on fp8 operand storage: one scale per VIRTUAL member (member x Monte-Carlo
   sample); same seed, same noise -- the loss is the bf16 step's, d mu / d rho of the Dense kernels within the fp8 bar of
   it, every other leaf equal."""
+  monkeypatch.setenv('BNF_FP8_CONTRACT', '0')
   n_rows, E = 300, 2
   net, model, X, y = util.make_problem(n_rows=n_rows, width=width, depth=depth)
   res = {}
@@ -147,6 +154,66 @@ def test_fp8_vi_step_against_the_bf16_panel_step(width, depth, S):
     e8 = util.per_leaf_rel_err(model, res['fp8'][1][k], res['bf16'][1][k])
     bad = {n: v for n, v in e8.items() if v > (8e-2 if n == 'Dense_0/bias' else 4e-2 if n in kernels else 1e-4)}
     assert not bad, (('mu', 'rho')[k], bad)   # (d bias0 = 1^T dZq_0: e5m2 alone, no averaging partner -- as in the MAP test)
+
+
+@pytest.mark.parametrize('case', ['C2-shaped', 'C5-shaped', 'W256-F49', 'NB', 'VI'])
+def test_fp8_forward_and_backward_data_contractions_on_the_fp8_mfma(case, monkeypatch):
+  """Round 6 (BASELINE configs[4] "fp8 MFMA dense layers"): on the folded two-layer forms the W x W forward
+  and backward-data contractions run on v_mfma_scale_f32_32x32x64_f8f6f4 -- H_1 as e4m3 and dZ_L as e5m2 / s_dZ in LDS,
+  weights as e4m3 x 2^5 fragments -- models.py:263-268 and its transpose.  Against the bf16 step of the same kernel family
+  and the float64 oracle: the network output within 2e-2 of its largest value (measured 5.6e-3; rms 2.6e-3; 5e-2 for the VI
+  step, whose sampled initial networks have outputs of a few tenths: measured 3.4e-2), the step loss 1e-3, the H_1 copy
+  still the bf16 panel value rounded once to e4m3, every gradient leaf within 1e-1 of the leaf's max of the oracle's (Dense
+  kernels 5e-2; measured <= 6.4e-2 / 2.9e-2; the SCALAR leaves -- one number each, sums with cancellation like
+  d logit_activation_weight = sum dH (elu - tanh) -- 2e-1: measured 1.2e-1) -- and the result DIFFERS from the copies-only
+  arithmetic (BNF_FP8_CONTRACT=0), i.e. the path under test is the one that ran.  What these per-step errors do to a fit is
+  the next test's business (SURVEY 8d's statistical gate)."""
+  kw = dict(n_rows=700, width=512, depth=2)
+  mode, obs, S = 'map', 'NORMAL', 1
+  if case == 'C5-shaped':      # 69 features -> the 128-feature W = 256 form (C5's)
+    kw = dict(n_rows=900, width=256, depth=2, periods=(7.0, 30.4375, 365.25), harmonics=(3, 10, 10), T=2000, interactions=())
+  elif case == 'W256-F49':
+    kw = dict(n_rows=600, width=256, depth=2)
+  elif case == 'NB':
+    kw, obs = dict(n_rows=700, width=256, depth=2, observation_model='NB'), 'NB'
+  elif case == 'VI':
+    kw, mode, S = dict(n_rows=300, width=512, depth=2), 'vi', 2
+  net, model, X, y = util.make_problem(**kw)
+  E = 2
+  theta = util.random_theta(model, E, scale=0.3)
+  res = {}
+  for name, dt, env in (('c8', 'fp8', '1'), ('copies', 'fp8', '0'), ('bf16', 'bf16', '1')):
+    monkeypatch.setenv('BNF_FP8_CONTRACT', env)
+    if mode == 'vi':
+      eng = _engine(net, X, y, mode='vi', members=E, vi_samples=S, kl_weight=0.2, seed=5, learning_rate=0.01, compute_dtype=dt,
+                    pipeline='panel')
+      eng.init_params(0.0)
+      loss, g = eng.debug_loss_and_grad(0, 0)
+      res[name] = dict(loss=loss, g=g[0], out=eng.debug_activation(200))
+    else:
+      eng = _engine(net, X, y, members=E, compute_dtype=dt, pipeline='panel')
+      eng.set_params(theta)
+      loss, g = eng.debug_loss_and_grad()
+      res[name] = dict(loss=loss, g=g, out=eng.debug_activation(200), H1=eng.debug_activation(1))
+    eng.close()
+  c8, cp, bf = res['c8'], res['copies'], res['bf16']
+  assert np.all(np.isfinite(c8['g'])) and np.all(np.isfinite(c8['out']))
+  assert util.rel_err(c8['out'], bf['out']) < (5e-2 if mode == 'vi' else 2e-2), util.rel_err(c8['out'], bf['out'])
+  assert util.rel_err(c8['out'], cp['out']) > 1e-4                        # the fp8 contraction ran (copies-only: the bf16 output)
+  np.testing.assert_allclose(cp['out'], bf['out'], rtol=0, atol=1e-6 * np.abs(bf['out']).max())
+  np.testing.assert_allclose(c8['loss'], bf['loss'], rtol=1e-3)
+  if mode == 'map':
+    a, b = c8['H1'], bf['H1']
+    assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 2.0 ** -6)) <= 2.0 ** -4 + 1e-6                # e4m3 of the bf16 panel value
+    _, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=kw['n_rows'])
+    eo = util.per_leaf_rel_err(model, c8['g'], g_o)
+    kernels = [f'Dense_{l}/kernel' for l in range(3)]
+    bad = {k: v for k, v in eo.items() if v > (5e-2 if k in kernels else 2e-1 if model.leaf[k].size == 1 else 1e-1)}
+    assert not bad, ('vs oracle', bad)
+  else:
+    e8 = util.per_leaf_rel_err(model, c8['g'], bf['g'])
+    bad = {k: v for k, v in e8.items() if v > (2e-1 if model.leaf[k].size == 1 else 1e-1)}
+    assert not bad, ('d mu vs the bf16 step', bad)
 
 
 @pytest.mark.parametrize('layout', ['C2', 'C5'])
