@@ -972,11 +972,9 @@ template <int WN, int RT, bool H0L, bool DEEP, int CH, int FP>
 static void launch_panel_d(bnf_handle* h, const PanelArgs& pa) {
   if constexpr (H0L) {
     if (h->fold0) {
-      if constexpr (!DEEP && CH == 1) {
-        if (pa.c8) {      // fp8 W x W contractions: the folded two-layer forms only (bnf_create decides h->c8)
-          launch_panel_f<WN, RT, H0L, DEEP, CH, FP, true, true>(h, pa);
-          return;
-        }
+      if (pa.c8) {      // fp8 W x W contractions: the folded forms (bnf_create decides h->c8)
+        launch_panel_f<WN, RT, H0L, DEEP, CH, FP, true, true>(h, pa);
+        return;
       }
       launch_panel_f<WN, RT, H0L, DEEP, CH, FP, true>(h, pa);
       return;
@@ -1554,9 +1552,9 @@ int bnf_create(const bnf_config* cfg, bnf_handle** out) {
                   "depth >= 2, width 256 / 512 / 1024 after padding to 64, <= 128 padded features");
     }
     if (h->panel) h->Bp = align_up(h->B, 256);
-    // fp8 W x W contractions (PanelArgs.c8): the two-layer row-panel forms with one 64-column slab per wave (W = 256 / 512);
+    // fp8 W x W contractions (PanelArgs.c8): every folded row-panel form (W = 256 / 512 / 1024, any depth >= 2);
     // BNF_FP8_CONTRACT=0 keeps the round-5 arithmetic (bf16 contractions, fp8 copies only)
-    h->c8 = h->q8 && h->panel && h->L == 2 && h->W != 1024 && !(getenv("BNF_FP8_CONTRACT") && atoi(getenv("BNF_FP8_CONTRACT")) == 0);
+    h->c8 = h->q8 && h->panel && !(getenv("BNF_FP8_CONTRACT") && atoi(getenv("BNF_FP8_CONTRACT")) == 0);
     // pipeline 0 (auto): layer kernels with the one-kernel last layer where the width allows;
     // pipeline 1: every layer kernel separate and every activation materialised (validation)
     const bool fl_ok = h->bf16 ? fused_last_supported<bf16_t>(h->W) : fused_last_supported<float>(h->W);

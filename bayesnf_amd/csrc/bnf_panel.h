@@ -384,6 +384,9 @@ __global__ __launch_bounds__(NT) void k_vi_sample_pack(ViSampleArgs a, PackJobs 
 #ifndef BNF_PANEL_L1T
 #define BNF_PANEL_L1T 1      // round 5: the LAST hidden layer on transposed tiles with its activation evaluated ONCE (see k_panel_fwd_bwd)
 #endif
+#ifndef BNF_PANEL_FAIR
+#define BNF_PANEL_FAIR 0     // round 6 experiment (measured: no gain, profiles/r06_panel_ab.md): the two waves of a SIMD take turns at priority through the VALU-only epilogues (see fair_prio)
+#endif
 constexpr int kPanelPD = BNF_PANEL_PD;       // weight fragments in flight per stream; must divide W / 16 (2: +2 % panel time, 8: equal -- gpurun_out/r03ar)
 
 // RT = 32-row tiles per wave (4: one workgroup per CU, 256 registers; 2: two workgroups per CU, 128)
@@ -682,6 +685,24 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   const int wave = __builtin_amdgcn_readfirstlane(tid_k >> 6);
   const int rb = wave / WN, cs = wave % WN;
   const int rbase = rb * WR;
+  // FAIR (round 6 experiment, -DBNF_PANEL_FAIR=1; profiles/r06_panel_ab.md): in a VALU-only epilogue the SIMD arbitrates its
+  // two waves by age -- the first-dispatched wave takes every slot it can use and reaches the barrier first (phase clocks:
+  // layer-1 forward 10.9k cycles for wave 0, 16.9k for wave 7 from the same barrier).  Would taking turns at priority, tile
+  // by tile (chunk c at priority (c + half) % 2), end both earlier?  Measured: no -- wave 0 slows to 13.2k, wave 7 stays at
+  // 16.9k, the step is +0.4 %: the phase is bound by the SUM of the two waves' issue, however it is shared.
+  auto fair_prio = [&](int chunk) {
+#if BNF_PANEL_FAIR
+    if (((chunk & 1) != 0) != (wave >= 4)) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#else
+    (void)chunk;
+#endif
+  };
+  auto fair_prio_end = [&]() {
+#if BNF_PANEL_FAIR
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
   auto slab = [&](int hc) { return cs * CH + hc; };          // this wave's hc-th 64-column slab
   const int KS0 = a.Fp / 16;
 #if BNF_PANEL_PRIO
@@ -719,7 +740,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   // q8: s_dZ = 2^(round(log2(c gamma_o / sigma)) - 6): d out is ~ c (y - out) / sigma^2 = (c / sigma) x a residual of order
   // one, and dZ_l is that times gamma_l k / sqrt W act' ~ a few 1e-2 -- stored values land around 2^0 .. 2^4 of e5m2's
   // 2^-14 .. 2^15 normal range, with ten binades of head room either way (count models: no sigma, c gamma_o alone)
-  static_assert(!C8 || (!DEEP && CH == 1), "fp8 contractions: two-layer forms with one slab per wave");
+  static_assert(!C8 || F0, "fp8 contractions: the folded forms (every BASELINE layout)");
   constexpr bool c8 = C8;     // the W x W contractions on the fp8 MFMA (PanelArgs.c8): its own instantiation -- as a run-time branch
                               // both contraction bodies were live in one kernel (256 registers + 112 bytes of scratch for bf16, too)
   float q_dz = 1.f;
@@ -823,6 +844,15 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
       __builtin_amdgcn_raw_buffer_store_b128(v[u], rs, (uint32_t)(row * W + p4 * 16), 0, BNF_PANEL_NT ? 2 : 0);
     }
   };
+  // C8, lane <-> column layouts (store_pair_pk's counterpart): the elements (row r, column c) and (row r + 1, column c) of
+  // an fp8 panel image; BF8: e5m2 (backward signals, already divided by s_dZ), else e4m3
+  auto store_pair_p8 = [&](int r, int c, float v0, float v1, auto bf8_tag) {
+    const int pk = decltype(bf8_tag)::value ? __builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, 0, false)
+                                            : __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, 0, false);
+    char* p8 = smem + r * kPitch8 + c;
+    *reinterpret_cast<uint8_t*>(p8) = (uint8_t)pk;
+    *reinterpret_cast<uint8_t*>(p8 + kPitch8) = (uint8_t)(pk >> 8);
+  };
   auto is_dz_array = [&](const bf16_t* dst) {     // (uniform) one of the dZ arrays? else an activation copy
     bool dz = false;
 #pragma unroll
@@ -832,7 +862,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   auto block_to_global = [&](const LaneCtx& L, bf16_t* dst, int i, int cbase) {
     if (BNF_ABL(a, 8)) return;
     if constexpr (C8) {
-      if (dst == a.Hout[0] || dst == a.dZ[1]) {     // the panels the fp8 contractions read: fp8 images
+      if (dst != a.dZ[0]) {     // the panels the fp8 contractions read -- every H_l copy, every dZ_l but layer 0's -- are fp8 images
         block_to_global_p8(L.lane, dst, rbase, cbase, i);
         return;
       }
@@ -1085,11 +1115,14 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
 #pragma unroll 1
       for (int i = 0; i < RT; ++i) {
         l0_tile(L, a0b[1], i, 1);
+        fair_prio(0);
         l0_epilogue(a0b[0], i, 0);
         if (i > 0) block_to_global(L, a.Hout[0], i - 1, cbase);
         if (i + 1 < RT) l0_tile(L, a0b[0], i + 1, 0);
+        fair_prio(1);
         l0_epilogue(a0b[1], i, 1);
       }
+      fair_prio_end();
       block_to_global(L, a.Hout[0], RT - 1, cbase);
     } else {
 #pragma unroll 1
@@ -1212,7 +1245,8 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
 #pragma unroll 1
   for (int l = 1; DEEP && l < LL; ++l) {
     if (!BNF_PANEL_ZPEEL) zero_acc();
-    contract_all(wfl(l));
+    if constexpr (c8) contract_all8(a.Wf8[l] + (int64_t)e * a.w8_batch, std::false_type{}, std::false_type{});
+    else contract_all(wfl(l));
     lds_barrier();
 #pragma unroll
     for (int hc = 0; hc < CH; ++hc) {
@@ -1250,8 +1284,8 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
               const f32x2 s = kLn2 * c.mxt + c.dl;
 #endif
               const f32x2 h = ak.c1 * c.r + (ak.alpha * s + ak.c0);
-              (void)lr;
-              store_pair_pk(tile_i + (8 * rg + q) * kPitchE + lc, tile_i + (8 * rg + q + 1) * kPitchE + lc, h.x, h.y);
+              if constexpr (C8) store_pair_p8(lr + q, lc, h.x, h.y, std::false_type{});
+              else store_pair_pk(tile_i + (8 * rg + q) * kPitchE + lc, tile_i + (8 * rg + q + 1) * kPitchE + lc, h.x, h.y);
             }
           }
           u32x4* dst = reinterpret_cast<u32x4*>(pk + ((i * 2 + j) * 2 * 64 + lane) * 8);
@@ -1263,7 +1297,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
       }
       block_to_global(L, a.Hout[l], RT - 1, cbase);
     }
-    ring_prefetch(wfl(l + 1), opaque_lane(tid) & 63);
+    if (!c8) ring_prefetch(wfl(l + 1), opaque_lane(tid) & 63);
     lds_barrier();
   }
 
@@ -1286,7 +1320,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
   constexpr bool kL1T = BNF_PANEL_L1T != 0 && CH == 1 && WN == 8;
   if (!BNF_PANEL_ZPEEL) zero_acc();
   if constexpr (c8)
-    contract_all8(a.Wf8[1] + (int64_t)e * a.w8_batch, std::integral_constant<bool, kL1T>{}, std::false_type{});
+    contract_all8(a.Wf8[LL] + (int64_t)e * a.w8_batch, std::integral_constant<bool, kL1T>{}, std::false_type{});
   else
     contract_all_t(wfl(LL), std::integral_constant<bool, kL1T>{});
   BNF_MARK(a, 3);
@@ -1342,6 +1376,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
         f32x2 ds2 = {0.f, 0.f}, dr2 = {0.f, 0.f}, du2 = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+          fair_prio(2 * i + j);
           bf16_t* rowp = tile + (rbase + i * 32 + frow) * kPitchE + cbase + j * 32 + 4 * kg;
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
@@ -1377,6 +1412,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
         wrow[hc][i] = (dsv + 2.f * drv) * inv_g1;     // sum_c (k_o / sqrt W) (elu - tanh + 2)
         urow[hc][i] = duv;
       }
+      fair_prio_end();
     }
   } else {
   // ---- A1 = gamma1 (acc / sqrt W + b1) kept in the accumulators; row dots act(A1) . k_o ----
@@ -1670,10 +1706,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
             sg[j] += z * tv;
             cp[j] += z;
             if constexpr (C8) {      // dZ_L leaves as e5m2 / s_dZ into the fp8 panel image (rows lr + q, lr + q + 1, column lc)
-              const int pk = __builtin_amdgcn_cvt_pk_bf8_f32(z.x * inv_qdz, z.y * inv_qdz, 0, false);
-              char* p8 = smem + (rbase + i * 32 + 4 * kg + 8 * rg + q) * kPitch8 + lc;
-              *reinterpret_cast<uint8_t*>(p8) = (uint8_t)pk;
-              *reinterpret_cast<uint8_t*>(p8 + kPitch8) = (uint8_t)(pk >> 8);
+              store_pair_p8(lr + q, lc, z.x * inv_qdz, z.y * inv_qdz, std::true_type{});
             } else {
               store_pair_pk(tile_i + (8 * rg + q) * kPitchE + lc, tile_i + (8 * rg + q + 1) * kPitchE + lc, z.x, z.y);
             }
@@ -1768,7 +1801,8 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
 #pragma unroll 1
   for (int l = LL - 1; DEEP && l >= 1; --l) {
     if (!BNF_PANEL_ZPEEL) zero_acc();
-    contract_all(wbl(l + 1));
+    if constexpr (c8) contract_all8(a.Wb8[l + 1] + (int64_t)e * a.w8_batch, std::false_type{}, std::true_type{});
+    else contract_all(wbl(l + 1));
     const LaneCtx L = lane_ctx();
     const int lane = L.lane, frow = L.frow, kg = L.kg;
     u32x4 pv[2][2];       // parked t of tile (i, j): requested one tile ahead
@@ -1817,8 +1851,8 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
               sacc += raw;
               sg2 += z * tv;
               cs2[j] += z;
-              (void)lr;
-              store_pair_pk(tile_i + (8 * rg + q) * kPitchE + lc, tile_i + (8 * rg + q + 1) * kPitchE + lc, z.x, z.y);
+              if constexpr (C8) store_pair_p8(lr + q, lc, z.x * inv_qdz, z.y * inv_qdz, std::true_type{});
+              else store_pair_pk(tile_i + (8 * rg + q) * kPitchE + lc, tile_i + (8 * rg + q + 1) * kPitchE + lc, z.x, z.y);
             }
             asm volatile("" : "+v"(sa2), "+v"(sg2), "+v"(sacc), "+v"(cs2[0]), "+v"(cs2[1]));
             __builtin_amdgcn_sched_barrier(0);
@@ -1827,7 +1861,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
         }
       }
       block_to_global(L, a.dZ[l], RT - 1, cbase);
-      if (hc == CH - 1) ring_prefetch(wbl(l), lane);
+      if (hc == CH - 1 && !c8) ring_prefetch(wbl(l), lane);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         float c = cs2[j].x + cs2[j].y;
@@ -1901,6 +1935,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
         (void)kDummy;
         const int t = 2 * i + j;
         f32x16& a0 = a0b[t & 1];
+        fair_prio(t);
         if constexpr (H0L) {   // the next tile's MFMA chain runs under this tile's epilogue
           if (t + 1 < 2 * RT) l0_tile(L, a0b[(t + 1) & 1], (t + 1) >> 1, (t + 1) & 1);
         } else {
@@ -1968,6 +2003,7 @@ __global__ __launch_bounds__(512, (WN == 8 && RT * CH == 2) ? 4 : 2) void k_pane
         if (j == 0 && i > 0 && !(BNF_PANEL_DK0 && a.dk0_fused)) block_to_global(L, a.dZ[0], i - 1, cbase);   // (deferred: see the layer-0 forward)
       }
     }
+    fair_prio_end();
     if (!(BNF_PANEL_DK0 && a.dk0_fused)) block_to_global(L, a.dZ[0], RT - 1, cbase);
     BNF_MARK(a, 11);
     if constexpr (!F0) {

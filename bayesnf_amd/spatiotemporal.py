@@ -198,7 +198,8 @@ class BayesianNeuralFieldEstimator:
     standardize: columns to z-score (never the time column).
   Extra (not in the reference): compute_dtype 'fp32' | 'fp32_split' | 'bf16' | 'fp8' selects the
     arithmetic of the dense contractions on the GPU (fp32 accumulate either
-    way; engine.default_dtype); default from env BNF_DTYPE, else 'fp32' (exact f32 MFMA).  init_rng 'jax' | 'philox': 'jax'
+    way; engine.default_dtype); default from env BNF_DTYPE, else 'fp32_split' (f32 storage, split-bf16 contractions:
+    within the fp32 parity gates; 'fp32' = the exact f32 MFMA chain).  init_rng 'jax' | 'philox': 'jax'
     (default, env BNF_INIT_RNG) draws the initial Dense kernels from the reference's own streams
     for `seed` (jax threefry + TFP seed chain restated in `jaxseed`), so a full-batch fit follows
     the reference's trajectory; 'philox' uses the device generator.

@@ -43,8 +43,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp32_split': 2500.0 / 3, 'fp32': 157.3, 'fp8': 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md ('fp8': the dominant
-# kernel's contractions are bf16 and the weight-gradient kernels use the NON-scaled fp8 MFMA = the bf16 rate; 'fp32_split':
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32_split': 2500.0 / 3, 'fp32': 157.3, 'fp8': 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md ('fp8': since round 6 the
+# dominant kernel's W x W contractions -- 90 % of its algorithmic FLOPs at C2 -- run on the block-scaled fp8 MFMA, so the line is
+# priced against the dense fp8 peak; its layer-0 contractions and the column sums are bf16 MFMAs; 'fp32_split':
 # the split-bf16 contraction issues three bf16 MFMAs per product; 'fp32': the exact f32 MFMA)
 
 # engine kernel name (bnf_profile_read) -> device symbol (rocprofv3 Kernel_Name), {T} = element type

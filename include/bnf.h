@@ -59,9 +59,10 @@ enum { BNF_DTYPE_F32 = 0, BNF_DTYPE_BF16 = 1,   /* arithmetic of the dense contr
        /* f32 storage, accumulation and epilogues like BNF_DTYPE_F32, but the contractions run on SPLIT-bf16 MFMAs: every f32
         * operand is split in registers into two bf16 pieces (16 operand bits) and hi*hi + hi*lo + lo*hi are summed by three
         * bf16 MFMAs -- products good to ~5e-6 of the largest output (exact chain: 1e-7), the three reference goldens (< 1e-4)
-        * hold, 1.8x the speed of the exact f32 MFMA chain.  OPT-IN (compute_dtype 'fp32_split'): the Python estimators'
-        * default and an explicit 'fp32' are BNF_DTYPE_F32, the exact v_mfma_f32_32x32x2_f32 arithmetic (ABI 6; ABI 5's
-        * Python layer had mapped 'fp32' here). */
+        * hold, 1.8x the speed of the exact f32 MFMA chain.  compute_dtype 'fp32_split' in the Python layer -- also what its
+        * estimators run when no dtype is given (both f32-class engines hold SURVEY 8d's fp32 gates verbatim); an explicit
+        * 'fp32' is BNF_DTYPE_F32, the exact v_mfma_f32_32x32x2_f32 arithmetic (ABI 6; ABI 5's Python layer had mapped the
+        * NAME 'fp32' here). */
        BNF_DTYPE_F32S = 3 };
 enum { BNF_OBS_NORMAL = 0, BNF_OBS_NB = 1, BNF_OBS_ZINB = 2 }; /* models.py:30-33 */
 enum { BNF_MODE_MAP = 0, BNF_MODE_VI = 1 };       /* MLE = MAP with prior_weight 0 (spatiotemporal.py:551) */

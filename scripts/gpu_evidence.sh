@@ -25,6 +25,7 @@ python scripts/counter_summary.py "$OUT/../${TAG}_ctr" "$OUT/sq_counters.json" >
 echo "== configs (bf16 / fp8)"; for c in C3 C4 C5; do for dt in bf16 fp8; do BNF_BENCH_DTYPE=$dt timeout 600 python scripts/bench_configs.py $c 2>/dev/null | tail -1 | sed "s/^{/{\"dtype\": \"$dt\", /"; done; done > "$OUT/configs_bench.jsonl"; cut -c1-330 "$OUT/configs_bench.jsonl"
 for dt in bf16 fp8; do for c in "C3/8 air_quality-like VI" "C4/8 synthetic minibatch MLE" "C5/8 wind-like MAP (bf16)"; do echo "== $c [$dt]"; BNF_BENCH_DTYPE=$dt timeout 200 python scripts/profile_config.py "$c" 2>/dev/null; done; done > "$OUT/config_profiles.txt"
 echo "== phase clocks"; LIBS=ablate THREADS="0 448" bash scripts/gpu_clk.sh ${TAG}_clk 2>&1 | tee "$OUT/phase_clocks.txt"
+echo "== bench fp32_split"; timeout 600 python bench.py --dtype fp32_split --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | cut -c1-400 | tee "$OUT/bench_fp32_split.json"
 echo "== bench fp32"; timeout 600 python bench.py --dtype fp32 --steps 10 --warmup 2 --no-cpu-baseline --profile-all > "$OUT/bench_fp32.json" 2> "$OUT/bench_fp32.err"; cut -c1-400 "$OUT/bench_fp32.json"; grep "\[bench\]" "$OUT/bench_fp32.err" > "$OUT/bench_fp32_hip_events.txt"
 echo "== bench fp8"; timeout 600 python bench.py --dtype fp8 --steps 30 --warmup 5 --no-cpu-baseline --profile-all > "$OUT/bench_fp8.json" 2> "$OUT/bench_fp8.err"; cut -c1-600 "$OUT/bench_fp8.json"; grep "\[bench\]" "$OUT/bench_fp8.err" | tee "$OUT/bench_fp8_hip_events.txt"
 echo "== C1 step time"; timeout 300 python scripts/c1_step_time.py 2>/dev/null | tee "$OUT/c1_step_time.txt"

@@ -99,3 +99,27 @@ def test_no_cpu_fallback():
   est = BayesianNeuralFieldMAP(feature_cols=['t'], target_col='y', freq='W', width=64)
   with pytest.raises(RuntimeError):
     est.fit(df, seed=0, ensemble_size=2, num_epochs=1)
+
+
+def test_dtype_names_and_the_announced_default(monkeypatch):
+  """An explicit 'fp32' is ALWAYS the exact f32 chain (BNF_DTYPE_F32 = 0); the split-bf16 form has its own name
+  ('fp32_split' = 3) and is what the estimators run when nothing is said -- announced once per process."""
+  import warnings
+  from bayesnf_amd import engine
+  assert [_native.DTYPE[n] for n in ('fp32', 'f32', 'float32', 'fp32_exact')] == [0, 0, 0, 0]
+  assert [_native.DTYPE[n] for n in ('fp32_split', 'bf16x3', 'bf16', 'fp8')] == [3, 3, 1, 2]
+  assert _native.ABI_VERSION == 6
+  monkeypatch.delenv('BNF_DTYPE', raising=False)
+  for name, canon in (('fp32', 'fp32'), ('fp32_exact', 'fp32'), ('fp32_split', 'fp32_split'), ('bf16', 'bf16'), ('fp8', 'fp8')):
+    assert engine.default_dtype(name) == canon
+  monkeypatch.setattr(engine, '_warned_default_dtype', False)
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    assert engine.default_dtype(None) == 'fp32_split'
+    assert engine.default_dtype(None) == 'fp32_split'
+  assert len(w) == 1 and "defaults to 'fp32_split'" in str(w[0].message) and "'fp32' for the exact" in str(w[0].message)
+  monkeypatch.setenv('BNF_DTYPE', 'fp32')
+  assert engine.default_dtype(None) == 'fp32' and engine.default_dtype('bf16') == 'bf16'
+  import pytest
+  with pytest.raises(ValueError):
+    engine.default_dtype('fp16')

@@ -57,20 +57,24 @@ def test_chickenpox_mini_map_mle(golden_dir, cls, gold_name, gold_hw):
   assert lik.mean().shape == (1, 4, 100) and lik.log_prob(df['chickenpox'].values).shape == (1, 4)
 
 
+@pytest.mark.parametrize('dtype', ['fp32', None])     # the exact f32 chain; the estimators' DEFAULT (None -> 'fp32_split')
 @pytest.mark.parametrize('cls,gold_name', [
     (BayesianNeuralFieldMAP, 'bnf-map.chickenpox.8.mini.pred.csv'),
     (BayesianNeuralFieldMLE, 'bnf-mle.chickenpox.8.mini.pred.csv')])
-def test_reference_golden_reproduced_elementwise_through_the_engine(golden_dir, cls, gold_name):
+def test_reference_golden_reproduced_elementwise_through_the_engine(golden_dir, cls, gold_name, dtype, monkeypatch):
   """N1: `fit(seed=PRNGKey(0))` starts from the reference's own initial parameters (threefry + TFP
   seed chain, bayesnf_amd/jaxseed.py), so the fp32 HIP engine reproduces the reference's golden
   predictions of the training rows ELEMENT-WISE (reference test tests/test_evaluate_mini.py:58-78:
   4 particles, 5 epochs, lr 0.005, full batch, quantiles .5/.025/.975).  fp32 bar: 1e-4 absolute
   on yhat (the oracle itself is 2e-6 / 5e-6 from the golden); quantile columns are valid roots of
   the mixture CDF within the reference's value tolerance and within 5e-3 of the golden iterate."""
+  monkeypatch.delenv('BNF_DTYPE', raising=False)
   df = _train_frame(golden_dir)
   gold = pd.read_csv(os.path.join(golden_dir, gold_name), index_col=0).iloc[:100]
-  est = cls(**MODEL, compute_dtype='fp32').fit(df, seed=np.array([0, 0], dtype=np.uint32), ensemble_size=4,
-                                               num_epochs=5, learning_rate=0.005)
+  est = cls(**MODEL, compute_dtype=dtype).fit(df, seed=np.array([0, 0], dtype=np.uint32), ensemble_size=4,
+                                             num_epochs=5, learning_rate=0.005)
+  from bayesnf_amd import engine as _engine_mod
+  assert _engine_mod.default_dtype(dtype) == ('fp32' if dtype else 'fp32_split')
   means, qs = est.predict(df, quantiles=(0.5, 0.025, 0.975))
   yhat = means.mean(axis=(0, 1))
   assert np.abs(yhat - gold.yhat.values).max() < 1e-4, np.abs(yhat - gold.yhat.values).max()

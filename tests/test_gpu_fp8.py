@@ -156,16 +156,18 @@ def test_fp8_vi_step_against_the_bf16_panel_step(width, depth, S, monkeypatch):
     assert not bad, (('mu', 'rho')[k], bad)   # (d bias0 = 1^T dZq_0: e5m2 alone, no averaging partner -- as in the MAP test)
 
 
-@pytest.mark.parametrize('case', ['C2-shaped', 'C5-shaped', 'W256-F49', 'NB', 'VI'])
+@pytest.mark.parametrize('case', ['C2-shaped', 'C5-shaped', 'W256-F49', 'NB', 'VI', 'depth3-W256', 'depth4-W512', 'W1024', 'VI-depth4'])
 def test_fp8_forward_and_backward_data_contractions_on_the_fp8_mfma(case, monkeypatch):
-  """Round 6 (BASELINE configs[4] "fp8 MFMA dense layers"): on the folded two-layer forms the W x W forward
-  and backward-data contractions run on v_mfma_scale_f32_32x32x64_f8f6f4 -- H_1 as e4m3 and dZ_L as e5m2 / s_dZ in LDS,
-  weights as e4m3 x 2^5 fragments -- models.py:263-268 and its transpose.  Against the bf16 step of the same kernel family
-  and the float64 oracle: the network output within 2e-2 of its largest value (measured 5.6e-3; rms 2.6e-3; 5e-2 for the VI
-  step, whose sampled initial networks have outputs of a few tenths: measured 3.4e-2), the step loss 1e-3, the H_1 copy
-  still the bf16 panel value rounded once to e4m3, every gradient leaf within 1e-1 of the leaf's max of the oracle's (Dense
-  kernels 5e-2; measured <= 6.4e-2 / 2.9e-2; the SCALAR leaves -- one number each, sums with cancellation like
-  d logit_activation_weight = sum dH (elu - tanh) -- 2e-1: measured 1.2e-1) -- and the result DIFFERS from the copies-only
+  """Round 6 (BASELINE configs[4] "fp8 MFMA dense layers"): on the folded row-panel forms (any depth >= 2,
+  W = 256 / 512 / 1024) every W x W forward and backward-data contraction runs on v_mfma_scale_f32_32x32x64_f8f6f4 -- H_l
+  as e4m3 and dZ_l as e5m2 / s_dZ in LDS, weights as e4m3 x 2^5 fragments -- models.py:263-268 and its transpose.  Against the bf16 step of the same kernel family
+  and the float64 oracle, bars PER HIDDEN LAYER (depth D: every further layer passes the e4m3 rounding of its input through
+  one more contraction): the network output within 1e-2 D of its largest value (measured at D = 2: 5.6e-3, rms 2.6e-3; the
+  VI step, whose sampled initial networks have outputs of a few tenths: 2.5e-2 D, measured 3.4e-2 at D = 2 and 5.8e-2 at
+  D = 4), the step loss 1e-3, the H_1 copy still the bf16 panel value rounded once to e4m3, every gradient leaf within
+  5e-2 D of the leaf's max of the oracle's (Dense kernels 2.5e-2 D; measured <= 6.4e-2 / 2.9e-2 at D = 2; the SCALAR
+  leaves -- one number each, sums with cancellation like d logit_activation_weight = sum dH (elu - tanh) -- 1e-1 D:
+  measured 1.2e-1 at D = 2, 2.1e-1 at D = 3) -- and the result DIFFERS from the copies-only
   arithmetic (BNF_FP8_CONTRACT=0), i.e. the path under test is the one that ran.  What these per-step errors do to a fit is
   the next test's business (SURVEY 8d's statistical gate)."""
   kw = dict(n_rows=700, width=512, depth=2)
@@ -178,6 +180,14 @@ def test_fp8_forward_and_backward_data_contractions_on_the_fp8_mfma(case, monkey
     kw, obs = dict(n_rows=700, width=256, depth=2, observation_model='NB'), 'NB'
   elif case == 'VI':
     kw, mode, S = dict(n_rows=300, width=512, depth=2), 'vi', 2
+  elif case == 'depth3-W256':      # the middle layers' contractions and epilogues (H_2 as e4m3, dZ_1 as e5m2 by byte pairs)
+    kw = dict(n_rows=600, width=256, depth=3)
+  elif case == 'depth4-W512':      # C3's network
+    kw = dict(n_rows=300, width=512, depth=4)
+  elif case == 'W1024':            # two 64-column slabs per wave, 64-row panels (C4's width)
+    kw = dict(n_rows=300, width=1024, depth=2)
+  elif case == 'VI-depth4':
+    kw, mode, S = dict(n_rows=200, width=512, depth=4), 'vi', 2
   net, model, X, y = util.make_problem(**kw)
   E = 2
   theta = util.random_theta(model, E, scale=0.3)
@@ -198,7 +208,8 @@ def test_fp8_forward_and_backward_data_contractions_on_the_fp8_mfma(case, monkey
     eng.close()
   c8, cp, bf = res['c8'], res['copies'], res['bf16']
   assert np.all(np.isfinite(c8['g'])) and np.all(np.isfinite(c8['out']))
-  assert util.rel_err(c8['out'], bf['out']) < (5e-2 if mode == 'vi' else 2e-2), util.rel_err(c8['out'], bf['out'])
+  D = kw['depth']      # every further hidden layer passes the e4m3 rounding of its input through one more contraction: bars per layer
+  assert util.rel_err(c8['out'], bf['out']) < (2.5e-2 if mode == 'vi' else 1e-2) * D, util.rel_err(c8['out'], bf['out'])
   assert util.rel_err(c8['out'], cp['out']) > 1e-4                        # the fp8 contraction ran (copies-only: the bf16 output)
   np.testing.assert_allclose(cp['out'], bf['out'], rtol=0, atol=1e-6 * np.abs(bf['out']).max())
   np.testing.assert_allclose(c8['loss'], bf['loss'], rtol=1e-3)
@@ -207,26 +218,38 @@ def test_fp8_forward_and_backward_data_contractions_on_the_fp8_mfma(case, monkey
     assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 2.0 ** -6)) <= 2.0 ** -4 + 1e-6                # e4m3 of the bf16 panel value
     _, g_o = O.map_loss_and_grad(model, theta, X, y, n_total=kw['n_rows'])
     eo = util.per_leaf_rel_err(model, c8['g'], g_o)
-    kernels = [f'Dense_{l}/kernel' for l in range(3)]
-    bad = {k: v for k, v in eo.items() if v > (5e-2 if k in kernels else 2e-1 if model.leaf[k].size == 1 else 1e-1)}
+    kernels = [f'Dense_{l}/kernel' for l in range(kw['depth'] + 1)]
+    bad = {k: v for k, v in eo.items() if v > (2.5e-2 if k in kernels else 1e-1 if model.leaf[k].size == 1 else 5e-2) * D}
     assert not bad, ('vs oracle', bad)
   else:
     e8 = util.per_leaf_rel_err(model, c8['g'], bf['g'])
-    bad = {k: v for k, v in e8.items() if v > (2e-1 if model.leaf[k].size == 1 else 1e-1)}
+    bad = {k: v for k, v in e8.items() if v > (1e-1 if model.leaf[k].size == 1 else 5e-2) * D}
     assert not bad, ('d mu vs the bf16 step', bad)
 
 
-@pytest.mark.parametrize('layout', ['C2', 'C5'])
-def test_fp8_training_within_survey_8d_statistical_bars_of_fp32(layout):
+@pytest.mark.parametrize('layout,steps', [('C2', 150), ('C5', 150), ('C5', 600), ('C3', 600), ('C4', 600)])
+def test_fp8_training_within_survey_8d_statistical_bars_of_fp32(layout, steps):
   """SURVEY.md 8d, fp8 class: from identical initial parameters, final loss within 3 % and RMSE of the ensemble-mean
-  prediction within 5 % of the fp32 run (C2's and C5's feature layouts and widths at a size the suite can afford)."""
+  prediction within 5 % of the fp32 run (C2's and C5's feature layouts and widths at a size the suite can afford), on the
+  default 'fp8' -- fp8 W x W contractions included.  Measured over three seeds (scripts/fp8_gate_probe.py,
+  profiles/r06_fp8_gate_probe.txt): C2 layout RMSE within 0.1 % at 150 and at 600 steps; C5 layout +0.1 .. +0.7 % at 600
+  steps (the fit has converged: RMSE 0.45), and +3.8 / +4.2 / +6.3 % at 150 steps, where the RMSE is still falling from
+  1.6 and a fixed step count reads the trajectory's small lag (fp8 operand storage alone: +1.5 / +1.7 / +2.9 %, bf16 +0.4
+  .. +1.5 %) -- the seed of this test is the first of the three; the one that exceeds 5 % mid-descent is within 0.2 % at
+  the end.  The deep / wide networks (MAP fits on C3's depth-4 W = 512 and C4's depth-4 W = 1024 networks) at 600 steps:
+  fp8 -1.1 / -2.0 % and -1.5 / +1.0 %, the bf16 engine -3.8 / -2.0 % and -1.2 / -0.4 % (two seeds each): four-layer fits amplify
+  any perturbation by a few per cent either way -- mid-descent (150 steps) one C3 seed reads -7.9 %, i.e. AHEAD of fp32."""
   if layout == 'C2':
     kw = dict(n_rows=4000, width=512, depth=2, periods=(4.0, 52.1775), harmonics=(2, 10), T=522)
-  else:
+  elif layout == 'C5':
     kw = dict(n_rows=6000, width=256, depth=2, periods=(7.0, 30.4375, 365.25), harmonics=(3, 10, 10), T=2000,
               interactions=())
+  elif layout == 'C3':
+    kw = dict(n_rows=3500, width=512, depth=4, periods=(24.0, 168.0), harmonics=(4, 4), T=2160, interactions=())
+  else:
+    kw = dict(n_rows=2048, width=1024, depth=4, periods=(7.0, 365.25), harmonics=(3, 10), T=10000, interactions=())
   net, model, X, y = util.make_problem(**kw)
-  E, steps = 8, 150
+  E = 8
   out = {}
   for dt in ('fp32', 'fp8', 'bf16'):
     eng = _engine(net, X, y, members=E, seed=3, learning_rate=0.005, compute_dtype=dt)
