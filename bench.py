@@ -554,6 +554,37 @@ def run_rank(args, rank, device, E, data, sync):
               device=str(device))
 
 
+def side_dtype_lines(args, device, E, X, y, input_scales, flops_step):
+  """After the timed region, N = 1 only: the same C2 step under the engine's other arithmetics, short runs (3 warm-up + 10
+  timed steps each, a fresh engine, the device already warm) -- reported beside the headline, never as it: 'fp8' (BASELINE
+  configs[4]'s arithmetic: fp8 MFMA contractions + fp8 operand storage) and 'fp32_split' (what the estimators run when no
+  compute_dtype is given)."""
+  import torch
+  from bayesnf_amd.engine import Engine
+  from bayesnf_amd.spec import NetSpec
+  net = NetSpec(input_scales=input_scales, **MODEL_KW)
+  out = {}
+  for dt in ('fp8', 'fp32_split'):
+    if dt == args.dtype:
+      continue
+    try:
+      eng = Engine(net, mode='map', X=X, y=y, members=E, seed=0, learning_rate=0.005, prior_weight=1.0, compute_dtype=dt,
+                   device_index=device.index)
+      eng.init_params(float(np.log(np.nanstd(y) / 2)))
+      eng.train(0, 3)
+      torch.cuda.synchronize(device)
+      t0 = time.perf_counter()
+      eng.train(3, 10)
+      torch.cuda.synchronize(device)
+      dt_s = time.perf_counter() - t0
+      eng.close()
+      out[dt] = {'ms_per_step': dt_s * 1e3 / 10, 'member_steps_per_s': E * 10 / dt_s, 'steps': 10,
+                 'algorithmic_tflops': flops_step * 10 / dt_s / 1e12}
+    except Exception as exc:   # pylint: disable=broad-except
+      out[dt] = {'error': f'{type(exc).__name__}: {exc}'[:200]}
+  return out
+
+
 def predictive_means(args, r, device, E, X):
   """this rank's members on the first 1024 training rows (forward-only handle): what the posterior gather carries"""
   import torch
@@ -786,6 +817,7 @@ def main(argv=None):
                           'flops_per_launch': d['flops'],
                           'issue_floors': issue_floors(ctr, d['avg_ms'] * 1e3), 'issue_floors_source': ctr_src}
       if world == 1 and not args.no_cpu_baseline:
+        line['other_dtypes'] = side_dtype_lines(args, device, E, X, y, input_scales, flops_step)
         line['cpu_baseline'] = cpu_baseline(X, y, input_scales)
     print(json.dumps(line), flush=True)
   for r in results:
