@@ -58,7 +58,8 @@ def fit_map(features, target, seed, observation_model, model_args, num_particles
   `jaxseed`) and, for minibatch fits, shuffles every epoch with the reference's own per-member
   `jax.random.permutation` stream (`jaxseed.map_shuffle_subkeys` -> `bnf_row_keys`: drawn on the device): same seed => the same
   initial particles and shuffles as the reference (pinned by its goldens for full-batch fits; the shuffle chain rests on
-  the reference's source + the pinned split / bits restatements -- no golden exercises a minibatch fit).  'philox' draws the initial parameters from the device generator
+  the reference's source + the pinned split / bits restatements -- no golden exercises a minibatch fit, and no end-to-end
+  known-answer vector of `jax.random.permutation` is held: DESIGN.md section 5).  'philox' draws the initial parameters from the device generator
   (`bnf_init_params`) and shuffles with the device's keyed Feistel permutation (no index arrays).
 
   Returns (params, losses): params is a StructTuple whose leaves have shape
@@ -163,7 +164,13 @@ def fit_vi(features, target, seed, observation_model, model_args, ensemble_size,
   """Fit mean-field surrogates.  Returns (surrogate, losses, predictions):
   losses (num_devices, E/num_devices, num_epochs) already multiplied by
   kl_weight; predictions = StructTuple of posterior draws with leaves
-  (num_devices, sample_size_posterior, E/num_devices, *leaf_shape)."""
+  (num_devices, sample_size_posterior, E/num_devices, *leaf_shape).
+
+  init_rng='jax' (default): initial surrogate means, optimisation noise and posterior draws are the reference's own for
+  `seed` (pinned by its VI golden: 2 full-batch steps; longer fits extrapolate the same key recurrence).  With `batch_size`
+  the one row permutation every step shares between the device's members is the reference's too as far as its source shows
+  it (inference.py:704-709) -- UNPINNED by any golden and resting on one stated assumption about tfp
+  (jaxseed.vi_batch_subkeys); 'philox': the device generator throughout (same law, other numbers)."""
   net = _net_from_args(model_args, observation_model)
   init_rng = init_rng or os.environ.get('BNF_INIT_RNG', 'jax')
   if init_rng not in ('jax', 'philox'):
