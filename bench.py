@@ -555,7 +555,7 @@ def run_rank(args, rank, device, E, data, sync):
 
 
 def side_dtype_lines(args, device, E, X, y, input_scales, flops_step):
-  """After the timed region, N = 1 only: the same C2 step under the engine's other arithmetics, short runs (3 warm-up + 10
+  """After the timed region, N = 1 only: the same C2 step under the engine's other arithmetics, short runs (8 warm-up + 20
   timed steps each, a fresh engine, the device already warm) -- reported beside the headline, never as it: 'fp8' (BASELINE
   configs[4]'s arithmetic: fp8 MFMA contractions + fp8 operand storage) and 'fp32_split' (what the estimators run when no
   compute_dtype is given)."""
@@ -571,15 +571,15 @@ def side_dtype_lines(args, device, E, X, y, input_scales, flops_step):
       eng = Engine(net, mode='map', X=X, y=y, members=E, seed=0, learning_rate=0.005, prior_weight=1.0, compute_dtype=dt,
                    device_index=device.index)
       eng.init_params(float(np.log(np.nanstd(y) / 2)))
-      eng.train(0, 3)
+      eng.train(0, 8)
       torch.cuda.synchronize(device)
       t0 = time.perf_counter()
-      eng.train(3, 10)
+      eng.train(8, 20)
       torch.cuda.synchronize(device)
       dt_s = time.perf_counter() - t0
       eng.close()
-      out[dt] = {'ms_per_step': dt_s * 1e3 / 10, 'member_steps_per_s': E * 10 / dt_s, 'steps': 10,
-                 'algorithmic_tflops': flops_step * 10 / dt_s / 1e12}
+      out[dt] = {'ms_per_step': dt_s * 1e3 / 20, 'member_steps_per_s': E * 20 / dt_s, 'steps': 20,
+                 'algorithmic_tflops': flops_step * 20 / dt_s / 1e12}
     except Exception as exc:   # pylint: disable=broad-except
       out[dt] = {'error': f'{type(exc).__name__}: {exc}'[:200]}
   return out
