@@ -1,7 +1,12 @@
 """One step of the fp8 engine (fp8 W x W contractions + fp8 copies) against the bf16 step on the same parameters: loss, network
 output, the H_1 / dZ_1 / dZ_0 copies and every gradient leaf (max / rms differences, correlation).  GPU diagnostic."""
-import sys, numpy as np
-from tests import util
+import sys
+
+import numpy as np
+
+sys.path.insert(0, '.')
+from bayesnf_amd.engine import Engine     # noqa: E402
+from tests import util                    # noqa: E402
 net, model, X, y = util.make_problem(n_rows=700, width=512, depth=2)
 E = 3
 theta = util.random_theta(model, E, scale=0.3)
