@@ -50,11 +50,13 @@ enum {
 };
 
 enum { BNF_DTYPE_F32 = 0, BNF_DTYPE_BF16 = 1,   /* arithmetic of the dense contractions; accumulation is always f32 */
-       /* BASELINE.json configs[4] ("fp8 MFMA dense layers"): the bf16 row-panel pipeline with FP8 OPERAND STORAGE for the
-        * weight-gradient contractions -- the activation copies H_l leave as OCP e4m3, the backward signals dZ_l as OCP
-        * e5m2 over a per-member power of two, and dK_l = H_l^T dZ_l runs on the non-scaled fp8 MFMA; forward and
-        * backward-data contractions stay bf16.  Needs the row-panel pipeline (depth >= 2, padded width 256 / 512 / 1024,
-        * <= 128 padded features): bnf_create refuses other shapes. */
+       /* BASELINE.json configs[4] ("fp8 MFMA dense layers"): the row-panel pipeline with (round 5) FP8 OPERAND STORAGE for
+        * the weight-gradient contractions -- the activation copies H_l leave as OCP e4m3, the backward signals dZ_l as OCP
+        * e5m2 over a per-member power of two, and dK_l = H_l^T dZ_l runs on the fp8 MFMA -- and (round 6, the folded forms:
+        * F + 2 <= padded feature count, i.e. every BASELINE layout) the W x W FORWARD and BACKWARD-DATA contractions on the
+        * block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) out of fp8 panels in LDS, weights as e4m3 x 2^5; layer 0
+        * and its backward-data stay bf16 (env BNF_FP8_CONTRACT=0 at bnf_create: storage only).  Needs the row-panel pipeline
+        * (depth >= 2, padded width 256 / 512 / 1024, <= 128 padded features): bnf_create refuses other shapes. */
        BNF_DTYPE_FP8 = 2,
        /* f32 storage, accumulation and epilogues like BNF_DTYPE_F32, but the contractions run on SPLIT-bf16 MFMAs: every f32
         * operand is split in registers into two bf16 pieces (16 operand bits) and hi*hi + hi*lo + lo*hi are summed by three
