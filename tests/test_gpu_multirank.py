@@ -106,6 +106,12 @@ def test_one_process_two_gpus_gathers_through_the_rccl_group(monkeypatch, golden
   lp, mp, notep = fit('0,1', 'peer')
   assert notep.get('impl') == 'peer-copies'
   l1, m1, _ = fit('0', 'rccl')
+  # the DEFAULT (round 6): the collective once the device set has passed its time-limited first-use check
+  distributed._group_verdict.clear()
+  la, ma, notea = fit('0,1', 'auto')
+  assert notea.get('impl') == 'rccl-group' and notea['check']['ok'] is True, notea
+  np.testing.assert_array_equal(la, l2)
+  np.testing.assert_array_equal(ma, m2)
   np.testing.assert_array_equal(l2, lp)
   np.testing.assert_array_equal(m2, mp)
   np.testing.assert_allclose(l2, l1, rtol=1e-5)
